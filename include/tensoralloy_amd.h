@@ -1,0 +1,195 @@
+/*
+ * tensoralloy_amd.h — C ABI of libtensoralloy_amd.so (MI355X / gfx950 only).
+ *
+ * The reference (Bismarrck/tensoralloy) has NO native plugin ABI: its hot path
+ * is a frozen TensorFlow-1 graph executed by `Session.run`
+ * (tensoralloy/calculator.py:335-370). This library is what sits UNDER the
+ * reference's two Python surfaces instead of that graph:
+ *
+ *   tensoralloy/calculator.py:31-383      TensorAlloyCalculator.calculate
+ *   tensoralloy/transformer/universal.py  UniversalTransformer (feed dict)
+ *
+ * Each entry point below names the reference interface it replaces. All
+ * buffers are caller-owned, C-contiguous; the library copies host->device and
+ * never keeps a host pointer after the call returns. A handle owns one device
+ * and one HIP stream; a handle is not thread-safe, different handles may be
+ * used from different threads. Every function returns TA_OK (0) or a negative
+ * error code; `ta_last_error` gives the message.
+ *
+ * There is no CPU fallback: without a gfx950 device `ta_create` fails with
+ * TA_ERR_HIP.
+ */
+#ifndef TENSORALLOY_AMD_H
+#define TENSORALLOY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ta_context *ta_handle;
+
+enum {
+  TA_OK = 0,
+  TA_ERR_INVALID = -1,     /* bad argument / inconsistent model  -> ValueError  */
+  TA_ERR_UNSUPPORTED = -2, /* model feature not implemented      -> ValueError  */
+  TA_ERR_HIP = -3,         /* HIP runtime failure / no device    -> RuntimeError */
+  TA_ERR_NOMEM = -4
+};
+
+/* `want` bits of ta_compute / ta_eval: which outputs of
+ * tensoralloy/nn/basic.py:679-787 (`BasicNN.build`) are produced. */
+enum {
+  TA_WANT_ENERGY = 1,      /* Output/Energy/energy     atomic.py:289-302        */
+  TA_WANT_FORCES = 2,      /* Output/Forces/forces     basic.py:277-290         */
+  TA_WANT_VIRIAL = 4,      /* Output/Stress (virial)   basic.py:293-331         */
+  TA_WANT_ATOMIC = 8,      /* Output/Energy/atomic     atomic.py:289-299        */
+  TA_WANT_DESCRIPTORS = 16 /* Atomic/<El> descriptors  sf.py:184-215 (debug)    */
+};
+
+enum { TA_MODEL_SF_MLP = 1, TA_MODEL_EAM_ALLOY = 2, TA_MODEL_EAM_ADP = 3 };
+enum { TA_CUTOFF_COSINE = 0, TA_CUTOFF_POLYNOMIAL = 1 }; /* nn/cutoff.py:20-85 */
+
+/* activation ids follow `actfn_map` of atomic.py:323 for 0..3 */
+enum {
+  TA_ACT_RELU = 0, TA_ACT_SOFTPLUS = 1, TA_ACT_TANH = 2, TA_ACT_SQUAREPLUS = 3,
+  TA_ACT_LEAKY_RELU = 4, TA_ACT_SIGMOID = 5, TA_ACT_SOFTSIGN = 6, TA_ACT_ELU = 7
+};
+
+/*
+ * Model description = what `BasicNN.export` bakes into the frozen graph
+ * (basic.py:1075-1092): `UniversalTransformer.as_dict()` (universal.py:323-331),
+ * `SymmetryFunction.as_dict()` (sf.py:58-68), `AtomicNN.as_dict()`
+ * (atomic.py:116-132) and the variables `Atomic/<El>/Conv1d{j}/{kernel,bias}`,
+ * `Atomic/<El>/Output/{kernel,bias}`, `Atomic/<El>/MinMax/{xlo,xhi}`.
+ * Elements are the SORTED unique symbols (utils.py:262); species indices in
+ * frames index this list.
+ */
+typedef struct {
+  int32_t kind;            /* TA_MODEL_*                                        */
+  int32_t n_elements;
+  double rcut;             /* UniversalTransformer.rcut                          */
+  double acut;             /* UniversalTransformer.acut (== rcut if not angular) */
+  int32_t angular;         /* G4 terms present                                   */
+  int32_t cutoff_function; /* TA_CUTOFF_*                                        */
+
+  /* SymmetryFunction parameter axes; grids are eta x omega (omega fastest) and
+   * beta x gamma x zeta (zeta fastest), sf.py:47-51. */
+  int32_t n_eta, n_omega, n_beta, n_gamma, n_zeta;
+  const double *eta, *omega, *beta, *gamma, *zeta;
+
+  /* per-element MLP (convolution1x1, convolutional.py:154-300) */
+  int32_t activation;      /* TA_ACT_*                                           */
+  int32_t use_resnet_dt;
+  int32_t minmax_scale;    /* atomic.py:157-195                                  */
+  const int32_t *n_layers; /* [n_elements] dense layers incl. the output layer   */
+  const int32_t *layer_sizes; /* per element [in, h1, ..., 1], concatenated      */
+  const double *weights;   /* per element, per layer: W[in][out] row-major, then
+                              b[out] (zeros when the layer has no bias)          */
+  const double *xlo, *xhi; /* [n_elements * in] when minmax_scale, else NULL     */
+
+  /* EAM / ADP analytic potentials (nn/eam/potentials/zjw04.py, mishin.py):
+   * flat parameter blocks, layout documented in tensoralloy_amd/eam.py */
+  int32_t n_eam_params;
+  const double *eam_params;
+} ta_model_desc;
+
+/* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`
+ * (universal.py:851-893) receives: an `ase.Atoms`. Atom order is the caller's
+ * (ASE) order; the GSL/VAP permutation (vap.py:26-137) is applied by the
+ * Python boundary, not here. */
+typedef struct {
+  int32_t n_atoms;
+  const int32_t *species;  /* [n_atoms] index into the sorted element list       */
+  const double *positions; /* [n_atoms][3] Angstrom                              */
+  const double *cell;      /* [3][3] row-major lattice vectors                   */
+  const int32_t *pbc;      /* [3]                                                */
+} ta_frame;
+
+typedef struct {
+  int32_t n_frames;
+  int64_t n_atoms;         /* total over frames                                  */
+  int64_t n_pairs;         /* directed pairs within max(rcut, acut)  (= nij)     */
+  int64_t n_triples;       /* sum_i n_i (n_i - 1) / 2               (= nijk)     */
+  int32_t nnl_max;         /* max neighbours of one centre                       */
+  int32_t descriptor_dim;  /* D per atom                                         */
+} ta_batch_info;
+
+/* number of kernel-timing slots filled by ta_time_compute */
+#define TA_N_KERNEL_SLOTS 8
+/* slot ids */
+enum {
+  TA_K_PAIR_GEOMETRY = 0, TA_K_G4_FORWARD = 1, TA_K_DESCRIPTOR_REDUCE = 2,
+  TA_K_MLP = 3, TA_K_BACKWARD = 4, TA_K_FORCE_GATHER = 5, TA_K_FRAME_REDUCE = 6,
+  TA_K_EAM = 7
+};
+
+int ta_device_count(void);
+
+/* replaces TensorAlloyCalculator.__init__ graph import + Session creation
+ * (calculator.py:40-87): validates the model, uploads weights to `device`. */
+int ta_create(const ta_model_desc *model, int device, ta_handle *out);
+int ta_destroy(ta_handle h);
+const char *ta_last_error(ta_handle h); /* h may be NULL: last create error */
+
+/* replaces UniversalTransformer.get_np_feed_dict (universal.py:851-893):
+ * neighbour list (ASE `neighbor_list('ijS')` semantics, universal.py:58),
+ * pair buffers sorted by centre, reverse-pair index; uploads everything so the
+ * batch is resident in HBM. Frames are independent units. */
+int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames,
+                  ta_batch_info *info);
+
+/* new positions/cells for the resident batch, same neighbour topology is NOT
+ * assumed: the list is rebuilt (equivalent to ta_set_frames). */
+
+/* replaces Session.run(ops, feed_dict) (calculator.py:368): enqueues the
+ * kernels on the handle's stream; asynchronous. */
+int ta_compute(ta_handle h, uint32_t want);
+
+/* copies results device->host and synchronises. Any pointer may be NULL.
+ *   energy      [n_frames]            eV
+ *   forces      [n_atoms_total][3]    eV/A        (caller's atom order)
+ *   virial      [n_frames][9]         eV, W_ab = sum_pairs dE/dD_a * D_b
+ *   atomic      [n_atoms_total]       eV
+ *   descriptors [n_atoms_total][D]    raw G (before min-max)             */
+int ta_get_results(ta_handle h, double *energy, double *forces, double *virial,
+                   double *atomic, double *descriptors);
+
+/* ta_set_frames + ta_compute + ta_get_results */
+int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want,
+            double *energy, double *forces, double *virial, double *atomic);
+
+/* blocks until the handle's stream is idle */
+int ta_synchronize(ta_handle h);
+
+/* Measurement (bench.py): runs `warmup` untimed then `steps` timed passes of
+ * ta_compute over the resident batch, timed with HIP events on the handle's
+ * stream. total_ms = wall of the `steps` passes; kernel_ms[k] (may be NULL) =
+ * average duration per pass of kernel slot k, measured in a second run with
+ * events around every launch. */
+int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
+                    double *total_ms, double *kernel_ms /*[TA_N_KERNEL_SLOTS]*/);
+
+/* sum of the resident batch's frame energies, left on the device for a
+ * collective: returns a device pointer to one double (valid until destroy). */
+int ta_batch_energy_device_ptr(ta_handle h, void **dptr);
+
+/* debugging / parity: host copy of the pair list of the resident batch
+ * (centre, neighbour, shift[3]) in the library's order. Arrays sized n_pairs. */
+int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift /*[n][3]*/);
+
+/* Host-only (no GPU needed): the neighbour list the library builds for one
+ * frame, i.e. `ase.neighborlist.neighbor_list('ijS', atoms, rc)` as called at
+ * transformer/universal.py:58, sorted by centre then neighbour species then
+ * distance. Output arrays are malloc'ed by the library; release with ta_free.
+ * rev[p] = index of the reverse pair (j -> i, -S). */
+int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64_t *n_pairs,
+                     int32_t **i, int32_t **j, int32_t **shift /*[n][3]*/, int32_t **rev);
+void ta_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSORALLOY_AMD_H */

@@ -1,0 +1,187 @@
+"""
+ctypes binding of `libtensoralloy_amd.so` (C ABI: include/tensoralloy_amd.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises — there is no Python/NumPy fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+CSRC_DIR = PKG_DIR / "csrc"
+INCLUDE_DIR = REPO_DIR / "include"
+LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
+
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_mlp.hip", "ta_eam.hip", "ta_neighbor.cpp"]
+
+TA_OK = 0
+TA_ERR_INVALID, TA_ERR_UNSUPPORTED, TA_ERR_HIP, TA_ERR_NOMEM = -1, -2, -3, -4
+TA_WANT_ENERGY, TA_WANT_FORCES, TA_WANT_VIRIAL, TA_WANT_ATOMIC, TA_WANT_DESCRIPTORS = 1, 2, 4, 8, 16
+TA_MODEL_SF_MLP, TA_MODEL_EAM_ALLOY, TA_MODEL_EAM_ADP = 1, 2, 3
+TA_CUTOFF = {"cosine": 0, "polynomial": 1}
+TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
+          "sigmoid": 5, "softsign": 6, "elu": 7}
+TA_N_KERNEL_SLOTS = 8
+KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
+                "force_gather", "frame_reduce", "eam"]
+
+# every symbol include/tensoralloy_amd.h declares
+EXPORTED_SYMBOLS = [
+    "ta_device_count", "ta_create", "ta_destroy", "ta_last_error", "ta_set_frames",
+    "ta_compute", "ta_get_results", "ta_eval", "ta_synchronize", "ta_time_compute",
+    "ta_batch_energy_device_ptr", "ta_get_pairs", "ta_neighbor_list", "ta_free",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n_elements", C.c_int32),
+        ("rcut", C.c_double), ("acut", C.c_double),
+        ("angular", C.c_int32), ("cutoff_function", C.c_int32),
+        ("n_eta", C.c_int32), ("n_omega", C.c_int32), ("n_beta", C.c_int32),
+        ("n_gamma", C.c_int32), ("n_zeta", C.c_int32),
+        ("eta", _dp), ("omega", _dp), ("beta", _dp), ("gamma", _dp), ("zeta", _dp),
+        ("activation", C.c_int32), ("use_resnet_dt", C.c_int32), ("minmax_scale", C.c_int32),
+        ("n_layers", _ip), ("layer_sizes", _ip), ("weights", _dp),
+        ("xlo", _dp), ("xhi", _dp),
+        ("n_eam_params", C.c_int32), ("eam_params", _dp),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [("n_atoms", C.c_int32), ("species", _ip), ("positions", _dp),
+                ("cell", _dp), ("pbc", _ip)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_atoms", C.c_int64), ("n_pairs", C.c_int64),
+                ("n_triples", C.c_int64), ("nnl_max", C.c_int32), ("descriptor_dim", C.c_int32)]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into the in-tree shared library."""
+    srcs = [CSRC_DIR / s for s in SOURCES]
+    deps = srcs + list(CSRC_DIR.glob("*.h")) + [INCLUDE_DIR / "tensoralloy_amd.h"]
+    if not force and LIB_PATH.exists():
+        newest = max(p.stat().st_mtime for p in deps)
+        if LIB_PATH.stat().st_mtime >= newest:
+            return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + [str(s) for s in srcs] + \
+          ["-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    H = C.c_void_p
+    lib.ta_device_count.restype = C.c_int
+    lib.ta_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(H)]
+    lib.ta_destroy.argtypes = [H]
+    lib.ta_last_error.argtypes = [H]
+    lib.ta_last_error.restype = C.c_char_p
+    lib.ta_set_frames.argtypes = [H, C.c_int32, C.POINTER(Frame), C.POINTER(BatchInfo)]
+    lib.ta_compute.argtypes = [H, C.c_uint32]
+    lib.ta_get_results.argtypes = [H, _dp, _dp, _dp, _dp, _dp]
+    lib.ta_eval.argtypes = [H, C.c_int32, C.POINTER(Frame), C.c_uint32, _dp, _dp, _dp, _dp]
+    lib.ta_synchronize.argtypes = [H]
+    lib.ta_time_compute.argtypes = [H, C.c_uint32, C.c_int32, C.c_int32, _dp, _dp]
+    lib.ta_batch_energy_device_ptr.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.ta_get_pairs.argtypes = [H, _ip, _ip, _ip]
+    lib.ta_neighbor_list.argtypes = [C.POINTER(Frame), C.c_int32, C.c_double,
+                                     C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),
+                                     C.POINTER(_ip), C.POINTER(_ip)]
+    lib.ta_free.argtypes = [C.c_void_p]
+    lib.ta_free.restype = None
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc):
+    """Map C error codes to the exceptions the reference raises for this path."""
+    if rc == TA_OK:
+        return
+    msg = lib.ta_last_error(handle)
+    msg = msg.decode("utf-8", "replace") if msg else f"error {rc}"
+    if rc in (TA_ERR_INVALID, TA_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    if rc == TA_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def as_dp(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def as_ip(a: np.ndarray):
+    return a.ctypes.data_as(_ip)
+
+
+class FrameArrays:
+    """Keeps the NumPy arrays behind a `Frame` alive."""
+
+    def __init__(self, species, positions, cell, pbc):
+        self.species = np.ascontiguousarray(species, dtype=np.int32)
+        self.positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        self.cell = np.ascontiguousarray(cell, dtype=np.float64).reshape(3, 3)
+        self.pbc = np.ascontiguousarray(np.asarray(pbc).astype(bool), dtype=np.int32).reshape(3)
+        if len(self.species) != len(self.positions):
+            raise ValueError("species and positions disagree on the number of atoms")
+
+    def as_struct(self) -> Frame:
+        return Frame(len(self.species), as_ip(self.species), as_dp(self.positions),
+                     as_dp(self.cell), as_ip(self.pbc))
+
+
+def neighbor_list(species, positions, cell, pbc, n_elements, rc):
+    """Host-only neighbour list of the library (no GPU needed)."""
+    lib = load()
+    fa = FrameArrays(species, positions, cell, pbc)
+    fr = fa.as_struct()
+    n = C.c_int64(0)
+    pi, pj, ps, pr = _ip(), _ip(), _ip(), _ip()
+    rc_ = lib.ta_neighbor_list(C.byref(fr), n_elements, float(rc), C.byref(n), C.byref(pi),
+                               C.byref(pj), C.byref(ps), C.byref(pr))
+    check(lib, None, rc_)
+    P = n.value
+    try:
+        i = np.ctypeslib.as_array(pi, shape=(max(P, 1),))[:P].copy()
+        j = np.ctypeslib.as_array(pj, shape=(max(P, 1),))[:P].copy()
+        s = np.ctypeslib.as_array(ps, shape=(max(3 * P, 1),))[:3 * P].copy().reshape(-1, 3)
+        r = np.ctypeslib.as_array(pr, shape=(max(P, 1),))[:P].copy()
+    finally:
+        for p in (pi, pj, ps, pr):
+            lib.ta_free(p)
+    return i, j, s, r

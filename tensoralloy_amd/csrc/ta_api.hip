@@ -1,0 +1,675 @@
+// C ABI of libtensoralloy_amd.so: context, device memory, launch sequencing.
+// Declarations and the reference interfaces they replace: include/tensoralloy_amd.h
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ta_device.h"
+#include "ta_internal.h"
+
+namespace ta {
+size_t mlp_scratch_doubles(const MlpDev &mlp);
+void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
+                     const DeviceBatch &b, double *scratch, hipStream_t s);
+// EAM / ADP (ta_eam.hip)
+struct EamModel;
+EamModel *eam_create(const ta_model_desc *m, std::string &err);
+void eam_destroy(EamModel *);
+void eam_ensure(EamModel *, const DeviceBatch &b);
+void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
+                 hipEvent_t *ev /* 2 events or null */);
+}  // namespace ta
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                     std::to_string(__LINE__) + ")");                                        \
+  } while (0)
+
+// grow-only device buffer
+template <typename T>
+struct DevBuf {
+  T *ptr = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (ptr) HIP_CHECK(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    HIP_CHECK(hipMalloc((void **)&ptr, want * sizeof(T)));
+    cap = want;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct ChunkPlan {
+  ta::AngChunk ch;
+  int nb, ng, nz;
+};
+
+}  // namespace
+
+struct ta_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int kind = 0;
+  int n_elements = 0;
+  int activation = 0;
+  double rmax = 0.0;
+  ta::SFParams sf;
+  std::vector<ChunkPlan> chunks;
+  ta::MlpDev mlp[ta::kMaxElements];
+  std::vector<void *> model_allocs;
+  ta::EamModel *eam = nullptr;
+
+  ta::HostPairs hp;
+  ta::DeviceBatch db;
+  bool have_batch = false;
+  uint32_t last_want = 0;
+
+  DevBuf<double> pos, cells, rec, part4, G, dEdG, eatom, g, forces, wat, energy, virial, benergy,
+      mlp_scratch;
+  DevBuf<int32_t> species, frame_of_atom, atom_start, pair_start, seg_start, pair_i, pair_j,
+      pair_shift, pair_rev, elem_atoms;
+
+  hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
+  std::string err;
+};
+
+namespace {
+
+int fail(ta_context *h, int code, const std::string &msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+template <typename T>
+T *upload(ta_context *h, const std::vector<T> &v) {
+  T *d = nullptr;
+  size_t n = v.size() ? v.size() : 1;
+  HIP_CHECK(hipMalloc((void **)&d, n * sizeof(T)));
+  h->model_allocs.push_back(d);
+  if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+void build_sf_model(ta_context *h, const ta_model_desc *m) {
+  using namespace ta;
+  SFParams &sf = h->sf;
+  std::memset(&sf, 0, sizeof(sf));
+  const int nel = m->n_elements;
+  if (m->n_eta < 1 || m->n_omega < 1 || !m->eta || !m->omega)
+    throw std::invalid_argument("eta / omega must be non-empty");
+  if (m->n_eta * m->n_omega > kMaxRadial)
+    throw std::domain_error("more than 64 radial (eta x omega) combinations");
+  if (!(m->rcut > 0.0)) throw std::invalid_argument("rcut must be positive");
+  sf.rcut = m->rcut;
+  sf.acut = m->angular ? m->acut : m->rcut;
+  if (m->angular && !(m->acut > 0.0)) throw std::invalid_argument("acut must be positive");
+  sf.inv_rc2 = 1.0 / (sf.rcut * sf.rcut);
+  sf.inv_ac2 = 1.0 / (sf.acut * sf.acut);
+  sf.eps = 1e-14;  // Precision.high eps, reference precision.py:113
+  sf.n_elements = nel;
+  sf.n_rad = m->n_eta * m->n_omega;
+  sf.angular = m->angular ? 1 : 0;
+  sf.cutoff = m->cutoff_function;
+  if (sf.cutoff != TA_CUTOFF_COSINE && sf.cutoff != TA_CUTOFF_POLYNOMIAL)
+    throw std::invalid_argument("unknown cutoff function");
+  // ParameterGrid order: eta outer, omega fastest (sf.py:47-48)
+  for (int e = 0; e < m->n_eta; ++e)
+    for (int o = 0; o < m->n_omega; ++o) {
+      sf.eta[e * m->n_omega + o] = m->eta[e];
+      sf.omega[e * m->n_omega + o] = m->omega[o];
+    }
+  sf.n_radial_dim = nel * sf.n_rad;
+  sf.n_ang = 0;
+  sf.n_beta = 0;
+  if (m->angular) {
+    if (m->n_beta < 1 || m->n_gamma < 1 || m->n_zeta < 1 || !m->beta || !m->gamma || !m->zeta)
+      throw std::invalid_argument("beta / gamma / zeta must be non-empty for an angular model");
+    if (m->n_beta > kMaxBetaSlots)
+      throw std::domain_error("more than 3 beta values are not supported by the pair record");
+    sf.n_beta = m->n_beta;
+    for (int k = 0; k < m->n_beta; ++k) sf.beta[k] = m->beta[k];
+    sf.n_ang = m->n_beta * m->n_gamma * m->n_zeta;
+    // channel (ib, ig, iz) -> (ib * n_gamma + ig) * n_zeta + iz  (zeta fastest, sf.py:49-51)
+    for (int b0 = 0; b0 < m->n_beta; b0 += 2)
+      for (int g0 = 0; g0 < m->n_gamma; g0 += 2)
+        for (int z0 = 0; z0 < m->n_zeta; z0 += 2) {
+          ChunkPlan cp;
+          std::memset(&cp, 0, sizeof(cp));
+          cp.nb = std::min(2, m->n_beta - b0);
+          cp.ng = std::min(2, m->n_gamma - g0);
+          cp.nz = std::min(2, m->n_zeta - z0);
+          for (int ib = 0; ib < cp.nb; ++ib) {
+            cp.ch.beta[ib] = m->beta[b0 + ib];
+            cp.ch.hslot[ib] = b0 + ib;
+          }
+          for (int ig = 0; ig < cp.ng; ++ig) cp.ch.gamma[ig] = m->gamma[g0 + ig];
+          for (int iz = 0; iz < cp.nz; ++iz) {
+            const double z = m->zeta[z0 + iz];
+            cp.ch.zeta[iz] = z;
+            cp.ch.kz[iz] = std::pow(2.0, 1.0 - z);
+            const double zr = std::nearbyint(z);
+            cp.ch.zeta_int[iz] = (zr == z && z >= 1.0 && z <= 1024.0) ? (int)zr : -1;
+          }
+          for (int ib = 0; ib < cp.nb; ++ib)
+            for (int ig = 0; ig < cp.ng; ++ig)
+              for (int iz = 0; iz < cp.nz; ++iz)
+                cp.ch.chan[(ib * cp.ng + ig) * cp.nz + iz] =
+                    ((b0 + ib) * m->n_gamma + (g0 + ig)) * m->n_zeta + (z0 + iz);
+          h->chunks.push_back(cp);
+        }
+  }
+  const int n_aterms = m->angular ? nel * (nel + 1) / 2 : 0;
+  sf.ndim = sf.n_radial_dim + n_aterms * sf.n_ang;
+  h->rmax = std::max(sf.rcut, sf.acut);
+
+  // MLP weights
+  if (!m->n_layers || !m->layer_sizes || !m->weights)
+    throw std::invalid_argument("MLP description missing");
+  h->activation = m->activation;
+  if (m->activation < 0 || m->activation > TA_ACT_ELU)
+    throw std::invalid_argument("unknown activation");
+  const int32_t *sizes = m->layer_sizes;
+  const double *wsrc = m->weights;
+  for (int el = 0; el < nel; ++el) {
+    MlpDev &md = h->mlp[el];
+    const int L = m->n_layers[el];
+    if (L < 1 || L > kMaxLayers) throw std::domain_error("MLP depth out of range (1..8 layers)");
+    if (sizes[0] != sf.ndim)
+      throw std::invalid_argument("MLP input size does not match the descriptor length");
+    if (sizes[L] != 1) throw std::invalid_argument("MLP output size must be 1");
+    md.n_layers = L;
+    md.max_np = md.max_kp = 0;
+    for (int l = 0; l < L; ++l) {
+      MlpLayerDev &ly = md.layer[l];
+      ly.k = sizes[l];
+      ly.n = sizes[l + 1];
+      if (ly.k < 1 || ly.n < 1 || ly.k > 512 || ly.n > 512)
+        throw std::domain_error("MLP layer width out of range (1..512)");
+      ly.kp = round_up(ly.k, 16);
+      ly.np = round_up(ly.n, 16);
+      ly.act = (l < L - 1) ? 1 : 0;
+      // ResNet skip: hidden layer j > 0 with equal widths (convolutional.py:272)
+      ly.res = (m->use_resnet_dt && l > 0 && l < L - 1 && ly.k == ly.n) ? 1 : 0;
+      std::vector<double> w((size_t)ly.kp * ly.np, 0.0), wt((size_t)ly.np * ly.kp, 0.0),
+          bb(ly.np, 0.0);
+      for (int k = 0; k < ly.k; ++k)
+        for (int n = 0; n < ly.n; ++n) {
+          const double v = wsrc[(size_t)k * ly.n + n];
+          w[(size_t)k * ly.np + n] = v;
+          wt[(size_t)n * ly.kp + k] = v;
+        }
+      wsrc += (size_t)ly.k * ly.n;
+      for (int n = 0; n < ly.n; ++n) bb[n] = wsrc[n];
+      wsrc += ly.n;
+      ly.w = upload(h, w);
+      ly.wt = upload(h, wt);
+      ly.b = upload(h, bb);
+      md.max_np = std::max(md.max_np, ly.np);
+      md.max_kp = std::max(md.max_kp, ly.kp);
+    }
+    if (m->minmax_scale) {
+      if (!m->xlo || !m->xhi) throw std::invalid_argument("minmax_scale set but xlo/xhi missing");
+      std::vector<double> lo(m->xlo + (size_t)el * sf.ndim, m->xlo + (size_t)(el + 1) * sf.ndim);
+      std::vector<double> hi(m->xhi + (size_t)el * sf.ndim, m->xhi + (size_t)(el + 1) * sf.ndim);
+      md.xlo = upload(h, lo);
+      md.xhi = upload(h, hi);
+    }
+    sizes += L + 1;
+  }
+}
+
+void upload_batch(ta_context *h) {
+  using namespace ta;
+  HostPairs &hp = h->hp;
+  DeviceBatch &db = h->db;
+  const size_t N = (size_t)hp.n_atoms, P = (size_t)hp.n_pairs;
+  const int nel = h->n_elements;
+  const int F = (int)hp.atom_start.size() - 1;
+  db.n_atoms = hp.n_atoms;
+  db.n_pairs = hp.n_pairs;
+  db.n_frames = F;
+  db.nnl_max = hp.nnl_max;
+
+  auto put = [&](auto &buf, const auto &vec) {
+    buf.ensure(vec.size());
+    if (!vec.empty())
+      HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
+                               hipMemcpyHostToDevice, h->stream));
+  };
+  put(h->frame_of_atom, hp.frame_of_atom);
+  put(h->atom_start, hp.atom_start);
+  put(h->pair_start, hp.pair_start);
+  put(h->seg_start, hp.seg_start);
+  put(h->pair_i, hp.pair_i);
+  put(h->pair_j, hp.pair_j);
+  put(h->pair_shift, hp.pair_shift);
+  put(h->pair_rev, hp.pair_rev);
+
+  const int D = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 1;
+  h->rec.ensure(P * kRecDoubles);
+  if (h->kind == TA_MODEL_SF_MLP && h->sf.angular) h->part4.ensure((size_t)nel * h->sf.n_ang * P);
+  h->G.ensure(N * D);
+  h->dEdG.ensure(N * D);
+  h->eatom.ensure(N);
+  h->g.ensure(3 * P);
+  h->forces.ensure(3 * N);
+  h->wat.ensure(9 * N);
+  h->energy.ensure(F);
+  h->virial.ensure(9 * (size_t)F);
+  h->benergy.ensure(1);
+
+  db.frame_of_atom = h->frame_of_atom.ptr;
+  db.atom_start = h->atom_start.ptr;
+  db.pair_start = h->pair_start.ptr;
+  db.seg_start = h->seg_start.ptr;
+  db.pair_i = h->pair_i.ptr;
+  db.pair_j = h->pair_j.ptr;
+  db.pair_shift = h->pair_shift.ptr;
+  db.pair_rev = h->pair_rev.ptr;
+  db.rec = h->rec.ptr;
+  db.part4 = h->part4.ptr;
+  db.G = h->G.ptr;
+  db.dEdG = h->dEdG.ptr;
+  db.eatom = h->eatom.ptr;
+  db.g = h->g.ptr;
+  db.forces = h->forces.ptr;
+  db.wat = h->wat.ptr;
+  db.energy = h->energy.ptr;
+  db.virial = h->virial.ptr;
+  db.batch_energy = h->benergy.ptr;
+}
+
+void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
+  using namespace ta;
+  const DeviceBatch &db = h->db;
+  hipStream_t s = h->stream;
+  const bool need_forces = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
+  auto begin = [&](int slot) {
+    if (timed) HIP_CHECK(hipEventRecord(h->ev[2 * slot], s));
+  };
+  auto end = [&](int slot) {
+    if (timed) HIP_CHECK(hipEventRecord(h->ev[2 * slot + 1], s));
+  };
+  bool used[TA_N_KERNEL_SLOTS] = {false};
+
+  if (h->kind == TA_MODEL_SF_MLP) {
+    begin(TA_K_PAIR_GEOMETRY);
+    launch_pair_geometry(h->sf, db, s);
+    end(TA_K_PAIR_GEOMETRY);
+    used[TA_K_PAIR_GEOMETRY] = true;
+    if (h->sf.angular) {
+      begin(TA_K_G4_FORWARD);
+      for (const ChunkPlan &cp : h->chunks) launch_g4_forward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, db, s);
+      end(TA_K_G4_FORWARD);
+      used[TA_K_G4_FORWARD] = true;
+    }
+    begin(TA_K_DESCRIPTOR_REDUCE);
+    launch_descriptor_reduce(h->sf, db, s);
+    end(TA_K_DESCRIPTOR_REDUCE);
+    used[TA_K_DESCRIPTOR_REDUCE] = true;
+    begin(TA_K_MLP);
+    for (int el = 0; el < h->n_elements; ++el) {
+      const int n_el = db.elem_start[el + 1] - db.elem_start[el];
+      launch_mlp_impl(h->mlp[el], h->activation, h->sf.ndim, db.elem_atoms + db.elem_start[el], n_el,
+                      db, h->mlp_scratch.ptr, s);
+    }
+    end(TA_K_MLP);
+    used[TA_K_MLP] = true;
+    if (need_forces) {
+      begin(TA_K_BACKWARD);
+      if (h->sf.angular) {
+        bool first = true;
+        for (const ChunkPlan &cp : h->chunks) {
+          launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
+          first = false;
+        }
+      } else {
+        AngChunk dummy;
+        std::memset(&dummy, 0, sizeof(dummy));
+        launch_backward(h->sf, dummy, 1, 1, 1, true, true, db, s);
+      }
+      end(TA_K_BACKWARD);
+      used[TA_K_BACKWARD] = true;
+      begin(TA_K_FORCE_GATHER);
+      launch_force_gather(h->sf, db, s);
+      end(TA_K_FORCE_GATHER);
+      used[TA_K_FORCE_GATHER] = true;
+    }
+  } else {
+    begin(TA_K_EAM);
+    eam_compute(h->eam, db, want, s, nullptr);
+    end(TA_K_EAM);
+    used[TA_K_EAM] = true;
+  }
+  begin(TA_K_FRAME_REDUCE);
+  launch_frame_reduce(db, need_forces, s);
+  end(TA_K_FRAME_REDUCE);
+  used[TA_K_FRAME_REDUCE] = true;
+  HIP_CHECK(hipGetLastError());
+  h->last_want = want;
+
+  if (timed) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < TA_N_KERNEL_SLOTS; ++k) {
+      if (!used[k]) continue;
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]));
+      slot_ms[k] += ms;
+    }
+  }
+}
+
+template <typename F>
+int guarded(ta_context *h, F &&fn) {
+  try {
+    if (h) HIP_CHECK(hipSetDevice(h->device));
+    fn();
+    return TA_OK;
+  } catch (const HipError &e) {
+    return fail(h, TA_ERR_HIP, e.what());
+  } catch (const std::domain_error &e) {
+    return fail(h, TA_ERR_UNSUPPORTED, e.what());
+  } catch (const std::invalid_argument &e) {
+    return fail(h, TA_ERR_INVALID, e.what());
+  } catch (const std::bad_alloc &) {
+    return fail(h, TA_ERR_NOMEM, "host allocation failed");
+  } catch (const std::exception &e) {
+    return fail(h, TA_ERR_INVALID, e.what());
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ta_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *ta_last_error(ta_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
+  if (!model || !out) return fail(nullptr, TA_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, TA_ERR_HIP, "no HIP device available: this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, TA_ERR_INVALID, "device index out of range");
+  if (model->n_elements < 1 || model->n_elements > ta::kMaxElements)
+    return fail(nullptr, TA_ERR_UNSUPPORTED, "n_elements must be in 1..8");
+  ta_context *h = new ta_context();
+  h->device = device;
+  h->kind = model->kind;
+  h->n_elements = model->n_elements;
+  int rc = guarded(h, [&]() {
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      throw HipError(std::string("device is ") + prop.gcnArchName +
+                     ", this library is built for gfx950 only");
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &e : h->ev) HIP_CHECK(hipEventCreate(&e));
+    if (model->kind == TA_MODEL_SF_MLP) {
+      build_sf_model(h, model);
+    } else if (model->kind == TA_MODEL_EAM_ALLOY || model->kind == TA_MODEL_EAM_ADP) {
+      std::string err;
+      h->eam = ta::eam_create(model, err);
+      if (!h->eam) throw std::invalid_argument(err);
+      h->rmax = model->rcut;
+      std::memset(&h->sf, 0, sizeof(h->sf));
+      h->sf.n_elements = model->n_elements;
+      h->sf.eps = 1e-14;
+    } else {
+      throw std::invalid_argument("unknown model kind");
+    }
+  });
+  if (rc != TA_OK) {
+    g_create_error = h->err;
+    ta_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return TA_OK;
+}
+
+int ta_destroy(ta_handle h) {
+  if (!h) return TA_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->model_allocs) (void)hipFree(p);
+  if (h->eam) ta::eam_destroy(h->eam);
+  h->pos.release(); h->cells.release(); h->rec.release(); h->part4.release(); h->G.release();
+  h->dEdG.release(); h->eatom.release(); h->g.release(); h->forces.release(); h->wat.release();
+  h->energy.release(); h->virial.release(); h->benergy.release(); h->mlp_scratch.release();
+  h->species.release(); h->frame_of_atom.release(); h->atom_start.release();
+  h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
+  h->pair_shift.release(); h->pair_rev.release(); h->elem_atoms.release();
+  for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return TA_OK;
+}
+
+int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batch_info *info) {
+  if (!h) return TA_ERR_INVALID;
+  if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(h, TA_ERR_INVALID, "bad frames argument");
+  return guarded(h, [&]() {
+    for (int f = 0; f < n_frames; ++f) {
+      const ta_frame &fr = frames[f];
+      if (fr.n_atoms < 0 || (fr.n_atoms > 0 && (!fr.species || !fr.positions)) || !fr.cell || !fr.pbc)
+        throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
+    }
+    ta::build_pairs(n_frames, frames, h->n_elements, h->rmax, h->hp);
+    const size_t N = (size_t)h->hp.n_atoms;
+    std::vector<double> pos(3 * N), cells(9 * (size_t)n_frames);
+    std::vector<int32_t> species(N);
+    size_t a = 0;
+    for (int f = 0; f < n_frames; ++f) {
+      const ta_frame &fr = frames[f];
+      std::memcpy(&pos[3 * a], fr.positions, 3 * (size_t)fr.n_atoms * sizeof(double));
+      std::memcpy(&species[a], fr.species, (size_t)fr.n_atoms * sizeof(int32_t));
+      std::memcpy(&cells[9 * (size_t)f], fr.cell, 9 * sizeof(double));
+      a += fr.n_atoms;
+    }
+    // atoms grouped by element for the batched MLP
+    std::vector<int32_t> elem_atoms(N);
+    {
+      std::vector<int32_t> count(h->n_elements + 1, 0);
+      for (size_t i = 0; i < N; ++i) count[species[i] + 1]++;
+      for (int e = 0; e < h->n_elements; ++e) count[e + 1] += count[e];
+      for (int e = 0; e <= h->n_elements; ++e) h->db.elem_start[e] = count[e];
+      std::vector<int32_t> fill(count.begin(), count.end() - 1);
+      for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
+    }
+    upload_batch(h);
+    auto put = [&](auto &buf, const auto &vec) {
+      buf.ensure(vec.size());
+      if (!vec.empty())
+        HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
+                                 hipMemcpyHostToDevice, h->stream));
+    };
+    put(h->pos, pos);
+    put(h->cells, cells);
+    put(h->species, species);
+    put(h->elem_atoms, elem_atoms);
+    h->db.pos = h->pos.ptr;
+    h->db.cells = h->cells.ptr;
+    h->db.species = h->species.ptr;
+    h->db.elem_atoms = h->elem_atoms.ptr;
+    if (h->kind == TA_MODEL_SF_MLP) {
+      if (ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
+        throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
+      size_t need = 0;
+      for (int e = 0; e < h->n_elements; ++e) {
+        const size_t tiles = (size_t)(h->db.elem_start[e + 1] - h->db.elem_start[e] + 15) / 16;
+        need = std::max(need, tiles * ta::mlp_scratch_doubles(h->mlp[e]));
+      }
+      h->mlp_scratch.ensure(need);
+    } else {
+      ta::eam_ensure(h->eam, h->db);
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+    h->have_batch = true;
+    if (info) {
+      info->n_frames = n_frames;
+      info->n_atoms = h->hp.n_atoms;
+      info->n_pairs = h->hp.n_pairs;
+      info->n_triples = h->hp.n_triples;
+      info->nnl_max = h->hp.nnl_max;
+      info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 0;
+    }
+  });
+}
+
+int ta_compute(ta_handle h, uint32_t want) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "ta_compute called before ta_set_frames");
+  return guarded(h, [&]() { compute_impl(h, want, false, nullptr); });
+}
+
+int ta_synchronize(ta_handle h) {
+  if (!h) return TA_ERR_INVALID;
+  return guarded(h, [&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); });
+}
+
+int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, double *atomic,
+                   double *descriptors) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  return guarded(h, [&]() {
+    const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+    hipStream_t s = h->stream;
+    const bool have_forces = (h->last_want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
+    if ((forces || virial) && !have_forces)
+      throw std::invalid_argument("forces / virial requested but the last ta_compute did not produce them");
+    if (descriptors && h->kind != TA_MODEL_SF_MLP)
+      throw std::invalid_argument("descriptors are only defined for symmetry-function models");
+    if (energy && F)
+      HIP_CHECK(hipMemcpyAsync(energy, h->db.energy, F * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (forces && N)
+      HIP_CHECK(hipMemcpyAsync(forces, h->db.forces, 3 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (virial && F)
+      HIP_CHECK(hipMemcpyAsync(virial, h->db.virial, 9 * F * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (atomic && N)
+      HIP_CHECK(hipMemcpyAsync(atomic, h->db.eatom, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (descriptors && N)
+      HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double),
+                               hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
+int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want, double *energy,
+            double *forces, double *virial, double *atomic) {
+  int rc = ta_set_frames(h, n_frames, frames, nullptr);
+  if (rc != TA_OK) return rc;
+  rc = ta_compute(h, want);
+  if (rc != TA_OK) return rc;
+  return ta_get_results(h, energy, forces, virial, atomic, nullptr);
+}
+
+int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps, double *total_ms,
+                    double *kernel_ms) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (steps < 1 || warmup < 0) return fail(h, TA_ERR_INVALID, "steps must be >= 1, warmup >= 0");
+  return guarded(h, [&]() {
+    hipStream_t s = h->stream;
+    for (int k = 0; k < warmup; ++k) compute_impl(h, want, false, nullptr);
+    HIP_CHECK(hipStreamSynchronize(s));
+    hipEvent_t e0 = h->ev[2 * TA_N_KERNEL_SLOTS], e1 = h->ev[2 * TA_N_KERNEL_SLOTS + 1];
+    HIP_CHECK(hipEventRecord(e0, s));
+    for (int k = 0; k < steps; ++k) compute_impl(h, want, false, nullptr);
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (total_ms) *total_ms = ms;
+    if (kernel_ms) {
+      double acc[TA_N_KERNEL_SLOTS] = {0};
+      for (int k = 0; k < steps; ++k) compute_impl(h, want, true, acc);
+      for (int k = 0; k < TA_N_KERNEL_SLOTS; ++k) kernel_ms[k] = acc[k] / steps;
+    }
+  });
+}
+
+int ta_batch_energy_device_ptr(ta_handle h, void **dptr) {
+  if (!h || !dptr) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  *dptr = h->db.batch_energy;
+  return TA_OK;
+}
+
+int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64_t *n_pairs,
+                     int32_t **i, int32_t **j, int32_t **shift, int32_t **rev) {
+  if (!frame || !n_pairs || n_elements < 1 || !(rc > 0.0))
+    return fail(nullptr, TA_ERR_INVALID, "bad argument");
+  try {
+    ta::HostPairs hp;
+    ta::build_pairs(1, frame, n_elements, rc, hp);
+    const size_t P = (size_t)hp.n_pairs;
+    *n_pairs = hp.n_pairs;
+    auto dup = [&](const std::vector<int32_t> &v) {
+      int32_t *p = (int32_t *)std::malloc((v.size() ? v.size() : 1) * sizeof(int32_t));
+      if (!p) throw std::bad_alloc();
+      if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(int32_t));
+      return p;
+    };
+    (void)P;
+    if (i) *i = dup(hp.pair_i);
+    if (j) *j = dup(hp.pair_j);
+    if (shift) *shift = dup(hp.pair_shift);
+    if (rev) *rev = dup(hp.pair_rev);
+    return TA_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(nullptr, TA_ERR_NOMEM, "host allocation failed");
+  } catch (const std::exception &e) {
+    return fail(nullptr, TA_ERR_INVALID, e.what());
+  }
+}
+
+void ta_free(void *p) { std::free(p); }
+
+int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  const size_t P = (size_t)h->hp.n_pairs;
+  if (i) std::memcpy(i, h->hp.pair_i.data(), P * sizeof(int32_t));
+  if (j) std::memcpy(j, h->hp.pair_j.data(), P * sizeof(int32_t));
+  if (shift) std::memcpy(shift, h->hp.pair_shift.data(), 3 * P * sizeof(int32_t));
+  return TA_OK;
+}
+
+}  // extern "C"

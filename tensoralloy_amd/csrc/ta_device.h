@@ -1,0 +1,103 @@
+// Device-side data structures and launcher declarations (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tensoralloy_amd.h"
+
+namespace ta {
+
+constexpr int kMaxRadial = 64;    // n_eta * n_omega
+constexpr int kMaxElements = 8;
+constexpr int kMaxBetaSlots = 3;  // H_beta slots in a pair record
+constexpr int kRecDoubles = 8;    // pair record = 64 bytes
+constexpr int kMaxLayers = 8;
+
+// Symmetry-function constants, passed by value to every kernel.
+struct SFParams {
+  double rcut, acut;
+  double inv_rc2, inv_ac2;  // 1 / rcut^2, 1 / acut^2
+  double eps;               // added under the square root (universal.py:470-472)
+  int n_elements;
+  int n_rad;                // radial parameter combinations (eta x omega)
+  int n_ang;                // angular parameter combinations (beta x gamma x zeta)
+  int n_radial_dim;         // n_elements * n_rad
+  int ndim;                 // descriptor length per atom
+  int angular;
+  int cutoff;               // TA_CUTOFF_*
+  int n_beta;
+  double eta[kMaxRadial], omega[kMaxRadial];
+  double beta[kMaxBetaSlots];
+};
+
+// One launch of the angular kernels handles NB x NG x NZ channels.
+struct AngChunk {
+  double beta[2];
+  int hslot[2];      // which H slot of the pair record holds exp(-beta r^2/ac^2) fc(r)
+  double gamma[2];
+  double zeta[2];
+  double kz[2];      // 2^(1 - zeta)
+  int zeta_int[2];   // zeta as integer >= 1, or -1 when not an integer
+  int chan[8];       // [(ib*NG + ig)*NZ + iz] -> channel index in [0, n_ang)
+};
+
+struct DeviceBatch {
+  int64_t n_atoms = 0, n_pairs = 0;
+  int n_frames = 0, nnl_max = 0;
+  // inputs
+  double *pos = nullptr;         // [N][3]
+  double *cells = nullptr;       // [F][9]
+  int32_t *species = nullptr;    // [N]
+  int32_t *frame_of_atom = nullptr;
+  int32_t *atom_start = nullptr; // [F+1]
+  int32_t *pair_start = nullptr; // [N+1]
+  int32_t *seg_start = nullptr;  // [N][nel+1]
+  int32_t *pair_i = nullptr, *pair_j = nullptr, *pair_shift = nullptr, *pair_rev = nullptr;
+  int32_t *elem_atoms = nullptr; // atoms grouped by element
+  int32_t elem_start[kMaxElements + 1] = {0};
+  // work buffers
+  double *rec = nullptr;    // [P][8]  {Dx,Dy,Dz,r2,1/r,H0,H1,H2}
+  double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
+  double *G = nullptr;      // [N][D]
+  double *dEdG = nullptr;   // [N][D]
+  double *eatom = nullptr;  // [N]
+  double *g = nullptr;      // [3][P]  dE/dD per directed pair
+  double *forces = nullptr; // [N][3]
+  double *wat = nullptr;    // [N][9] per-atom virial
+  double *energy = nullptr; // [F]
+  double *virial = nullptr; // [F][9]
+  double *batch_energy = nullptr;  // [1]
+};
+
+// Per-element MLP on the device: padded weights, both orientations.
+struct MlpLayerDev {
+  int k, n;        // logical in / out
+  int kp, np;      // padded: kp % 4 == 0, np % 16 == 0
+  double *w;       // [kp][np]
+  double *wt;      // [np][kp]
+  double *b;       // [np]
+  int act;         // apply activation
+  int res;         // resnet skip
+};
+struct MlpDev {
+  int n_layers = 0;  // incl. output layer
+  MlpLayerDev layer[kMaxLayers];
+  double *xlo = nullptr, *xhi = nullptr;  // [D] or null
+  int max_np = 0, max_kp = 0;
+};
+
+void launch_pair_geometry(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
+void launch_g4_forward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz,
+                       const DeviceBatch &b, hipStream_t s);
+void launch_descriptor_reduce(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
+void launch_mlp(const SFParams &sf, const MlpDev &mlp, int activation, int element,
+                const DeviceBatch &b, hipStream_t s);
+void launch_backward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz,
+                     bool first, bool radial_only, const DeviceBatch &b, hipStream_t s);
+void launch_force_gather(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
+void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s);
+
+size_t g4_lds_bytes(int nnl_max);
+
+}  // namespace ta

@@ -1,0 +1,538 @@
+// Hand-written gfx950 kernels for the symmetry-function + MLP hot path.
+//
+// What each kernel replaces in the reference (TensorFlow-1 graph ops):
+//   pair_geometry_kernel      calculate_rij            transformer/universal.py:448-474
+//   g4_forward_kernel         build_angular_graph + _apply_g4_functions
+//                                                       universal.py:622-694, nn/atomic/sf.py:121-182
+//   descriptor_reduce_kernel  build_radial_graph + _apply_g2_functions + concat
+//                                                       universal.py:583-620, sf.py:79-119, :184-215
+//   backward_kernel           tf.gradients(E, positions/cell) through all of the above
+//                                                       nn/basic.py:277-331
+//   force_gather_kernel       forces = -dE/dR ; virial  basic.py:277-331
+//   frame_reduce_kernel       energy = sum(atomic)      nn/atomic/atomic.py:289-302
+//
+// Layout. Directed pairs are sorted by centre atom (and by neighbour species
+// inside a centre). Each pair owns one 64-byte record {Dx,Dy,Dz,r^2,1/r,H0,H1,H2}
+// with H_k = exp(-beta_k r^2/acut^2) fc(r; acut). The angular kernels give one
+// lane to one directed pair (i, a); a 256-lane workgroup stages the records of
+// the 3-5 centres it touches in LDS and every lane walks the other neighbours b
+// of its centre, reading their records as LDS broadcasts. Triples are never
+// materialised in HBM: r_jk comes from |D_b - D_a|^2 and the cosine cutoff is a
+// polynomial in r_jk^2, so a triple costs no sqrt and no trig. Lane a sums the
+// ordered pairs (a, b), b != a: every unordered triple is visited from both of
+// its neighbours, which gives each lane the complete dE/dD_a in registers
+// (no atomics, no cross-lane traffic); the descriptor sum takes half of it.
+#include <hip/hip_runtime.h>
+
+#include "ta_device.h"
+#include "ta_math.h"
+
+namespace ta {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int radial_term(int center, int other) {
+  // [AA, AB (B != A, sorted)]  (reference utils.py:265-273)
+  return other == center ? 0 : (other < center ? other + 1 : other);
+}
+__device__ __forceinline__ int angular_term(int s1, int s2, int nel) {
+  // sorted pair (j <= k) in row-major upper-triangular order (utils.py:274-282)
+  int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
+  return a * nel - (a * (a - 1)) / 2 + (b - a);
+}
+
+// --------------------------------------------------------------------------
+// K1: pair geometry
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pair_geometry_kernel(SFParams sf, DeviceBatch b) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= b.n_pairs) return;
+  const int i = b.pair_i[p], j = b.pair_j[p];
+  const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
+  const double sx = (double)b.pair_shift[3 * p], sy = (double)b.pair_shift[3 * p + 1],
+               sz = (double)b.pair_shift[3 * p + 2];
+  const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+  // D = Rj - Ri + S.h  (universal.py:463-468)
+  const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+  const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+  const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+  const double r2 = dx * dx + dy * dy + dz * dz + sf.eps;  // universal.py:470-472
+  const double r = sqrt(r2);
+  double rec[kRecDoubles];
+  rec[0] = dx;
+  rec[1] = dy;
+  rec[2] = dz;
+  rec[3] = r2;
+  rec[4] = 1.0 / r;
+  rec[5] = rec[6] = rec[7] = 0.0;
+  if (sf.angular) {
+    const double u = r2 * sf.inv_ac2;
+    if (u < 1.0) {
+      const double f = cutoff_u_value(sf.cutoff, u);
+      for (int k = 0; k < sf.n_beta; ++k) rec[5 + k] = ta_exp(-sf.beta[k] * u) * f;
+    }
+  }
+  double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)p);
+  dst[0] = make_double2(rec[0], rec[1]);
+  dst[1] = make_double2(rec[2], rec[3]);
+  dst[2] = make_double2(rec[4], rec[5]);
+  dst[3] = make_double2(rec[6], rec[7]);
+}
+
+// stage the pair records of every centre touched by this workgroup into LDS
+__device__ __forceinline__ int stage_records(const DeviceBatch &b, double *lds, int64_t p0) {
+  const int64_t plast = (p0 + kBlock - 1 < b.n_pairs) ? p0 + kBlock - 1 : b.n_pairs - 1;
+  const int i_lo = b.pair_i[p0], i_hi = b.pair_i[plast];
+  const int s0 = b.pair_start[i_lo], s1 = b.pair_start[i_hi + 1];
+  const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)s0);
+  double2 *dst = reinterpret_cast<double2 *>(lds);
+  const int n16 = (s1 - s0) * (kRecDoubles / 2);
+  for (int k = threadIdx.x; k < n16; k += kBlock) dst[k] = src[k];
+  __syncthreads();
+  return s0;
+}
+
+// --------------------------------------------------------------------------
+// K2: angular descriptors, forward. part4[(sb*n_ang + c)][p] = sum over
+// neighbours b of species sb of centre(p) of the G4 summand of channel c for
+// the ordered pair (a = p, b).
+// --------------------------------------------------------------------------
+template <int NB, int NG, int NZ>
+__global__ __launch_bounds__(kBlock) void g4_forward_kernel(SFParams sf, AngChunk ch, DeviceBatch b) {
+  extern __shared__ double lds[];
+  const int64_t p0 = (int64_t)blockIdx.x * kBlock;
+  const int s0 = stage_records(b, lds, p0);
+  const int64_t p = p0 + threadIdx.x;
+  if (p >= b.n_pairs) return;
+
+  const double *ra = lds + kRecDoubles * (size_t)(p - s0);
+  const double ax = ra[0], ay = ra[1], az = ra[2], ra2 = ra[3], inv_ra = ra[4];
+  double Ha[NB];
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) Ha[ib] = ra[5 + ch.hslot[ib]];
+  const int i = b.pair_i[p];
+  const int nel = sf.n_elements;
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  const int lp = (int)(p - s0);
+
+  for (int sb = 0; sb < nel; ++sb) {
+    const int q0 = seg[sb] - s0, q1 = seg[sb + 1] - s0;
+    double acc[NB][NG][NZ];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) acc[ib][ig][iz] = 0.0;
+
+    for (int q = q0; q < q1; ++q) {
+      const double *rb = lds + kRecDoubles * (size_t)q;
+      const double ex = rb[0] - ax, ey = rb[1] - ay, ez = rb[2] - az;
+      const double rb2 = rb[3], inv_rb = rb[4];
+      // r_jk^2 = |D_ik - D_ij|^2 + eps  (universal.py:213, :470-472)
+      const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
+      const double u = d2 * sf.inv_ac2;
+      const bool ok = (q != lp) && (u < 1.0);
+      // cos(theta) = (rij^2 + rik^2 - rjk^2) / (2 rij rik)  (sf.py:145-148)
+      const double cth = (ra2 + rb2 - d2) * 0.5 * inv_ra * inv_rb;
+      const double fd = cutoff_u_value(sf.cutoff, u);
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) {
+        const double ed = ta_exp(-ch.beta[ib] * u);
+        double common = Ha[ib] * rb[5 + ch.hslot[ib]] * ed * fd;
+        common = ok ? common : 0.0;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double base = fma(ch.gamma[ig], cth, 1.0);
+#pragma unroll
+          for (int iz = 0; iz < NZ; ++iz) {
+            double pw;
+            if (ch.zeta_int[iz] > 0)
+              pw = pow_int_m1(base, ch.zeta_int[iz]) * base;
+            else
+              pw = pow(base, ch.zeta[iz]);
+            acc[ib][ig][iz] = fma(pw, common, acc[ib][ig][iz]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) {
+          const int c = ch.chan[(ib * NG + ig) * NZ + iz];
+          b.part4[(size_t)(sb * sf.n_ang + c) * b.n_pairs + p] = acc[ib][ig][iz] * ch.kz[iz];
+        }
+  }
+}
+
+// --------------------------------------------------------------------------
+// K3a: per-atom descriptors: G2 straight from the pair records, G4 from the
+// per-pair partial sums. One wavefront per atom, shuffle reduction.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void descriptor_reduce_kernel(SFParams sf, DeviceBatch b) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= b.n_atoms) return;
+  const int nel = sf.n_elements;
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  double *Gi = b.G + (size_t)i * sf.ndim;
+
+  for (int sb = 0; sb < nel; ++sb) {
+    const int tr = radial_term(sA, sb);
+    for (int c = 0; c < sf.n_rad; ++c) {
+      const double eta = sf.eta[c], omega = sf.omega[c];
+      double acc = 0.0;
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+        const double r2 = b.rec[kRecDoubles * (size_t)q + 3];
+        const double u = r2 * sf.inv_rc2;
+        if (u < 1.0) {
+          const double r = sqrt(r2);
+          const double f = cutoff_u_value(sf.cutoff, u);
+          const double dr = r - omega;
+          // exp(-eta (r - omega)^2 / rc^2) fc(r)   (sf.py:101-108)
+          acc += ta_exp(-eta * dr * dr * sf.inv_rc2) * f;
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) Gi[tr * sf.n_rad + c] = acc;
+    }
+  }
+  if (sf.angular) {
+    for (int s1 = 0; s1 < nel; ++s1)
+      for (int s2 = s1; s2 < nel; ++s2) {
+        const int t = angular_term(s1, s2, nel);
+        for (int c = 0; c < sf.n_ang; ++c) {
+          double acc = 0.0;
+          const double *col = b.part4 + (size_t)(s2 * sf.n_ang + c) * b.n_pairs;
+          for (int q = seg[s1] + lane; q < seg[s1 + 1]; q += 64) acc += col[q];
+          if (s1 != s2) {
+            const double *col2 = b.part4 + (size_t)(s1 * sf.n_ang + c) * b.n_pairs;
+            for (int q = seg[s2] + lane; q < seg[s2 + 1]; q += 64) acc += col2[q];
+          }
+          acc = wave_sum(acc);
+          // every unordered {j, k} was visited from both sides
+          if (lane == 0) Gi[sf.n_radial_dim + t * sf.n_ang + c] = 0.5 * acc;
+        }
+      }
+  }
+}
+
+// --------------------------------------------------------------------------
+// K4: backward. g[p] = dE/dD_p for the directed pair p = (i, a):
+//   G2:  s_p D_a / r_a,  s_p = sum_c dE/dG_c d g_c / d r
+//   G4:  D_a sum_b (A_ab + Q_ab) - sum_b Q_ab D_b   
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void radial_backward(const SFParams &sf, const DeviceBatch &b, int i,
+                                                int sa, double ra2, double inv_ra, double &s) {
+  s = 0.0;
+  const double u = ra2 * sf.inv_rc2;
+  if (u < 1.0) {
+    double f, dfdu;
+    cutoff_u(sf.cutoff, u, f, dfdu);
+    const double r = sqrt(ra2);
+    const double dfdr = dfdu * 2.0 * r * sf.inv_rc2;
+    const int tr = radial_term(b.species[i], sa);
+    const double *w = b.dEdG + (size_t)i * sf.ndim + tr * sf.n_rad;
+    for (int c = 0; c < sf.n_rad; ++c) {
+      const double dr = r - sf.omega[c];
+      const double e = ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2);
+      s = fma(w[c], e * (dfdr - 2.0 * sf.eta[c] * dr * f * sf.inv_rc2), s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void g2_backward_kernel(SFParams sf, DeviceBatch b) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= b.n_pairs) return;
+  const double *ra = b.rec + kRecDoubles * (size_t)p;
+  const int i = b.pair_i[p];
+  const int sa = b.species[b.pair_j[p]];
+  double s;
+  radial_backward(sf, b, i, sa, ra[3], ra[4], s);
+  s *= ra[4];
+  b.g[p] = s * ra[0];
+  b.g[b.n_pairs + p] = s * ra[1];
+  b.g[2 * b.n_pairs + p] = s * ra[2];
+}
+
+template <int NB, int NG, int NZ>
+__global__ __launch_bounds__(kBlock) void backward_kernel(SFParams sf, AngChunk ch, DeviceBatch b,
+                                                          int first) {
+  extern __shared__ double lds[];
+  const int64_t p0 = (int64_t)blockIdx.x * kBlock;
+  const int s0 = stage_records(b, lds, p0);
+  const int64_t p = p0 + threadIdx.x;
+  if (p >= b.n_pairs) return;
+
+  const double *ra = lds + kRecDoubles * (size_t)(p - s0);
+  const double ax = ra[0], ay = ra[1], az = ra[2], ra2 = ra[3], inv_ra = ra[4];
+  const int i = b.pair_i[p];
+  const int sa = b.species[b.pair_j[p]];
+  const int nel = sf.n_elements;
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  const int lp = (int)(p - s0);
+
+  // own-pair factors: H_a = exp(-beta u_a) fc(u_a),  G_a = (dH_a/dr_a) / r_a
+  double Ha[NB], Ga[NB];
+  {
+    const double ua = ra2 * sf.inv_ac2;
+    double fa = 0.0, dfa = 0.0;
+    const bool oka = ua < 1.0;
+    if (oka) cutoff_u(sf.cutoff, ua, fa, dfa);
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+      const double ea = oka ? ta_exp(-ch.beta[ib] * ua) : 0.0;
+      Ha[ib] = ea * fa;
+      Ga[ib] = ea * 2.0 * sf.inv_ac2 * (dfa - ch.beta[ib] * fa);
+    }
+  }
+
+  double sumAQ = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
+  const double inv_ra2 = inv_ra * inv_ra;
+  for (int sb = 0; sb < nel; ++sb) {
+    const int q0 = seg[sb] - s0, q1 = seg[sb + 1] - s0;
+    // dE/dG of the channels of this (a-species, b-species) term, times 2^(1-zeta)
+    double w[NB][NG][NZ];
+    {
+      const double *wsrc = b.dEdG + (size_t)i * sf.ndim + sf.n_radial_dim +
+                           angular_term(sa, sb, nel) * sf.n_ang;
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+          for (int iz = 0; iz < NZ; ++iz)
+            w[ib][ig][iz] = wsrc[ch.chan[(ib * NG + ig) * NZ + iz]] * ch.kz[iz];
+    }
+    for (int q = q0; q < q1; ++q) {
+      const double *rb = lds + kRecDoubles * (size_t)q;
+      const double bx = rb[0], by = rb[1], bz = rb[2];
+      const double ex = bx - ax, ey = by - ay, ez = bz - az;
+      const double rb2 = rb[3], inv_rb = rb[4];
+      const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
+      const double u = d2 * sf.inv_ac2;
+      const bool ok = (q != lp) && (u < 1.0);
+      const double inv_ab = inv_ra * inv_rb;
+      const double cth = (ra2 + rb2 - d2) * 0.5 * inv_ab;
+      double fd, dfd;
+      cutoff_u(sf.cutoff, u, fd, dfd);
+      double A = 0.0, Q = 0.0;
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) {
+        const double ed = ta_exp(-ch.beta[ib] * u);
+        const double Hb = rb[5 + ch.hslot[ib]];
+        const double Hd = ed * fd;
+        const double Hd2 = 2.0 * sf.inv_ac2 * ed * (dfd - ch.beta[ib] * fd);
+        double S0 = 0.0, S1 = 0.0;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double base = fma(ch.gamma[ig], cth, 1.0);
+#pragma unroll
+          for (int iz = 0; iz < NZ; ++iz) {
+            double pm1;
+            if (ch.zeta_int[iz] > 0)
+              pm1 = pow_int_m1(base, ch.zeta_int[iz]);
+            else
+              pm1 = pow(base, ch.zeta[iz] - 1.0);
+            S0 = fma(w[ib][ig][iz], pm1 * base, S0);
+            S1 = fma(w[ib][ig][iz] * ch.zeta[iz] * ch.gamma[ig], pm1, S1);
+          }
+        }
+        A = fma(Hb * Hd, fma(S1 * Ha[ib], inv_ab - cth * inv_ra2, S0 * Ga[ib]), A);
+        Q = fma(Ha[ib] * Hb, fma(-S1 * inv_ab, Hd, S0 * Hd2), Q);
+      }
+      A = ok ? A : 0.0;
+      Q = ok ? Q : 0.0;
+      sumAQ += A + Q;
+      vx = fma(Q, bx, vx);
+      vy = fma(Q, by, vy);
+      vz = fma(Q, bz, vz);
+    }
+  }
+  double gx = fma(ax, sumAQ, -vx), gy = fma(ay, sumAQ, -vy), gz = fma(az, sumAQ, -vz);
+  if (first) {
+    double s;
+    radial_backward(sf, b, i, sa, ra2, inv_ra, s);
+    s *= inv_ra;
+    gx = fma(s, ax, gx);
+    gy = fma(s, ay, gy);
+    gz = fma(s, az, gz);
+  } else {
+    gx += b.g[p];
+    gy += b.g[b.n_pairs + p];
+    gz += b.g[2 * b.n_pairs + p];
+  }
+  b.g[p] = gx;
+  b.g[b.n_pairs + p] = gy;
+  b.g[2 * b.n_pairs + p] = gz;
+}
+
+// --------------------------------------------------------------------------
+// K5: forces and per-atom virial. Full list => the reaction force on j of the
+// pair (i -> j) is read from its reverse pair (j -> i): no atomics, fixed order.
+//   F_i = sum_{p in N(i)} (g[p] - g[rev p])        (F = -dE/dR, basic.py:281-287)
+//   W_i = sum_{p in N(i)} g[p] (x) D[p]            (== -F^T R + (dE/dh)^T h, basic.py:306-316)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= b.n_atoms) return;
+  const int64_t P = b.n_pairs;
+  double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = b.pair_start[i] + lane; q < b.pair_start[i + 1]; q += 64) {
+    const int r = b.pair_rev[q];
+    const double gx = b.g[q], gy = b.g[P + q], gz = b.g[2 * P + q];
+    f[0] += gx - b.g[r];
+    f[1] += gy - b.g[P + r];
+    f[2] += gz - b.g[2 * P + r];
+    const double *rec = b.rec + kRecDoubles * (size_t)q;
+    const double dx = rec[0], dy = rec[1], dz = rec[2];
+    w[0] = fma(gx, dx, w[0]);
+    w[1] = fma(gx, dy, w[1]);
+    w[2] = fma(gx, dz, w[2]);
+    w[3] = fma(gy, dx, w[3]);
+    w[4] = fma(gy, dy, w[4]);
+    w[5] = fma(gy, dz, w[5]);
+    w[6] = fma(gz, dx, w[6]);
+    w[7] = fma(gz, dy, w[7]);
+    w[8] = fma(gz, dz, w[8]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = wave_sum(f[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wave_sum(w[k]);
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
+    for (int k = 0; k < 9; ++k) b.wat[9 * (size_t)i + k] = w[k];
+  }
+}
+
+// --------------------------------------------------------------------------
+// K6: per-frame energy and virial (fixed-order tree), then the batch energy.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial) {
+  __shared__ double red[kBlock];
+  const int f = blockIdx.x;
+  const int a0 = b.atom_start[f], a1 = b.atom_start[f + 1];
+  const int nv = want_virial ? 10 : 1;
+  for (int k = 0; k < nv; ++k) {
+    double acc = 0.0;
+    for (int a = a0 + threadIdx.x; a < a1; a += kBlock)
+      acc += (k == 0) ? b.eatom[a] : b.wat[9 * (size_t)a + (k - 1)];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (k == 0)
+        b.energy[f] = red[0];
+      else
+        b.virial[9 * (size_t)f + (k - 1)] = red[0];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void batch_energy_kernel(DeviceBatch b) {
+  __shared__ double red[kBlock];
+  double acc = 0.0;
+  for (int f = threadIdx.x; f < b.n_frames; f += kBlock) acc += b.energy[f];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) b.batch_energy[0] = red[0];
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) {
+  return (unsigned)((n + per_block - 1) / per_block);
+}
+
+template <int NB, int NG, int NZ>
+void launch_fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, hipStream_t s) {
+  hipLaunchKernelGGL((g4_forward_kernel<NB, NG, NZ>), dim3(blocks_for(b.n_pairs, kBlock)),
+                     dim3(kBlock), g4_lds_bytes(b.nnl_max), s, sf, ch, b);
+}
+template <int NB, int NG, int NZ>
+void launch_bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int first,
+                  hipStream_t s) {
+  hipLaunchKernelGGL((backward_kernel<NB, NG, NZ>), dim3(blocks_for(b.n_pairs, kBlock)),
+                     dim3(kBlock), g4_lds_bytes(b.nnl_max), s, sf, ch, b, first);
+}
+
+}  // namespace
+
+size_t g4_lds_bytes(int nnl_max) {
+  return (size_t)(kBlock + 2 * (size_t)nnl_max) * kRecDoubles * sizeof(double);
+}
+
+void launch_pair_geometry(const SFParams &sf, const DeviceBatch &b, hipStream_t s) {
+  if (b.n_pairs == 0) return;
+  hipLaunchKernelGGL(pair_geometry_kernel, dim3(blocks_for(b.n_pairs, kBlock)), dim3(kBlock), 0, s,
+                     sf, b);
+}
+
+#define TA_DISPATCH(FN, ...)                                             \
+  do {                                                                   \
+    const int key = nb * 100 + ng * 10 + nz;                             \
+    switch (key) {                                                       \
+      case 111: FN<1, 1, 1>(__VA_ARGS__); break;                         \
+      case 112: FN<1, 1, 2>(__VA_ARGS__); break;                         \
+      case 121: FN<1, 2, 1>(__VA_ARGS__); break;                         \
+      case 122: FN<1, 2, 2>(__VA_ARGS__); break;                         \
+      case 211: FN<2, 1, 1>(__VA_ARGS__); break;                         \
+      case 212: FN<2, 1, 2>(__VA_ARGS__); break;                         \
+      case 221: FN<2, 2, 1>(__VA_ARGS__); break;                         \
+      case 222: FN<2, 2, 2>(__VA_ARGS__); break;                         \
+      default: break;                                                    \
+    }                                                                    \
+  } while (0)
+
+void launch_g4_forward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz,
+                       const DeviceBatch &b, hipStream_t s) {
+  if (b.n_pairs == 0) return;
+  TA_DISPATCH(launch_fwd_t, sf, ch, b, s);
+}
+
+void launch_descriptor_reduce(const SFParams &sf, const DeviceBatch &b, hipStream_t s) {
+  if (b.n_atoms == 0) return;
+  hipLaunchKernelGGL(descriptor_reduce_kernel, dim3(blocks_for(b.n_atoms * 64, kBlock)),
+                     dim3(kBlock), 0, s, sf, b);
+}
+
+void launch_backward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz, bool first,
+                     bool radial_only, const DeviceBatch &b, hipStream_t s) {
+  if (b.n_pairs == 0) return;
+  if (radial_only) {
+    hipLaunchKernelGGL(g2_backward_kernel, dim3(blocks_for(b.n_pairs, kBlock)), dim3(kBlock), 0, s,
+                       sf, b);
+    return;
+  }
+  const int f = first ? 1 : 0;
+  TA_DISPATCH(launch_bwd_t, sf, ch, b, f, s);
+}
+
+void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) {
+  if (b.n_atoms == 0) return;
+  hipLaunchKernelGGL(force_gather_kernel, dim3(blocks_for(b.n_atoms * 64, kBlock)), dim3(kBlock), 0,
+                     s, b);
+}
+
+void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s) {
+  if (b.n_frames == 0) return;
+  hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames), dim3(kBlock), 0, s, b,
+                     want_virial ? 1 : 0);
+  hipLaunchKernelGGL(batch_energy_kernel, dim3(1), dim3(kBlock), 0, s, b);
+}
+
+}  // namespace ta

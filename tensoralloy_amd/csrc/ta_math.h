@@ -1,0 +1,183 @@
+// Device math helpers (fp64) for the descriptor kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ta {
+
+// exp(x) for x <= ~50 (the kernels only call it with x <= 0): round-to-nearest
+// range reduction with a two-part ln2 and a degree-13 Taylor polynomial on
+// |r| <= ln2/2 (truncation 4e-18 relative), scaled by v_ldexp_f64.
+__device__ __forceinline__ double ta_exp(double x) {
+  const double kLog2e = 1.4426950408889634074;
+  const double kLn2Hi = 6.93147180369123816490e-01;
+  const double kLn2Lo = 1.90821492927058770002e-10;
+  double kf = rint(x * kLog2e);
+  double r = fma(-kf, kLn2Hi, x);
+  r = fma(-kf, kLn2Lo, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  kf = fmax(kf, -1100.0);
+  return ldexp(p, (int)kf);
+}
+
+// Coefficients of Y(u) = cos(pi sqrt(u) / 2) = sum_k (-pi^2 u / 4)^k / (2k)!.
+// The cosine cutoff 0.5 (cos(pi r / rc) + 1) (reference nn/cutoff.py:43-48)
+// equals Y(u)^2 with u = (r / rc)^2, so no square root or trigonometric
+// instruction is needed for a distance known only through its square.
+constexpr double kQ = -2.4674011002723396547;  // -(pi^2) / 4
+constexpr double cos_coef(int k) {
+  double v = 1.0;
+  for (int j = 1; j <= k; ++j) v *= kQ / double((2 * j - 1) * (2 * j));
+  return v;
+}
+
+// fc(u) and d fc / d u for u = (r / rc)^2 in [0, 1). Callers mask u >= 1.
+__device__ __forceinline__ void cutoff_u(int kind, double u, double &f, double &dfdu) {
+  if (kind == TA_CUTOFF_COSINE) {
+    constexpr double c0 = cos_coef(0), c1 = cos_coef(1), c2 = cos_coef(2), c3 = cos_coef(3),
+                     c4 = cos_coef(4), c5 = cos_coef(5), c6 = cos_coef(6), c7 = cos_coef(7),
+                     c8 = cos_coef(8), c9 = cos_coef(9), c10 = cos_coef(10), c11 = cos_coef(11);
+    double y = c11;
+    y = fma(y, u, c10);
+    y = fma(y, u, c9);
+    y = fma(y, u, c8);
+    y = fma(y, u, c7);
+    y = fma(y, u, c6);
+    y = fma(y, u, c5);
+    y = fma(y, u, c4);
+    y = fma(y, u, c3);
+    y = fma(y, u, c2);
+    y = fma(y, u, c1);
+    y = fma(y, u, c0);
+    double d = 11.0 * c11;
+    d = fma(d, u, 10.0 * c10);
+    d = fma(d, u, 9.0 * c9);
+    d = fma(d, u, 8.0 * c8);
+    d = fma(d, u, 7.0 * c7);
+    d = fma(d, u, 6.0 * c6);
+    d = fma(d, u, 5.0 * c5);
+    d = fma(d, u, 4.0 * c4);
+    d = fma(d, u, 3.0 * c3);
+    d = fma(d, u, 2.0 * c2);
+    d = fma(d, u, c1);
+    f = y * y;
+    dfdu = 2.0 * y * d;
+  } else {
+    // polynomial cutoff, gamma = 5 (reference nn/cutoff.py:78-85):
+    // f = 1 + 5 x^6 - 6 x^5, x = sqrt(u);  df/du = 15 x^3 (x - 1)
+    double x = sqrt(u);
+    double x2 = u, x3 = x2 * x, x5 = x3 * x2;
+    f = 1.0 + 5.0 * x5 * x - 6.0 * x5;
+    dfdu = 15.0 * x3 * (x - 1.0);
+  }
+}
+
+// value only
+__device__ __forceinline__ double cutoff_u_value(int kind, double u) {
+  if (kind == TA_CUTOFF_COSINE) {
+    constexpr double c0 = cos_coef(0), c1 = cos_coef(1), c2 = cos_coef(2), c3 = cos_coef(3),
+                     c4 = cos_coef(4), c5 = cos_coef(5), c6 = cos_coef(6), c7 = cos_coef(7),
+                     c8 = cos_coef(8), c9 = cos_coef(9), c10 = cos_coef(10), c11 = cos_coef(11);
+    double y = c11;
+    y = fma(y, u, c10);
+    y = fma(y, u, c9);
+    y = fma(y, u, c8);
+    y = fma(y, u, c7);
+    y = fma(y, u, c6);
+    y = fma(y, u, c5);
+    y = fma(y, u, c4);
+    y = fma(y, u, c3);
+    y = fma(y, u, c2);
+    y = fma(y, u, c1);
+    y = fma(y, u, c0);
+    return y * y;
+  } else {
+    double x = sqrt(u);
+    double x5 = u * u * x;
+    return 1.0 + 5.0 * x5 * x - 6.0 * x5;
+  }
+}
+
+// base^(zi - 1) for integer zi >= 1 (wave-uniform exponent).
+__device__ __forceinline__ double pow_int_m1(double base, int zi) {
+  double r = 1.0, b = base;
+  int e = zi - 1;
+  while (e) {
+    if (e & 1) r *= b;
+    e >>= 1;
+    if (e) b *= b;
+  }
+  return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// activation value and derivative (reference nn/utils.py:39-74)
+__device__ __forceinline__ void activation_fn(int act, double x, double &h, double &dh) {
+  switch (act) {
+    case TA_ACT_SOFTPLUS: {
+      double e = exp(-fabs(x));
+      h = fmax(x, 0.0) + log1p(e);
+      dh = (x >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
+      break;
+    }
+    case TA_ACT_RELU:
+      h = fmax(x, 0.0);
+      dh = x > 0.0 ? 1.0 : 0.0;
+      break;
+    case TA_ACT_LEAKY_RELU:
+      h = x > 0.0 ? x : 0.2 * x;
+      dh = x > 0.0 ? 1.0 : 0.2;
+      break;
+    case TA_ACT_TANH: {
+      double t = tanh(x);
+      h = t;
+      dh = 1.0 - t * t;
+      break;
+    }
+    case TA_ACT_SIGMOID: {
+      double e = exp(-fabs(x));
+      double s = (x >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
+      h = s;
+      dh = s * (1.0 - s);
+      break;
+    }
+    case TA_ACT_SOFTSIGN: {
+      double d = 1.0 + fabs(x);
+      h = x / d;
+      dh = 1.0 / (d * d);
+      break;
+    }
+    case TA_ACT_ELU:
+      h = x > 0.0 ? x : expm1(x);
+      dh = x > 0.0 ? 1.0 : exp(x);
+      break;
+    case TA_ACT_SQUAREPLUS: {
+      double s = sqrt(x * x + 4.0);
+      h = 0.5 * (x + s);
+      dh = 0.5 * (1.0 + x / s);
+      break;
+    }
+    default:
+      h = x;
+      dh = 1.0;
+  }
+}
+
+}  // namespace ta
