@@ -1,0 +1,204 @@
+"""
+`TensorAlloyCalculator`: drop-in for reference tensoralloy/calculator.py:31-383.
+
+Same constructor, properties and methods; `calculate` runs the HIP library
+instead of a TensorFlow session. `self.results` holds the same keys and shapes
+as the reference: GSL-ordered (element-sorted), virtual-row-stripped arrays for
+`forces` and `energy/atom`; `get_forces` / `get_atomic` map them back to the
+caller's atom order exactly as the reference does (calculator.py:217-249).
+
+Differences (documented in INTEGRATION.md):
+  * `graph_model_path` names a `<name>.json` + `<name>.npz` pair written by
+    `AtomicNN.export` / `EamAlloyNN.export`; TensorFlow GraphDef `.pb` files
+    cannot be parsed without TensorFlow and raise `ValueError`.
+  * `session`, `graph`, `get_op` are TensorFlow objects in the reference; here
+    they raise `AttributeError`.
+  * `hessian`, `elastic`, `eentropy`, `free_energy` are not implemented.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+
+from . import _lib
+from .atoms import BaseCalculator, all_changes
+from .engine import Engine
+from .model import EXPORTABLE_PROPERTIES, load_model
+from .utils import GPa, ModeKeys
+
+
+class TensorAlloyCalculator(BaseCalculator):
+    """ASE-Calculator for tensoralloy_amd model files."""
+
+    implemented_properties = list(EXPORTABLE_PROPERTIES)
+    default_parameters = {}
+    nolabel = True
+
+    def __init__(self, graph_model_path: str, atoms=None, serial_mode=False, device: int = 0):
+        """
+        graph_model_path : the exported model to load.
+        atoms            : the target `Atoms` object.
+        serial_mode      : accepted for compatibility (the reference limits TF
+                           to one CPU thread, calculator.py:70-75); ignored.
+        device           : HIP device index (new; default 0).
+        """
+        super().__init__(restart=None, ignore_bad_restart_file=False, label=None, atoms=atoms)
+        self._graph_model_path = graph_model_path
+        self._mode = ModeKeys.PREDICT
+        nn, clf, meta = load_model(graph_model_path)
+        self._nn = nn
+        self._transformer = clf
+        self._meta = meta
+        self._get_ops()
+        self._engine = Engine(nn, device=device)
+        self.implemented_properties = self._predict_properties
+        self._ncalls = 0
+        self._prerequisite_properties = []
+
+    # -- TF-specific members of the reference ------------------------------------
+    @property
+    def session(self):
+        raise AttributeError("tensoralloy_amd has no TensorFlow session")
+
+    @property
+    def graph(self):
+        raise AttributeError("tensoralloy_amd has no TensorFlow graph")
+
+    def get_op(self, name):
+        raise AttributeError("tensoralloy_amd has no TensorFlow graph")
+
+    # -- metadata ---------------------------------------------------------------------
+    def _get_ops(self):
+        ops = {prop: name for prop, name in self._meta["Metadata/ops"].items()
+               if name.endswith(":0")}
+        if not ops:
+            raise Exception("Validated Ops cannot be found")  # calculator.py:161
+        self._ops = ops
+        self._predict_properties = list(ops.keys())
+        self._fp_precision = self._meta.get("Metadata/precision", "high")
+        if self._fp_precision != "high":
+            raise ValueError("only 'high' (float64) precision models are implemented")
+        self._is_finite_temperature = bool(int(self._meta.get("Metadata/is_finite_temperature", 0)))
+        self._variational_energy = self._meta.get("Metadata/variational_energy", "energy")
+        self._api_version = self._meta.get("Metadata/api", "1.1")
+
+    @property
+    def elements(self) -> List[str]:
+        return self._transformer.elements
+
+    @property
+    def transformer(self):
+        return self._transformer
+
+    @property
+    def predict_properties(self):
+        return self._predict_properties
+
+    def get_model_timestamp(self):
+        return self._meta.get("Metadata/timestamp")
+
+    @property
+    def api_version(self):
+        return self._api_version
+
+    @property
+    def variational_energy(self):
+        return self._variational_energy
+
+    # -- property getters ----------------------------------------------------------------
+    def get_potential_energy(self, atoms=None, force_consistent=False):
+        return self.get_property("energy", atoms)
+
+    def get_magnetic_moment(self, atoms=None):
+        return None
+
+    def get_magnetic_moments(self, atoms=None):
+        return None
+
+    def get_electron_entropy(self, atoms=None):
+        return self.get_property("eentropy", atoms=atoms)
+
+    def get_free_energy(self, atoms=None):
+        return self.get_property("free_energy", atoms=atoms)
+
+    def get_atomic(self, atoms=None, prop="energy"):
+        """Per-atom values in the caller's atom order (calculator.py:217-226)."""
+        atoms = atoms if atoms is not None else self.atoms
+        values = self.get_property(f"{prop}/atom", atoms=atoms)
+        values = np.insert(values, 0, 0, 0)
+        clf = self.transformer.get_vap_transformer(atoms)
+        return clf.map_array(values.reshape((-1, 1)), reverse=True).flatten()
+
+    def get_hessian(self, atoms=None):
+        return self.get_property("hessian", atoms)
+
+    def get_forces(self, atoms=None):
+        atoms = atoms if atoms is not None else self.atoms
+        forces = np.insert(self.get_property("forces", atoms), 0, 0, 0)
+        clf = self.transformer.get_vap_transformer(atoms)
+        return clf.map_forces(forces, reverse=True)
+
+    def get_stress(self, atoms=None, voigt=True):
+        """Stress in eV/Angstrom**3; Voigt order (xx, yy, zz, yz, xz, xy)."""
+        if atoms is None:
+            atoms = self.atoms
+        stress = self.get_property("stress", atoms)
+        if not voigt:
+            xx, yy, zz, yz, xz, xy = stress
+            stress = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+        return stress
+
+    def get_total_pressure(self, atoms=None):
+        """Total pressure in GPa (calculator.py:279-295)."""
+        stress = self.get_stress(atoms)
+        return np.mean(stress[:3]) * (-1.0) / GPa
+
+    def get_elastic_constant_tensor(self, atoms=None):
+        return self.get_property("elastic", atoms, allow_calculation=True)
+
+    def set_prerequisite_properties(self, properties: List[str]):
+        for prop in properties:
+            if prop in self.implemented_properties:
+                self._prerequisite_properties.append(prop)
+
+    # -- the hot path ------------------------------------------------------------------------
+    def calculate(self, atoms=None, properties=("energy", "forces"), system_changes=all_changes,
+                  debug_mode=False, extra_ops=None):
+        """
+        Evaluate `properties` (plus the prerequisite ones) for `atoms`.
+        Replaces `Session.run(ops, feed_dict)` (calculator.py:355-370).
+        """
+        BaseCalculator.calculate(self, atoms, properties, system_changes)
+        atoms = atoms if atoms is not None else self.atoms
+        properties = set(properties).union(self._prerequisite_properties)
+        for target in properties:
+            if target not in self._ops:
+                raise KeyError(target)  # self._ops[target], calculator.py:360
+        want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC
+        if properties & {"forces", "stress", "virial", "total_pressure"}:
+            want |= _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
+        res = self._engine.evaluate([atoms], want=want, descriptors=debug_mode)[0]
+        vap = self.transformer.get_vap_transformer(atoms)
+        results = {}
+        for target in properties:
+            if target == "energy":
+                results[target] = res["energy"]
+            elif target == "energy/atom":
+                # GSL order, virtual row stripped (atomic.py:289-299)
+                results[target] = vap.map_array(res["atomic"].reshape(-1, 1))[1:, 0]
+            elif target == "forces":
+                results[target] = vap.map_forces(res["forces"])[1:]
+            elif target in ("stress", "virial", "total_pressure"):
+                results[target] = res[target]
+        if debug_mode:
+            results["descriptors"] = res["descriptors"]
+        self.results = results
+        self._ncalls += 1
+
+    def reset_call_counter(self):
+        self._ncalls = 0
+
+    @property
+    def ncalls(self):
+        return self._ncalls

@@ -1,0 +1,158 @@
+"""
+`Engine`: thin Python owner of one `ta_handle` (one GPU, one HIP stream).
+
+This is the only place where Python meets the C ABI for evaluation. It plays
+the role of `tf.Session` in the reference calculator (calculator.py:79, :368):
+load once, then run many structures. Frames of a batch are independent units
+and are evaluated by a single set of kernel launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Sequence
+
+import numpy as np
+
+from . import _lib
+from .utils import GPa
+
+
+class Engine:
+    def __init__(self, nn, device: int = 0):
+        self._lib = _lib.load()
+        self._nn = nn
+        self._clf = nn.transformer
+        if self._clf is None:
+            raise ValueError("A descriptor transformer must be attached.")
+        desc, keep = nn.to_desc()
+        self._handle = C.c_void_p()
+        rc = self._lib.ta_create(C.byref(desc), int(device), C.byref(self._handle))
+        del keep
+        if rc != _lib.TA_OK:
+            _lib.check(self._lib, None, rc)
+        self.device = int(device)
+        self.info = None
+        self._frames = None
+        self._volumes = None
+
+    # -- lifetime ----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.ta_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        _lib.check(self._lib, self._handle, rc)
+
+    # -- batch ----------------------------------------------------------------------
+    def set_frames(self, atoms_list: Sequence) -> _lib.BatchInfo:
+        """Neighbour lists + upload; afterwards the batch is resident in HBM."""
+        frames = []
+        periodic = self._clf.periodic
+        for atoms in atoms_list:
+            pbc = np.asarray(atoms.pbc, dtype=bool) if periodic else np.zeros(3, dtype=bool)
+            frames.append(_lib.FrameArrays(self._clf.species_indices(atoms), atoms.positions,
+                                           np.asarray(atoms.get_cell(complete=True)), pbc))
+        arr = (_lib.Frame * max(len(frames), 1))(*[f.as_struct() for f in frames])
+        info = _lib.BatchInfo()
+        self._check(self._lib.ta_set_frames(self._handle, len(frames), arr, C.byref(info)))
+        self.info = info
+        self._frames = frames
+        self._volumes = np.array([abs(np.linalg.det(f.cell)) for f in frames])
+        self._natoms = np.array([len(f.species) for f in frames], dtype=np.int64)
+        return info
+
+    def compute(self, want: int):
+        self._check(self._lib.ta_compute(self._handle, int(want)))
+
+    def synchronize(self):
+        self._check(self._lib.ta_synchronize(self._handle))
+
+    def fetch(self, want: int, descriptors=False) -> dict:
+        """Copy back what `want` asked for; arrays cover the whole batch."""
+        info = self.info
+        N, F = int(info.n_atoms), int(info.n_frames)
+        out = {"energy": np.zeros(F)}
+        forces = virial = atomic = desc = None
+        if want & (_lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL):
+            forces = np.zeros((N, 3))
+            virial = np.zeros((F, 3, 3))
+        if want & _lib.TA_WANT_ATOMIC:
+            atomic = np.zeros(N)
+        if descriptors:
+            desc = np.zeros((N, int(info.descriptor_dim)))
+        null = C.POINTER(C.c_double)()
+        self._check(self._lib.ta_get_results(
+            self._handle, _lib.as_dp(out["energy"]),
+            _lib.as_dp(forces) if forces is not None else null,
+            _lib.as_dp(virial) if virial is not None else null,
+            _lib.as_dp(atomic) if atomic is not None else null,
+            _lib.as_dp(desc) if desc is not None else null))
+        if forces is not None:
+            out["forces"], out["virial"] = forces, virial
+        if atomic is not None:
+            out["atomic"] = atomic
+        if desc is not None:
+            out["descriptors"] = desc
+        return out
+
+    def evaluate(self, atoms_list: Sequence, want: int = None, descriptors=False) -> List[dict]:
+        """One dict per frame: energy, atomic, forces, virial, stress (Voigt,
+        eV/A^3), total_pressure (GPa) in the caller's atom order."""
+        if want is None:
+            want = (_lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL |
+                    _lib.TA_WANT_ATOMIC)
+        self.set_frames(atoms_list)
+        self.compute(want)
+        res = self.fetch(want, descriptors=descriptors)
+        out, a = [], 0
+        for f, n in enumerate(self._natoms):
+            d = {"energy": float(res["energy"][f])}
+            if "atomic" in res:
+                d["atomic"] = res["atomic"][a:a + n].copy()
+            if "forces" in res:
+                d["forces"] = res["forces"][a:a + n].copy()
+                w = res["virial"][f].copy()
+                d["virial"] = w
+                s = w / self._volumes[f]                       # basic.py:317
+                d["stress"] = np.array([s[0, 0], s[1, 1], s[2, 2], s[1, 2], s[0, 2], s[0, 1]])
+                d["total_pressure"] = float(np.trace(s) / (-3.0 * GPa))  # basic.py:403-405
+            if "descriptors" in res:
+                d["descriptors"] = res["descriptors"][a:a + n].copy()
+            out.append(d)
+            a += n
+        return out
+
+    # -- measurement -------------------------------------------------------------------
+    def time_compute(self, want: int, warmup: int, steps: int, per_kernel=True):
+        total = C.c_double(0.0)
+        slots = np.zeros(_lib.TA_N_KERNEL_SLOTS)
+        self._check(self._lib.ta_time_compute(
+            self._handle, int(want), int(warmup), int(steps), C.byref(total),
+            _lib.as_dp(slots) if per_kernel else C.POINTER(C.c_double)()))
+        return total.value, dict(zip(_lib.KERNEL_SLOTS, slots.tolist()))
+
+    def batch_energy_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.ta_batch_energy_device_ptr(self._handle, C.byref(p)))
+        return p.value
+
+    def pairs(self):
+        P = int(self.info.n_pairs)
+        i = np.zeros(max(P, 1), dtype=np.int32)
+        j = np.zeros(max(P, 1), dtype=np.int32)
+        s = np.zeros((max(P, 1), 3), dtype=np.int32)
+        self._check(self._lib.ta_get_pairs(self._handle, _lib.as_ip(i), _lib.as_ip(j), _lib.as_ip(s)))
+        return i[:P], j[:P], s[:P]

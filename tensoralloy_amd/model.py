@@ -1,0 +1,412 @@
+"""
+Host-side model descriptions that mirror the reference's model classes for
+the hot path (names, constructor arguments and `as_dict()` contents match), and
+the model-file format that replaces the frozen TensorFlow `.pb`.
+
+  SymmetryFunction  <- reference tensoralloy/nn/atomic/sf.py:26-77
+  AtomicNN          <- reference tensoralloy/nn/atomic/atomic.py:60-132 (+ BasicNN,
+                       tensoralloy/nn/basic.py:99-160)
+  AtomicNN.export   <- reference tensoralloy/nn/basic.py:1017-1153: the JSON
+                       constants `Transformer/params` and `Metadata/*` become
+                       `<name>.json`, the frozen variables become `<name>.npz`
+                       with the key naming of `export_to_lammps_native`
+                       (atomic.py:452-478): `weights_{element}_{layer}`,
+                       `biases_{element}_{layer}`, plus `xlo_{element}`,
+                       `xhi_{element}` for the min-max variables.
+
+These classes hold parameters only; all arithmetic happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from datetime import datetime
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from .utils import Defaults, get_kbody_terms, parameter_grid
+
+API_VERSION = "1.1"  # reference nn/basic.py:43
+
+#: properties the reference can export (nn/basic.py:74-92)
+EXPORTABLE_PROPERTIES = ["energy", "eentropy", "free_energy", "atomic", "forces", "stress",
+                         "total_pressure", "hessian", "elastic"]
+#: properties this build computes
+SUPPORTED_PROPERTIES = ["energy", "atomic", "forces", "stress", "total_pressure"]
+
+
+def _safe_select(a, b):
+    if a is None:
+        return b
+    if hasattr(a, "__len__") and len(a) == 0:
+        return b
+    return a
+
+
+class SymmetryFunction:
+    """Behler G2 / G4 symmetry-function descriptor parameters."""
+
+    def __init__(self, elements: Sequence[str], eta=Defaults.eta, omega=Defaults.omega,
+                 beta=Defaults.beta, gamma=Defaults.gamma, zeta=Defaults.zeta,
+                 cutoff_function="cosine"):
+        self._elements = sorted(list(elements))
+        self._eta = np.asarray(eta, dtype=np.float64).ravel()
+        self._omega = np.asarray(omega, dtype=np.float64).ravel()
+        self._beta = np.asarray(beta, dtype=np.float64).ravel()
+        self._gamma = np.asarray(gamma, dtype=np.float64).ravel()
+        self._zeta = np.asarray(zeta, dtype=np.float64).ravel()
+        if cutoff_function not in _lib.TA_CUTOFF:
+            # the reference silently uses the polynomial cutoff for any other
+            # string (sf.py:70-77); refuse instead of guessing
+            raise ValueError(f"Unknown cutoff function: {cutoff_function}")
+        self._cutoff_function = cutoff_function
+        self._radial_parameters = parameter_grid(eta=self._eta, omega=self._omega)
+        self._angular_parameters = parameter_grid(beta=self._beta, gamma=self._gamma,
+                                                  zeta=self._zeta)
+
+    @property
+    def name(self):
+        return "SF"
+
+    @property
+    def elements(self):
+        return self._elements
+
+    @property
+    def radial_parameters(self):
+        return self._radial_parameters
+
+    @property
+    def angular_parameters(self):
+        return self._angular_parameters
+
+    @property
+    def cutoff_function(self):
+        return self._cutoff_function
+
+    def as_dict(self):
+        return {"class": self.__class__.__name__, "elements": self._elements,
+                "eta": self._eta.tolist(), "omega": self._omega.tolist(),
+                "gamma": self._gamma.tolist(), "zeta": self._zeta.tolist(),
+                "beta": self._beta.tolist(), "cutoff_function": self._cutoff_function}
+
+    def ndim(self, angular: bool) -> int:
+        n = len(self._elements)
+        d = n * len(self._radial_parameters)
+        if angular:
+            d += n * (n + 1) // 2 * len(self._angular_parameters)
+        return d
+
+
+class AtomicNN:
+    """
+    Per-element MLP on symmetry-function descriptors: parameter container with
+    the constructor of the reference `AtomicNN`.
+    """
+
+    scope = "Atomic"
+
+    def __init__(self, elements: Sequence[str], descriptor: Union[SymmetryFunction, dict],
+                 hidden_sizes=None, activation=None, kernel_initializer="he_normal",
+                 minmax_scale=True, use_resnet_dt=False, atomic_static_energy=None,
+                 use_atomic_static_energy=True, fixed_atomic_static_energy=False,
+                 minimize_properties=("energy", "forces"),
+                 export_properties=("energy", "forces")):
+        self._elements = sorted(list(elements))
+        self._hidden_sizes = self._get_hidden_sizes(
+            _safe_select(hidden_sizes, Defaults.hidden_sizes))
+        self._activation = _safe_select(activation, Defaults.activation)
+        if self._activation.lower() not in _lib.TA_ACT:
+            raise ValueError(
+                f"The activation function '{self._activation}' cannot be recognized!")
+        for prop in export_properties:
+            if prop not in EXPORTABLE_PROPERTIES:
+                raise ValueError(f"'{prop}' is not an exportable property.")
+        self._kernel_initializer = kernel_initializer
+        self._minmax_scale = bool(minmax_scale)
+        self._use_resnet_dt = bool(use_resnet_dt)
+        self._atomic_static_energy = dict(atomic_static_energy or {})
+        self._use_atomic_static_energy = bool(use_atomic_static_energy)
+        self._fixed_atomic_static_energy = bool(fixed_atomic_static_energy)
+        self._minimize_properties = list(minimize_properties)
+        self._export_properties = list(export_properties)
+        if isinstance(descriptor, dict):
+            d = dict(descriptor)
+            cls = d.pop("class", "SymmetryFunction")
+            d.pop("@module", None)
+            d.pop("@class", None)
+            if cls != "SymmetryFunction":
+                raise ValueError(f"Unsupported descriptor: {cls}")
+            descriptor = SymmetryFunction(**d)
+        self._descriptor = descriptor
+        self._transformer = None
+        #: {element: [(W [in, out], b [out] | None), ...]} last entry = output layer
+        self.weights: Dict[str, List] = {}
+        #: {element: (xlo [D], xhi [D])}
+        self.minmax: Dict[str, tuple] = {}
+
+    def _get_hidden_sizes(self, hidden_sizes) -> Dict[str, List[int]]:
+        if isinstance(hidden_sizes, dict):
+            out = {}
+            for el in self._elements:
+                v = hidden_sizes.get(el, Defaults.hidden_sizes)
+                out[el] = [int(x) for x in np.atleast_1d(v)]
+            return out
+        sizes = [int(x) for x in np.atleast_1d(hidden_sizes)]
+        return {el: list(sizes) for el in self._elements}
+
+    # -- reference-compatible surface ------------------------------------
+    @property
+    def elements(self):
+        return self._elements
+
+    @property
+    def hidden_sizes(self):
+        return self._hidden_sizes
+
+    @property
+    def descriptor(self):
+        return self._descriptor
+
+    @property
+    def predict_properties(self):
+        return self._export_properties
+
+    @property
+    def variational_energy(self):
+        return "energy"
+
+    @property
+    def is_finite_temperature(self):
+        return False
+
+    @property
+    def transformer(self):
+        return self._transformer
+
+    def attach_transformer(self, clf):
+        self._transformer = clf
+
+    def as_dict(self):
+        return {"class": self.__class__.__name__, "elements": self._elements,
+                "hidden_sizes": self._hidden_sizes, "activation": self._activation,
+                "kernel_initializer": self._kernel_initializer,
+                "minmax_scale": self._minmax_scale, "use_resnet_dt": self._use_resnet_dt,
+                "use_atomic_static_energy": self._use_atomic_static_energy,
+                "fixed_atomic_static_energy": self._fixed_atomic_static_energy,
+                "atomic_static_energy": self._atomic_static_energy,
+                "minimize_properties": self._minimize_properties,
+                "export_properties": self._export_properties,
+                "descriptor": self._descriptor.as_dict()}
+
+    # -- weights -----------------------------------------------------------
+    def ndim(self) -> int:
+        if self._transformer is None:
+            raise ValueError("A descriptor transformer must be attached.")
+        return self._descriptor.ndim(self._transformer.angular)
+
+    def initialize(self, seed=Defaults.seed, bias_scale=0.0):
+        """
+        Random-init variables the way the reference initialises them: He-normal
+        kernels (sigma = sqrt(2 / fan_in), truncated at 2 sigma,
+        nn/init_ops.py:20-30), zero biases, output bias = atomic static energy
+        (atomic.py:236-259), xlo = 1000 / xhi = 0 (atomic.py:176-177).
+        """
+        rng = np.random.RandomState(seed)
+        D = self.ndim()
+        for el in self._elements:
+            sizes = [D] + list(self._hidden_sizes[el]) + [1]
+            layers = []
+            for l in range(len(sizes) - 1):
+                fan_in, fan_out = sizes[l], sizes[l + 1]
+                sigma = np.sqrt(2.0 / fan_in)
+                w = rng.normal(0.0, sigma, size=(fan_in, fan_out))
+                bad = np.abs(w) > 2 * sigma
+                while bad.any():
+                    w[bad] = rng.normal(0.0, sigma, size=int(bad.sum()))
+                    bad = np.abs(w) > 2 * sigma
+                last = l == len(sizes) - 2
+                if last:
+                    b = (np.full(1, float(self._atomic_static_energy.get(el, 0.0)))
+                         if self._use_atomic_static_energy else None)
+                else:
+                    b = bias_scale * rng.normal(size=fan_out) if bias_scale else np.zeros(fan_out)
+                layers.append((w, b))
+            self.weights[el] = layers
+            if self._minmax_scale:
+                self.minmax[el] = (np.full(D, 1000.0), np.zeros(D))
+
+    # -- model file ----------------------------------------------------------
+    def export(self, output_graph_path: str, **_ignored):
+        """
+        Write `<stem>.json` + `<stem>.npz`. `output_graph_path` may end in
+        `.json`, `.npz`, `.pb` (the reference's extension) or nothing.
+        """
+        if self._transformer is None:
+            raise ValueError("A transformer must be attached before exporting to a pb file.")
+        if not self.weights:
+            raise ValueError("The model has no weights: call initialize() or set .weights")
+        stem = _model_stem(output_graph_path)
+        props = {"energy": "Output/Energy/energy:0", "energy/atom": "Output/Energy/atomic:0"}
+        want = set(self._export_properties)
+        if want & {"forces", "stress", "total_pressure"}:
+            props["forces"] = "Output/Forces/forces:0"
+        if "stress" in want:
+            props["stress"] = "Output/Stress/Voigt/stress:0"
+            props["virial"] = "Output/Stress/Full/virial:0"
+            props["total_pressure"] = "Output/Stress/pressure/GPa:0"
+        for unsupported in ("hessian", "elastic"):
+            if unsupported in want:
+                raise ValueError(f"'{unsupported}' is not implemented by tensoralloy_amd")
+        meta = {
+            "format": "tensoralloy_amd/1",
+            "Transformer/params": self._transformer.as_dict(),
+            "Metadata/timestamp": str(datetime.today()),
+            "Metadata/precision": "high",
+            "Metadata/variational_energy": self.variational_energy,
+            "Metadata/is_finite_temperature": 0,
+            "Metadata/api": API_VERSION,
+            "Metadata/ops": props,
+            "nn": self.as_dict(),
+            "weights": os.path.basename(stem) + ".npz",
+        }
+        data = {}
+        for i, el in enumerate(self._elements):
+            for j, (w, b) in enumerate(self.weights[el]):
+                data[f"weights_{i}_{j}"] = np.asarray(w, dtype=np.float64)
+                if b is not None:
+                    data[f"biases_{i}_{j}"] = np.asarray(b, dtype=np.float64)
+            if self._minmax_scale:
+                xlo, xhi = self.minmax[el]
+                data[f"xlo_{i}"] = np.asarray(xlo, dtype=np.float64)
+                data[f"xhi_{i}"] = np.asarray(xhi, dtype=np.float64)
+        np.savez(stem + ".npz", **data)
+        with open(stem + ".json", "w") as fp:
+            json.dump(meta, fp, indent=1)
+        return stem + ".json"
+
+    # -- C ABI -----------------------------------------------------------------
+    def to_desc(self):
+        """Flatten into a `ta_model_desc`; returns (desc, keepalive list)."""
+        clf = self._transformer
+        if clf is None:
+            raise ValueError("A descriptor transformer must be attached.")
+        if not clf.symmetric and clf.angular:
+            raise ValueError("symmetric=False angular terms are not implemented by tensoralloy_amd")
+        sf = self._descriptor
+        D = self.ndim()
+        keep = []
+
+        def dptr(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return _lib.as_dp(a)
+
+        def iptr(a):
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            keep.append(a)
+            return _lib.as_ip(a)
+
+        n_layers, sizes, flat = [], [], []
+        for el in self._elements:
+            layers = self.weights[el]
+            n_layers.append(len(layers))
+            s = [D]
+            for w, b in layers:
+                w = np.asarray(w, dtype=np.float64)
+                if w.ndim != 2 or w.shape[0] != s[-1]:
+                    raise ValueError(f"weight shape {w.shape} does not chain from {s[-1]}")
+                s.append(w.shape[1])
+                flat.append(w.ravel())
+                flat.append(np.zeros(w.shape[1]) if b is None
+                            else np.asarray(b, dtype=np.float64).ravel())
+            sizes.extend(s)
+        desc = _lib.ModelDesc()
+        desc.kind = _lib.TA_MODEL_SF_MLP
+        desc.n_elements = len(self._elements)
+        desc.rcut = float(clf.rcut)
+        desc.acut = float(clf.acut if clf.acut is not None else clf.rcut)
+        desc.angular = int(bool(clf.angular))
+        desc.cutoff_function = _lib.TA_CUTOFF[sf.cutoff_function]
+        desc.n_eta, desc.n_omega = len(sf._eta), len(sf._omega)
+        desc.n_beta, desc.n_gamma, desc.n_zeta = len(sf._beta), len(sf._gamma), len(sf._zeta)
+        desc.eta, desc.omega = dptr(sf._eta), dptr(sf._omega)
+        desc.beta, desc.gamma, desc.zeta = dptr(sf._beta), dptr(sf._gamma), dptr(sf._zeta)
+        desc.activation = _lib.TA_ACT[self._activation.lower()]
+        desc.use_resnet_dt = int(self._use_resnet_dt)
+        desc.minmax_scale = int(self._minmax_scale)
+        desc.n_layers = iptr(n_layers)
+        desc.layer_sizes = iptr(sizes)
+        desc.weights = dptr(np.concatenate(flat))
+        if self._minmax_scale:
+            desc.xlo = dptr(np.concatenate([np.ravel(self.minmax[el][0]) for el in self._elements]))
+            desc.xhi = dptr(np.concatenate([np.ravel(self.minmax[el][1]) for el in self._elements]))
+        desc.n_eam_params = 0
+        return desc, keep
+
+
+def _model_stem(path: str) -> str:
+    path = str(path)
+    for ext in (".json", ".npz", ".pb"):
+        if path.endswith(ext):
+            return path[: -len(ext)]
+    return path
+
+
+def load_model(graph_model_path: str):
+    """
+    Read a model written by `AtomicNN.export` (or `EamAlloyNN.export`). Returns
+    (nn, transformer, metadata dict).
+    """
+    from .transformer import UniversalTransformer
+
+    path = str(graph_model_path)
+    if path.endswith(".pb"):
+        stem = _model_stem(path)
+        if not os.path.exists(stem + ".json"):
+            raise ValueError(
+                f"{path}: TensorFlow GraphDef files cannot be read by tensoralloy_amd; "
+                f"export the model as <name>.json + <name>.npz (see INTEGRATION.md)")
+    stem = _model_stem(path)
+    with open(stem + ".json") as fp:
+        meta = json.load(fp)
+    if meta.get("format") != "tensoralloy_amd/1":
+        raise ValueError(f"{stem}.json: unknown model format {meta.get('format')!r}")
+    params = dict(meta["Transformer/params"])
+    cls = params.pop("class")
+    params.pop("predict_properties", None)
+    if cls != "UniversalTransformer":
+        raise ValueError(f"Unsupported transformer: {cls}")  # calculator.py:142
+    clf = UniversalTransformer(**params)
+    cfg = dict(meta["nn"])
+    nn_cls = cfg.pop("class")
+    if nn_cls == "AtomicNN":
+        nn = AtomicNN(**cfg)
+        nn.attach_transformer(clf)
+        npz = np.load(os.path.join(os.path.dirname(stem) or ".", meta["weights"]))
+        for i, el in enumerate(nn.elements):
+            layers = []
+            j = 0
+            while f"weights_{i}_{j}" in npz:
+                w = np.array(npz[f"weights_{i}_{j}"], dtype=np.float64)
+                if w.ndim == 1:
+                    w = w.reshape(-1, 1)
+                b = np.array(npz[f"biases_{i}_{j}"], dtype=np.float64).ravel() \
+                    if f"biases_{i}_{j}" in npz else None
+                layers.append((w, b))
+                j += 1
+            if not layers:
+                raise ValueError(f"{stem}.npz holds no weights for element {el}")
+            nn.weights[el] = layers
+            if nn._minmax_scale:
+                nn.minmax[el] = (np.array(npz[f"xlo_{i}"]), np.array(npz[f"xhi_{i}"]))
+    elif nn_cls in ("EamAlloyNN", "AdpNN"):
+        from .eam import nn_from_dict
+        nn = nn_from_dict(nn_cls, cfg)
+        nn.attach_transformer(clf)
+    else:
+        raise ValueError(f"Unsupported model class: {nn_cls}")
+    return nn, clf, meta

@@ -1,0 +1,6 @@
+"""Host-side mirror of `tensoralloy.transformer` (descriptor surface)."""
+from .universal import UniversalTransformer
+from .vap import VirtualAtomMap
+from .metadata import RadialMetadata, AngularMetadata
+
+__all__ = ["UniversalTransformer", "VirtualAtomMap", "RadialMetadata", "AngularMetadata"]

@@ -1,0 +1,60 @@
+"""Shared builders for tests: structures and seeded models."""
+import numpy as np
+
+from tensoralloy_amd import Atoms, AtomicNN, SymmetryFunction, UniversalTransformer
+
+
+def fcc(symbol="Ni", a=3.524, rep=(2, 2, 2), jitter=0.05, seed=611):
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
+    pts = np.array([base + np.array([x, y, z]) * a
+                    for x in range(rep[0]) for y in range(rep[1]) for z in range(rep[2])]).reshape(-1, 3)
+    rng = np.random.RandomState(seed)
+    pts = pts + rng.normal(0.0, jitter, pts.shape)
+    return Atoms(symbols=[symbol] * len(pts), positions=pts,
+                 cell=np.diag([a * rep[0], a * rep[1], a * rep[2]]), pbc=True)
+
+
+def pd3o2():
+    return Atoms(symbols="Pd3O2", pbc=[True, True, False],
+                 cell=np.array([[7.78, 0., 0.], [0., 5.50129076, 0.], [0., 0., 15.37532269]]),
+                 positions=np.array([[3.89, 0., 8.37532269], [0., 2.75064538, 8.37532269],
+                                     [3.89, 2.75064538, 8.37532269], [5.835, 1.37532269, 8.5],
+                                     [5.835, 7.12596807, 8.]]))
+
+
+def make_nn(elements, rcut, angular, hidden, activation="softplus", acut=None, seed=611,
+            minmax=False, resnet=False, bias_scale=0.1, cutoff="cosine", sf_kwargs=None,
+            static_energy=None):
+    clf = UniversalTransformer(elements, rcut=rcut, acut=acut, angular=angular)
+    sf = SymmetryFunction(elements, cutoff_function=cutoff, **(sf_kwargs or {}))
+    nn = AtomicNN(elements, sf, hidden_sizes=hidden, activation=activation,
+                  minmax_scale=minmax, use_resnet_dt=resnet,
+                  atomic_static_energy=static_energy or {},
+                  export_properties=("energy", "forces", "stress"))
+    nn.attach_transformer(clf)
+    nn.initialize(seed=seed, bias_scale=bias_scale)
+    if minmax:
+        rng = np.random.RandomState(seed + 1)
+        D = nn.ndim()
+        for el in nn.elements:
+            nn.minmax[el] = (rng.rand(D) * 0.1, 1.0 + rng.rand(D) * 5.0)
+    return nn
+
+
+def oracle_model(nn):
+    """The same model as an oracle `SFModel` (test infrastructure only)."""
+    from oracle.sf import SFModel
+    clf, sf = nn.transformer, nn.descriptor
+    d = sf.as_dict()
+    m = SFModel(nn.elements, clf.rcut, acut=clf.acut, angular=clf.angular, eta=d["eta"],
+                omega=d["omega"], beta=d["beta"], gamma=d["gamma"], zeta=d["zeta"],
+                cutoff_function=d["cutoff_function"], hidden_sizes=nn.hidden_sizes,
+                activation=nn._activation, weights=nn.weights, use_resnet_dt=nn._use_resnet_dt,
+                minmax=nn.minmax if nn._minmax_scale else None)
+    return m
+
+
+def oracle_eval(nn, atoms, want_forces=True):
+    from oracle.sf import evaluate
+    return evaluate(oracle_model(nn), atoms.get_chemical_symbols(), atoms.positions,
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, want_forces=want_forces)
