@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""
+bench.py — atom-steps/s of the hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (pair geometry -> G2/G4 descriptors ->
+per-atom MLP -> energy -> analytic forces + virial) over this rank's resident
+batch of frames. Workload at N = 1 = BASELINE.json configs[1]: 4000-atom Ni fcc
+supercell (a = 3.524 A, 10x10x10 cells, N(0, 0.05 A) jitter, RandomState(611)),
+rcut = acut = 6.5 A, G2 eta {0.05,4,20,80} x omega {0}, G4 beta {0.005} x
+gamma {1,-1} x zeta {1,4} (D = 8), MLP 8-64-64-1 softplus, fp64,
+energy + forces + virial. Inputs (positions, cells, neighbour list) are
+resident in HBM before the timed region; the neighbour-list build is reported
+separately. For N > 1 every rank owns `--frames-per-gpu` independent frames
+(weak scaling) and the only collective is one RCCL all-reduce of the batch
+energy per step.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md §Chip-level parameters
+E_TOL, F_TOL = 1e-6, 1e-5  # north_star parity tolerances (eV, eV/A)
+
+
+def host_cores():
+    """Threads for the CPU baseline: the cores this process may actually use
+    (affinity mask, capped by the cgroup CPU quota when there is one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fp:
+            quota, period = fp.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        n = int(env)
+    return max(1, min(n, 64))
+
+
+def ni_frame(seed, rep=10, a=3.524, jitter=0.05):
+    from tensoralloy_amd import Atoms
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
+    pts = np.array([base + np.array([x, y, z]) * a
+                    for x in range(rep) for y in range(rep) for z in range(rep)]).reshape(-1, 3)
+    pts = pts + np.random.RandomState(seed).normal(0.0, jitter, pts.shape)
+    return Atoms(symbols=["Ni"] * len(pts), positions=pts, cell=np.eye(3) * a * rep, pbc=True)
+
+
+def ni_model():
+    from tensoralloy_amd import AtomicNN, SymmetryFunction, UniversalTransformer
+    clf = UniversalTransformer(["Ni"], rcut=6.5, acut=6.5, angular=True)
+    nn = AtomicNN(["Ni"], SymmetryFunction(["Ni"]), hidden_sizes=[64, 64], activation="softplus",
+                  minmax_scale=False, use_resnet_dt=False, use_atomic_static_energy=True,
+                  export_properties=("energy", "forces", "stress"))
+    nn.attach_transformer(clf)
+    nn.initialize(seed=611)
+    return nn
+
+
+def oracle_sfmodel(nn):
+    """Same model for the CPU oracle (checker / cpu_baseline only)."""
+    from oracle.sf import SFModel
+    d = nn.descriptor.as_dict()
+    clf = nn.transformer
+    return SFModel(nn.elements, clf.rcut, acut=clf.acut, angular=clf.angular, eta=d["eta"],
+                   omega=d["omega"], beta=d["beta"], gamma=d["gamma"], zeta=d["zeta"],
+                   cutoff_function=d["cutoff_function"], hidden_sizes=nn.hidden_sizes,
+                   activation=nn._activation, weights=nn.weights,
+                   use_resnet_dt=nn._use_resnet_dt, minmax=None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--rep", type=int, default=10, help="fcc cells per edge (10 -> 4000 atoms)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-evals", type=int, default=6)
+    args = ap.parse_args()
+
+    from tensoralloy_amd.parallel import world_from_env
+    rank, local_rank, world = world_from_env()
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime must be the one the process shares
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tensoralloy_amd import Engine, _lib
+    _lib.build()
+    nn = ni_model()
+    eng = Engine(nn, device=local_rank)
+    fpg = args.frames_per_gpu
+    frames = [ni_frame(611 + rank * fpg + k, rep=args.rep) for k in range(fpg)]
+    t0 = time.perf_counter()
+    info = eng.set_frames(frames)
+    t_nl = time.perf_counter() - t0
+    want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
+    n_atoms, P, T = int(info.n_atoms), int(info.n_pairs), int(info.n_triples)
+    D = int(info.descriptor_dim)
+
+    ebuf = None
+    if world > 1:
+        ebuf = torch.zeros(2, dtype=torch.float64, device=f"cuda:{local_rank}")
+
+    def step(k):
+        eng.compute(want)
+        if world > 1:
+            # batch energy -> torch buffer on the engine's stream, then one RCCL all-reduce
+            slot = ebuf[k % 2:k % 2 + 1]
+            eng.copy_batch_energy(slot.data_ptr())
+            eng.synchronize()
+            return dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    def sync_all():
+        eng.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pending = [step(k) for k in range(args.warmup)]
+    for w in pending:
+        if w is not None:
+            w.wait()
+    sync_all()
+    t0 = time.perf_counter()
+    pending = [step(k) for k in range(args.steps)]
+    for w in pending:
+        if w is not None:
+            w.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(n_atoms)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_atoms = float(tot.item())
+    else:
+        total_atoms = float(n_atoms)
+    value = total_atoms * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations with HIP events on the engine's stream ----
+        ev_total_ms, slots = eng.time_compute(want, 2, max(5, min(args.steps, 20)))
+        # dominant kernel = backward sweep over ordered triples: SURVEY §8(d) prices one
+        # pass over the packed records at 32 B / pair + 60 B / triple
+        bwd_bytes = 32.0 * P + 60.0 * T
+        bwd_ms = slots["backward"]
+        achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        eval_bytes = 2.0 * (32.0 * P + 60.0 * T) + n_atoms * 8.0 * (3 * D + 4) + 72.0 * fpg
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fp:
+                    traffic = json.load(fp).get("backward_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "backward_kernel<1,2,2>", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "algorithmic_bytes_per_launch": bwd_bytes,
+                    "kernel_ms": bwd_ms,
+                    "whole_eval_bytes": eval_bytes,
+                    "whole_eval_frac": eval_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    "note": "triples are generated on the fly from LDS-staged pair records, so "
+                            "HBM traffic is far below the packed-record bytes the formula prices"}
+
+        # ---- parity gate + CPU baseline (oracle = checker, timed on host cores) ----
+        res = eng.fetch(want)
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import csf
+            m = oracle_sfmodel(nn)
+            a = frames[0]
+            prep = csf.prepare(m, a.get_chemical_symbols(), a.positions,
+                               np.asarray(a.get_cell(complete=True)), a.pbc)
+            cm = csf.make_cmodel(m)
+            cores = host_cores()
+            ref = csf.run(m, prep, True, cores, cm)  # warm-up + parity reference
+            n0 = len(a)
+            dE = abs(ref["energy"] - float(res["energy"][0]))
+            dF = float(np.abs(ref["forces"] - res["forces"][:n0]).max())
+            dW = float(np.abs(ref["virial"] - res["virial"][0]).max())
+            if not (dE < E_TOL and dF < F_TOL):
+                raise SystemExit(f"PARITY FAILURE vs CPU oracle: dE={dE:.3e} eV dF={dF:.3e} eV/A")
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_evals):
+                csf.run(m, prep, True, cores, cm)
+            tc = (time.perf_counter() - t0) / args.cpu_evals
+            cpu = {"value": n0 / tc, "unit": "atom-steps/s", "cores": cores, "kind": "port",
+                   "sample": f"{args.cpu_evals} evaluations of frame 0 ({n0} atoms, {len(prep['i'])} "
+                             f"pairs) by oracle/c/sf_oracle.c (OpenMP, {cores} threads), same "
+                             f"model; neighbour list excluded as for the GPU",
+                   "ms_per_eval": tc * 1e3,
+                   "parity": {"dE_eV": dE, "dF_max_eV_per_A": dF, "dW_max_eV": dW}}
+        out = {
+            "metric": "atom-steps/sec (energy+forces), 4000-atom Ni rcut=6.5 A",
+            "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_atoms // fpg}-atom Ni fcc supercell (a=3.524, "
+                                   f"{args.rep}^3 cells, jitter 0.05 A, seed 611+frame), G2+G4 "
+                                   f"rcut=acut=6.5, D={D}, MLP {D}-64-64-1 softplus, "
+                                   f"energy+forces+virial",
+                       "frames_per_gpu": fpg, "atoms_per_gpu": n_atoms, "pairs_per_gpu": P,
+                       "triples_per_gpu": T, "parallelism": f"frames sharded over {world} GPU(s)"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernel_ms": slots,
+            "event_ms_per_step": ev_total_ms / max(5, min(args.steps, 20)),
+            "neighbor_list_host_s": t_nl,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

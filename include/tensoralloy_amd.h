@@ -176,6 +176,10 @@ int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
  * collective: returns a device pointer to one double (valid until destroy). */
 int ta_batch_energy_device_ptr(ta_handle h, void **dptr);
 
+/* enqueues, on the handle's stream, a device-to-device copy of that double into
+ * `dst_device` (e.g. the buffer a RCCL all-reduce will sum across ranks). */
+int ta_copy_batch_energy(ta_handle h, void *dst_device);
+
 /* debugging / parity: host copy of the pair list of the resident batch
  * (centre, neighbour, shift[3]) in the library's order. Arrays sized n_pairs. */
 int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift /*[n][3]*/);

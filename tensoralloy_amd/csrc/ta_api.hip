@@ -632,6 +632,15 @@ int ta_batch_energy_device_ptr(ta_handle h, void **dptr) {
   return TA_OK;
 }
 
+int ta_copy_batch_energy(ta_handle h, void *dst_device) {
+  if (!h || !dst_device) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  return guarded(h, [&]() {
+    HIP_CHECK(hipMemcpyAsync(dst_device, h->db.batch_energy, sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+  });
+}
+
 int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64_t *n_pairs,
                      int32_t **i, int32_t **j, int32_t **shift, int32_t **rev) {
   if (!frame || !n_pairs || n_elements < 1 || !(rc > 0.0))

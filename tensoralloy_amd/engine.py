@@ -149,6 +149,10 @@ class Engine:
         self._check(self._lib.ta_batch_energy_device_ptr(self._handle, C.byref(p)))
         return p.value
 
+    def copy_batch_energy(self, dst_device_ptr: int):
+        """Enqueue a D2D copy of the batch energy (one double) on the engine's stream."""
+        self._check(self._lib.ta_copy_batch_energy(self._handle, C.c_void_p(int(dst_device_ptr))))
+
     def pairs(self):
         P = int(self.info.n_pairs)
         i = np.zeros(max(P, 1), dtype=np.int32)
