@@ -19,7 +19,8 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_mlp.hip", "ta_eam.hip", "ta_neighbor.cpp"]
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_mlp.hip", "ta_eam.hip",
+           "ta_neighbor.cpp"]
 
 TA_OK = 0
 TA_ERR_INVALID, TA_ERR_UNSUPPORTED, TA_ERR_HIP, TA_ERR_NOMEM = -1, -2, -3, -4

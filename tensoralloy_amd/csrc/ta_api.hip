@@ -78,7 +78,9 @@ struct ta_context {
   int activation = 0;
   double rmax = 0.0;
   ta::SFParams sf;
-  std::vector<ChunkPlan> chunks;
+  std::vector<ChunkPlan> chunks;     // first-generation kernels: up to 2 betas per launch
+  std::vector<ChunkPlan> chunks_v2;  // second-generation kernels: one beta per launch
+  bool use_v2 = false;
   ta::MlpDev mlp[ta::kMaxElements];
   std::vector<void *> model_allocs;
   ta::EamModel *eam = nullptr;
@@ -91,7 +93,7 @@ struct ta_context {
   DevBuf<double> pos, cells, rec, part4, G, dEdG, eatom, g, forces, wat, energy, virial, benergy,
       mlp_scratch;
   DevBuf<int32_t> species, frame_of_atom, atom_start, pair_start, seg_start, pair_i, pair_j,
-      pair_shift, pair_rev, elem_atoms;
+      pair_shift, pair_rev, elem_atoms, blk_center;
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
   std::string err;
@@ -118,6 +120,46 @@ T *upload(ta_context *h, const std::vector<T> &v) {
 }
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Power series in u of Hd(u) = exp(-beta u) * 0.5 (1 + cos(pi sqrt(u))) on [0, 1]
+// (cosine cutoff nn/cutoff.py:43-48 times the Gaussian of sf.py:166-168 for the
+// third side of a triple), in long double. Picks 16 or 24 coefficients when
+// the truncated tail is below 1e-17, otherwise leaves n_hd = 0 (exact path).
+void hd_series(int cutoff, double beta, ta::AngChunk &ch) {
+  ch.n_hd = 0;
+  for (double &c : ch.hd) c = 0.0;
+  if (cutoff != TA_CUTOFF_COSINE || !(beta >= 0.0)) return;
+  constexpr int NT = 64;
+  const long double pi2 = 9.869604401089358618834490999876151135L;
+  long double fc[NT], ex[NT], prod[NT];
+  long double t = 1.0L;  // (-pi^2)^k / (2k)!
+  for (int k = 0; k < NT; ++k) {
+    fc[k] = 0.5L * t + (k == 0 ? 0.5L : 0.0L);
+    t *= -pi2 / (long double)((2 * k + 1) * (2 * k + 2));
+  }
+  t = 1.0L;  // (-beta)^k / k!
+  for (int k = 0; k < NT; ++k) {
+    ex[k] = t;
+    t *= -(long double)beta / (long double)(k + 1);
+  }
+  for (int k = 0; k < NT; ++k) {
+    long double acc = 0.0L;
+    for (int j = 0; j <= k; ++j) acc += fc[j] * ex[k - j];
+    prod[k] = acc;
+  }
+  for (int n : {16, 24}) {
+    long double tail = 0.0L;
+    for (int k = n; k < NT; ++k) tail += fabsl(prod[k]);
+    // the derivative series loses one more order: bound k |c_k| as well
+    long double dtail = 0.0L;
+    for (int k = n; k < NT; ++k) dtail += (long double)k * fabsl(prod[k]);
+    if (tail < 1e-17L && dtail < 1e-15L) {
+      ch.n_hd = n;
+      for (int k = 0; k < n; ++k) ch.hd[k] = (double)prod[k];
+      return;
+    }
+  }
+}
 
 void build_sf_model(ta_context *h, const ta_model_desc *m) {
   using namespace ta;
@@ -159,12 +201,13 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
     for (int k = 0; k < m->n_beta; ++k) sf.beta[k] = m->beta[k];
     sf.n_ang = m->n_beta * m->n_gamma * m->n_zeta;
     // channel (ib, ig, iz) -> (ib * n_gamma + ig) * n_zeta + iz  (zeta fastest, sf.py:49-51)
-    for (int b0 = 0; b0 < m->n_beta; b0 += 2)
+    for (int pass = 0; pass < 2; ++pass)
+    for (int b0 = 0; b0 < m->n_beta; b0 += (pass == 0 ? 2 : 1))
       for (int g0 = 0; g0 < m->n_gamma; g0 += 2)
         for (int z0 = 0; z0 < m->n_zeta; z0 += 2) {
           ChunkPlan cp;
           std::memset(&cp, 0, sizeof(cp));
-          cp.nb = std::min(2, m->n_beta - b0);
+          cp.nb = std::min(pass == 0 ? 2 : 1, m->n_beta - b0);
           cp.ng = std::min(2, m->n_gamma - g0);
           cp.nz = std::min(2, m->n_zeta - z0);
           for (int ib = 0; ib < cp.nb; ++ib) {
@@ -184,7 +227,8 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
               for (int iz = 0; iz < cp.nz; ++iz)
                 cp.ch.chan[(ib * cp.ng + ig) * cp.nz + iz] =
                     ((b0 + ib) * m->n_gamma + (g0 + ig)) * m->n_zeta + (z0 + iz);
-          h->chunks.push_back(cp);
+          if (pass == 1) hd_series(sf.cutoff, cp.ch.beta[0], cp.ch);
+          (pass == 0 ? h->chunks : h->chunks_v2).push_back(cp);
         }
   }
   const int n_aterms = m->angular ? nel * (nel + 1) / 2 : 0;
@@ -328,11 +372,15 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
     used[TA_K_PAIR_GEOMETRY] = true;
     if (h->sf.angular) {
       begin(TA_K_G4_FORWARD);
-      for (const ChunkPlan &cp : h->chunks) launch_g4_forward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, db, s);
+      if (h->use_v2)
+        for (const ChunkPlan &cp : h->chunks_v2) launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, db, s);
+      else
+        for (const ChunkPlan &cp : h->chunks) launch_g4_forward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, db, s);
       end(TA_K_G4_FORWARD);
       used[TA_K_G4_FORWARD] = true;
     }
     begin(TA_K_DESCRIPTOR_REDUCE);
+    h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
     launch_descriptor_reduce(h->sf, db, s);
     end(TA_K_DESCRIPTOR_REDUCE);
     used[TA_K_DESCRIPTOR_REDUCE] = true;
@@ -348,10 +396,16 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       begin(TA_K_BACKWARD);
       if (h->sf.angular) {
         bool first = true;
-        for (const ChunkPlan &cp : h->chunks) {
-          launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
-          first = false;
-        }
+        if (h->use_v2)
+          for (const ChunkPlan &cp : h->chunks_v2) {
+            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+            first = false;
+          }
+        else
+          for (const ChunkPlan &cp : h->chunks) {
+            launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
+            first = false;
+          }
       } else {
         AngChunk dummy;
         std::memset(&dummy, 0, sizeof(dummy));
@@ -475,6 +529,7 @@ int ta_destroy(ta_handle h) {
   h->species.release(); h->frame_of_atom.release(); h->atom_start.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release(); h->elem_atoms.release();
+  h->blk_center.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -514,6 +569,28 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
     }
     upload_batch(h);
+    // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
+    h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && h->n_elements <= 3 &&
+                h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
+    const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
+    h->db.cap = cap;
+    std::vector<int32_t> blk;
+    if (h->use_v2) {
+      blk.push_back(0);
+      int32_t load = 0;
+      for (size_t i = 0; i < N; ++i) {
+        const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
+        if (load + cnt > cap) {
+          blk.push_back((int32_t)i);
+          load = 0;
+        }
+        load += cnt;
+      }
+      if (N) blk.push_back((int32_t)N);
+      h->db.n_blk = (int)blk.size() - 1;
+    } else {
+      h->db.n_blk = 0;
+    }
     auto put = [&](auto &buf, const auto &vec) {
       buf.ensure(vec.size());
       if (!vec.empty())
@@ -524,12 +601,14 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     put(h->cells, cells);
     put(h->species, species);
     put(h->elem_atoms, elem_atoms);
+    put(h->blk_center, blk);
+    h->db.blk_center = h->blk_center.ptr;
     h->db.pos = h->pos.ptr;
     h->db.cells = h->cells.ptr;
     h->db.species = h->species.ptr;
     h->db.elem_atoms = h->elem_atoms.ptr;
     if (h->kind == TA_MODEL_SF_MLP) {
-      if (ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
+      if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
         throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
       size_t need = 0;
       for (int e = 0; e < h->n_elements; ++e) {

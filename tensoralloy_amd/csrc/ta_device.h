@@ -13,12 +13,16 @@ constexpr int kMaxElements = 8;
 constexpr int kMaxBetaSlots = 3;  // H_beta slots in a pair record
 constexpr int kRecDoubles = 8;    // pair record = 64 bytes
 constexpr int kMaxLayers = 8;
+constexpr int kCapMin = 192;      // pair records one v2 workgroup (one wavefront) stages in LDS
+constexpr int kCapMax = 1024;
+constexpr int kMaxHd = 24;        // coefficients of the Hd(u) expansion
 
 // Symmetry-function constants, passed by value to every kernel.
 struct SFParams {
   double rcut, acut;
   double inv_rc2, inv_ac2;  // 1 / rcut^2, 1 / acut^2
   double eps;               // added under the square root (universal.py:470-472)
+  double ang_scale;         // 0.5 when every {j,k} is visited twice (v1 kernels), else 1
   int n_elements;
   int n_rad;                // radial parameter combinations (eta x omega)
   int n_ang;                // angular parameter combinations (beta x gamma x zeta)
@@ -40,6 +44,8 @@ struct AngChunk {
   double kz[2];      // 2^(1 - zeta)
   int zeta_int[2];   // zeta as integer >= 1, or -1 when not an integer
   int chan[8];       // [(ib*NG + ig)*NZ + iz] -> channel index in [0, n_ang)
+  int n_hd;          // 0 (exact), 16 or 24 coefficients of Hd(u) = exp(-beta u) fc(u)
+  double hd[kMaxHd]; // power-series coefficients in u (v2 kernels, beta[0] only)
 };
 
 struct DeviceBatch {
@@ -54,6 +60,9 @@ struct DeviceBatch {
   int32_t *pair_start = nullptr; // [N+1]
   int32_t *seg_start = nullptr;  // [N][nel+1]
   int32_t *pair_i = nullptr, *pair_j = nullptr, *pair_shift = nullptr, *pair_rev = nullptr;
+  int32_t *blk_center = nullptr; // [n_blk+1] first centre of every v2 workgroup
+  int n_blk = 0;
+  int cap = kCapMin;             // records per v2 workgroup (multiple of 64)
   int32_t *elem_atoms = nullptr; // atoms grouped by element
   int32_t elem_start[kMaxElements + 1] = {0};
   // work buffers
@@ -99,5 +108,12 @@ void launch_force_gather(const SFParams &sf, const DeviceBatch &b, hipStream_t s
 void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s);
 
 size_t g4_lds_bytes(int nnl_max);
+
+// second-generation angular kernels (ta_kernels_v2.hip); `ch` holds one beta
+size_t v2_lds_bytes(bool backward, int cap);
+void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz,
+                          const DeviceBatch &b, hipStream_t s);
+void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
+                        const DeviceBatch &b, hipStream_t s);
 
 }  // namespace ta

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(kBlock) void descriptor_reduce_kernel(SFParams sf, 
             for (int q = seg[s2] + lane; q < seg[s2 + 1]; q += 64) acc += col2[q];
           }
           acc = wave_sum(acc);
-          // every unordered {j, k} was visited from both sides
-          if (lane == 0) Gi[sf.n_radial_dim + t * sf.n_ang + c] = 0.5 * acc;
+          // v1 kernels visit every unordered {j, k} from both sides (ang_scale = 0.5)
+          if (lane == 0) Gi[sf.n_radial_dim + t * sf.n_ang + c] = sf.ang_scale * acc;
         }
       }
   }
@@ -414,44 +414,58 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
 }
 
 // --------------------------------------------------------------------------
-// K6: per-frame energy and virial (fixed-order tree), then the batch energy.
+// K6: per-frame energy and virial (fixed summation order), then the batch energy.
+// One 1024-lane workgroup per frame: every lane strides over the frame's atoms
+// with 10 running sums, then shuffle + LDS reduction.
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial) {
-  __shared__ double red[kBlock];
+constexpr int kRedBlock = 1024;
+
+__global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial) {
+  __shared__ double red[10][kRedBlock / 64];
   const int f = blockIdx.x;
   const int a0 = b.atom_start[f], a1 = b.atom_start[f + 1];
-  const int nv = want_virial ? 10 : 1;
-  for (int k = 0; k < nv; ++k) {
-    double acc = 0.0;
-    for (int a = a0 + threadIdx.x; a < a1; a += kBlock)
-      acc += (k == 0) ? b.eatom[a] : b.wat[9 * (size_t)a + (k - 1)];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  for (int a = a0 + threadIdx.x; a < a1; a += kRedBlock) {
+    acc[0] += b.eatom[a];
+    if (want_virial) {
+      const double *w = b.wat + 9 * (size_t)a;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[1 + k] += w[k];
     }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    double v = 0.0;
+    for (int w = 0; w < kRedBlock / 64; ++w) v += red[threadIdx.x][w];
     if (threadIdx.x == 0) {
-      if (k == 0)
-        b.energy[f] = red[0];
-      else
-        b.virial[9 * (size_t)f + (k - 1)] = red[0];
+      b.energy[f] = v;
+      if (b.n_frames == 1) b.batch_energy[0] = v;
+    } else if (want_virial) {
+      b.virial[9 * (size_t)f + (threadIdx.x - 1)] = v;
     }
-    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(kBlock) void batch_energy_kernel(DeviceBatch b) {
-  __shared__ double red[kBlock];
+  __shared__ double red[kBlock / 64];
   double acc = 0.0;
   for (int f = threadIdx.x; f < b.n_frames; f += kBlock) acc += b.energy[f];
-  red[threadIdx.x] = acc;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) v += red[w];
+    b.batch_energy[0] = v;
   }
-  if (threadIdx.x == 0) b.batch_energy[0] = red[0];
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) {
@@ -530,9 +544,9 @@ void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) 
 
 void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s) {
   if (b.n_frames == 0) return;
-  hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames), dim3(kBlock), 0, s, b,
+  hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames), dim3(kRedBlock), 0, s, b,
                      want_virial ? 1 : 0);
-  hipLaunchKernelGGL(batch_energy_kernel, dim3(1), dim3(kBlock), 0, s, b);
+  if (b.n_frames > 1) hipLaunchKernelGGL(batch_energy_kernel, dim3(1), dim3(kBlock), 0, s, b);
 }
 
 }  // namespace ta

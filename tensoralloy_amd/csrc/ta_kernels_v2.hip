@@ -1,0 +1,419 @@
+// Angular (G4) kernels, second generation: every unordered triple {j, k} of a
+// centre is evaluated ONCE, and only when r_jk < acut.
+//
+// Replaces the same reference ops as ta_kernels.hip (build_angular_graph +
+// _apply_g4_functions, transformer/universal.py:622-694, nn/atomic/sf.py:121-182,
+// and their tf.gradients, nn/basic.py:277-331).
+//
+// Work decomposition. A workgroup is ONE wavefront and owns a run of WHOLE
+// centre atoms whose neighbour counts sum to <= cap (packed on the host, cap =
+// 192 or the largest neighbour count); their pair records are
+// staged in LDS as structure-of-arrays {x, y, z, r^2, 1/r, H, G} (H = exp(-beta
+// u) fc(u), G = (dH/dr)/r for this launch's beta, computed while staging) so a
+// wavefront's per-lane reads of consecutive neighbours are bank-conflict free.
+// One lane = one directed pair (i, a). Lane a is responsible for the partners
+// b = a + s (mod n), s = 1..n/2 ("rotation" schedule): every unordered {a, b}
+// has exactly one owner and the owners' loads are balanced. For each block of
+// 64 candidate steps the lane first builds a 64-bit mask of the partners with
+// r_ab < acut (cheap: 3 subtractions, 3 FMAs, a compare), then runs the
+// expensive body only over the set bits, so the ~55 % of triples whose cutoff
+// factor vanishes cost almost nothing. In the backward kernel the partner's
+// share of dE/dD_b goes through ds_add_f64 into an LDS accumulator (3 adds per
+// triple); the own share stays in registers.
+//
+// Cutoff x Gaussian of the third side. For the cosine cutoff the factor
+// Hd(u) = exp(-beta u) fc(u), u = r_jk^2 / acut^2, is an entire function of u;
+// the host expands it in powers of u (long double) and the kernels evaluate
+// value and derivative with one Horner sweep whose coefficients sit in scalar
+// registers (template parameter HD = number of coefficients; HD = 0 keeps the
+// exact exp + cutoff evaluation, used for the polynomial cutoff or large beta).
+#include <hip/hip_runtime.h>
+
+#include "ta_device.h"
+#include "ta_math.h"
+
+namespace ta {
+namespace {
+
+constexpr int kBlock = 64;
+constexpr int kNF = 7;  // x y z r2 inv_r H G
+
+__device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
+  int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
+  return a * nel - (a * (a - 1)) / 2 + (b - a);
+}
+__device__ __forceinline__ int radial_term2(int center, int other) {
+  return other == center ? 0 : (other < center ? other + 1 : other);
+}
+
+struct Fields {
+  double *x, *y, *z, *r2, *inv, *H, *G;
+  unsigned char *sp;
+};
+
+__device__ __forceinline__ Fields carve(double *lds, int cap) {
+  Fields f;
+  f.x = lds;
+  f.y = f.x + cap;
+  f.z = f.y + cap;
+  f.r2 = f.z + cap;
+  f.inv = f.r2 + cap;
+  f.H = f.inv + cap;
+  f.G = f.H + cap;
+  f.sp = reinterpret_cast<unsigned char *>(f.G + cap);
+  return f;
+}
+
+// Hd(u) = exp(-beta u) fc(u) and dHd/du. HD > 0: Horner with derivative on the
+// host-expanded coefficients; HD == 0: exact evaluation.
+template <int HD>
+__device__ __forceinline__ void hd_eval(const SFParams &sf, const AngChunk &ch, double beta,
+                                        double u, double &h, double &dh) {
+  if constexpr (HD > 0) {
+    double p = ch.hd[HD - 1], d = 0.0;
+#pragma unroll
+    for (int k = HD - 2; k >= 0; --k) {
+      d = fma(d, u, p);
+      p = fma(p, u, ch.hd[k]);
+    }
+    h = p;
+    dh = d;
+  } else {
+    double fd, dfd;
+    cutoff_u(sf.cutoff, u, fd, dfd);
+    const double ed = ta_exp(-beta * u);
+    h = ed * fd;
+    dh = ed * (dfd - beta * fd);
+  }
+}
+template <int HD>
+__device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &ch, double beta,
+                                           double u) {
+  if constexpr (HD > 0) {
+    double p = ch.hd[HD - 1];
+#pragma unroll
+    for (int k = HD - 2; k >= 0; --k) p = fma(p, u, ch.hd[k]);
+    return p;
+  } else {
+    return ta_exp(-beta * u) * cutoff_u_value(sf.cutoff, u);
+  }
+}
+
+__device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
+                                      const Fields &f, int s0, int M) {
+  for (int item = threadIdx.x; item < M; item += kBlock) {
+    const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)(s0 + item));
+    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    f.x[item] = v0.x;
+    f.y[item] = v0.y;
+    f.z[item] = v1.x;
+    f.r2[item] = v1.y;
+    f.inv[item] = v2.x;
+    const double u = v1.y * sf.inv_ac2;
+    double H = 0.0, G = 0.0;
+    if (u < 1.0) {
+      double fc, dfdu;
+      cutoff_u(sf.cutoff, u, fc, dfdu);
+      const double e = ta_exp(-beta * u);
+      H = e * fc;
+      G = e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
+    }
+    f.H[item] = H;
+    f.G[item] = G;
+    f.sp[item] = (unsigned char)b.species[b.pair_j[s0 + item]];
+  }
+  __syncthreads();
+}
+
+// validity mask of the partners a + s, s in [sc, sc + 63]
+__device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, const Fields &f,
+                                                           int base, int n, int a, int sc, int smax,
+                                                           double ax, double ay, double az) {
+  unsigned long long mask = 0ull;
+  const int send = (smax < sc + 63) ? smax : sc + 63;
+  for (int s = sc; s <= send; ++s) {
+    int bl = a + s;
+    if (bl >= n) bl -= n;
+    const int q = base + bl;
+    const double ex = f.x[q] - ax, ey = f.y[q] - ay, ez = f.z[q] - az;
+    const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
+    bool v = (d2 * sf.inv_ac2 < 1.0) && (f.H[q] != 0.0);
+    // even n: the antipodal partner is shared by two lanes, the lower one keeps it
+    if (2 * s == n && a >= s) v = false;
+    mask |= (unsigned long long)(v ? 1u : 0u) << (s - sc);
+  }
+  return mask;
+}
+
+template <int NSPEC, int NG, int NZ, int HD>
+__global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
+                                                               DeviceBatch b) {
+  extern __shared__ double lds[];
+  const Fields f = carve(lds, b.cap);
+  const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
+  const int s0 = b.pair_start[c0];
+  const int M = b.pair_start[c1] - s0;
+  const double beta = ch.beta[0];
+  stage(sf, beta, b, f, s0, M);
+
+  for (int item = threadIdx.x; item < M; item += kBlock) {
+    const int64_t p = (int64_t)s0 + item;
+    const int i = b.pair_i[p];
+    const int base = b.pair_start[i] - s0;
+    const int n = b.pair_start[i + 1] - b.pair_start[i];
+    const int a = item - base;
+    const double ax = f.x[item], ay = f.y[item], az = f.z[item];
+    const double ra2 = f.r2[item], inv_ra = f.inv[item], Ha = f.H[item];
+
+    double acc[NSPEC][NG][NZ];
+#pragma unroll
+    for (int sp = 0; sp < NSPEC; ++sp)
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) acc[sp][ig][iz] = 0.0;
+
+    const int smax = (Ha != 0.0) ? n / 2 : 0;
+    for (int sc = 1; sc <= smax; sc += 64) {
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, ax, ay, az);
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        int bl = a + sc + k;
+        if (bl >= n) bl -= n;
+        const int q = base + bl;
+        const double ex = f.x[q] - ax, ey = f.y[q] - ay, ez = f.z[q] - az;
+        const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
+        const double u = d2 * sf.inv_ac2;
+        const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ra * f.inv[q];
+        const double common = Ha * f.H[q] * hd_value<HD>(sf, ch, beta, u);
+        const int sb = f.sp[q];
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double basev = fma(ch.gamma[ig], cth, 1.0);
+#pragma unroll
+          for (int iz = 0; iz < NZ; ++iz) {
+            double pw;
+            if (ch.zeta_int[iz] > 0)
+              pw = pow_int_m1(basev, ch.zeta_int[iz]) * basev;
+            else
+              pw = pow(basev, ch.zeta[iz]);
+            const double v = pw * common;
+#pragma unroll
+            for (int sp = 0; sp < NSPEC; ++sp)
+              acc[sp][ig][iz] += (NSPEC == 1 || sb == sp) ? v : 0.0;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sp = 0; sp < NSPEC; ++sp)
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) {
+          const int c = ch.chan[ig * NZ + iz];
+          b.part4[(size_t)(sp * sf.n_ang + c) * b.n_pairs + p] = acc[sp][ig][iz] * ch.kz[iz];
+        }
+  }
+}
+
+template <int NSPEC, int NG, int NZ, int HD>
+__global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChunk ch,
+                                                             DeviceBatch b, int first) {
+  extern __shared__ double lds[];
+  const int kCap = b.cap;  // multiple of 64
+  const Fields f = carve(lds, kCap);
+  // partner accumulators sit behind the species bytes, 8-byte aligned
+  double *gacc = lds + kNF * kCap + kCap / 8;
+  const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
+  const int s0 = b.pair_start[c0];
+  const int M = b.pair_start[c1] - s0;
+  const double beta = ch.beta[0];
+  for (int k = threadIdx.x; k < 3 * kCap; k += kBlock) gacc[k] = 0.0;
+  stage(sf, beta, b, f, s0, M);
+  const int nel = sf.n_elements;
+
+  for (int item = threadIdx.x; item < M; item += kBlock) {
+    const int64_t p = (int64_t)s0 + item;
+    const int i = b.pair_i[p];
+    const int base = b.pair_start[i] - s0;
+    const int n = b.pair_start[i + 1] - b.pair_start[i];
+    const int a = item - base;
+    const double ax = f.x[item], ay = f.y[item], az = f.z[item];
+    const double ra2 = f.r2[item], inv_ra = f.inv[item], Ha = f.H[item], Ga = f.G[item];
+    const double inv_ra2 = inv_ra * inv_ra;
+    const int sa = f.sp[item];
+
+    // dE/dG of the channels of term (sa, sp) for every partner species sp
+    double w[NSPEC][NG][NZ];
+#pragma unroll
+    for (int sp = 0; sp < NSPEC; ++sp) {
+      const double *wsrc = b.dEdG + (size_t)i * sf.ndim + sf.n_radial_dim +
+                           angular_term2(sa, sp, nel) * sf.n_ang;
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) w[sp][ig][iz] = wsrc[ch.chan[ig * NZ + iz]] * ch.kz[iz];
+    }
+
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    const int smax = (Ha != 0.0) ? n / 2 : 0;
+    for (int sc = 1; sc <= smax; sc += 64) {
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, ax, ay, az);
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        int bl = a + sc + k;
+        if (bl >= n) bl -= n;
+        const int q = base + bl;
+        const double bx = f.x[q], by = f.y[q], bz = f.z[q];
+        const double ex = bx - ax, ey = by - ay, ez = bz - az;
+        const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
+        const double u = d2 * sf.inv_ac2;
+        const double inv_rb = f.inv[q];
+        const double inv_ab = inv_ra * inv_rb;
+        const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ab;
+        double Hd, dHd;
+        hd_eval<HD>(sf, ch, beta, u, Hd, dHd);
+        const double Hd2 = 2.0 * sf.inv_ac2 * dHd;
+        const double Hb = f.H[q], Gb = f.G[q];
+        const int sb = f.sp[q];
+        double S0 = 0.0, S1 = 0.0;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double basev = fma(ch.gamma[ig], cth, 1.0);
+#pragma unroll
+          for (int iz = 0; iz < NZ; ++iz) {
+            double pm1;
+            if (ch.zeta_int[iz] > 0)
+              pm1 = pow_int_m1(basev, ch.zeta_int[iz]);
+            else
+              pm1 = pow(basev, ch.zeta[iz] - 1.0);
+            double ws = w[0][ig][iz];
+#pragma unroll
+            for (int sp = 1; sp < NSPEC; ++sp) ws = (sb == sp) ? w[sp][ig][iz] : ws;
+            S0 = fma(ws, pm1 * basev, S0);
+            S1 = fma(ws * ch.zeta[iz] * ch.gamma[ig], pm1, S1);
+          }
+        }
+        // (dV/dr_a)/r_a, (dV/dr_b)/r_b, (dV/dr_jk)/r_jk for V = sum_c w_c v_c
+        const double Aa = Hb * Hd * fma(S1 * Ha, inv_ab - cth * inv_ra2, S0 * Ga);
+        const double Ab = Ha * Hd * fma(S1 * Hb, inv_ab - cth * inv_rb * inv_rb, S0 * Gb);
+        const double Q = Ha * Hb * fma(-S1 * inv_ab, Hd, S0 * Hd2);
+        const double ca = Aa + Q, cb = Ab + Q;
+        gx = fma(ca, ax, fma(-Q, bx, gx));
+        gy = fma(ca, ay, fma(-Q, by, gy));
+        gz = fma(ca, az, fma(-Q, bz, gz));
+        atomicAdd(&gacc[q], fma(cb, bx, -Q * ax));
+        atomicAdd(&gacc[kCap + q], fma(cb, by, -Q * ay));
+        atomicAdd(&gacc[2 * kCap + q], fma(cb, bz, -Q * az));
+      }
+    }
+    atomicAdd(&gacc[item], gx);
+    atomicAdd(&gacc[kCap + item], gy);
+    atomicAdd(&gacc[2 * kCap + item], gz);
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < M; item += kBlock) {
+    const int64_t p = (int64_t)s0 + item;
+    double gx = gacc[item], gy = gacc[kCap + item], gz = gacc[2 * kCap + item];
+    if (first) {
+      // radial (G2) share: s_p D / r  (sf.py:101-108 differentiated)
+      const int i = b.pair_i[p];
+      const double r2 = f.r2[item], inv_r = f.inv[item];
+      const double ur = r2 * sf.inv_rc2;
+      double s = 0.0;
+      if (ur < 1.0) {
+        double fc, dfdu;
+        cutoff_u(sf.cutoff, ur, fc, dfdu);
+        const double r = sqrt(r2);
+        const double dfdr = dfdu * 2.0 * r * sf.inv_rc2;
+        const double *wr = b.dEdG + (size_t)i * sf.ndim + radial_term2(b.species[i], f.sp[item]) * sf.n_rad;
+        for (int c = 0; c < sf.n_rad; ++c) {
+          const double dr = r - sf.omega[c];
+          const double e = ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2);
+          s = fma(wr[c], e * (dfdr - 2.0 * sf.eta[c] * dr * fc * sf.inv_rc2), s);
+        }
+      }
+      s *= inv_r;
+      gx = fma(s, f.x[item], gx);
+      gy = fma(s, f.y[item], gy);
+      gz = fma(s, f.z[item], gz);
+    } else {
+      gx += b.g[p];
+      gy += b.g[b.n_pairs + p];
+      gz += b.g[2 * b.n_pairs + p];
+    }
+    b.g[p] = gx;
+    b.g[b.n_pairs + p] = gy;
+    b.g[2 * b.n_pairs + p] = gz;
+  }
+}
+
+template <int NSPEC, int NG, int NZ>
+void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, hipStream_t s) {
+  const dim3 grid((unsigned)b.n_blk), block(kBlock);
+  const size_t lds = v2_lds_bytes(false, b.cap);
+  if (ch.n_hd == 16)
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16>), grid, block, lds, s, sf, ch, b);
+  else if (ch.n_hd == 24)
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24>), grid, block, lds, s, sf, ch, b);
+  else
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0>), grid, block, lds, s, sf, ch, b);
+}
+template <int NSPEC, int NG, int NZ>
+void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int first, hipStream_t s) {
+  const dim3 grid((unsigned)b.n_blk), block(kBlock);
+  const size_t lds = v2_lds_bytes(true, b.cap);
+  if (ch.n_hd == 16)
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16>), grid, block, lds, s, sf, ch, b, first);
+  else if (ch.n_hd == 24)
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24>), grid, block, lds, s, sf, ch, b, first);
+  else
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 0>), grid, block, lds, s, sf, ch, b, first);
+}
+
+}  // namespace
+
+size_t v2_lds_bytes(bool backward, int cap) {
+  return (size_t)cap * kNF * sizeof(double) + cap + (backward ? 3 * (size_t)cap * sizeof(double) : 0);
+}
+
+#define TA_DISPATCH_V2(FN, ...)                                   \
+  do {                                                            \
+    const int key = nspec * 100 + ng * 10 + nz;                   \
+    switch (key) {                                                \
+      case 111: FN<1, 1, 1>(__VA_ARGS__); break;                  \
+      case 112: FN<1, 1, 2>(__VA_ARGS__); break;                  \
+      case 121: FN<1, 2, 1>(__VA_ARGS__); break;                  \
+      case 122: FN<1, 2, 2>(__VA_ARGS__); break;                  \
+      case 211: FN<2, 1, 1>(__VA_ARGS__); break;                  \
+      case 212: FN<2, 1, 2>(__VA_ARGS__); break;                  \
+      case 221: FN<2, 2, 1>(__VA_ARGS__); break;                  \
+      case 222: FN<2, 2, 2>(__VA_ARGS__); break;                  \
+      case 311: FN<3, 1, 1>(__VA_ARGS__); break;                  \
+      case 312: FN<3, 1, 2>(__VA_ARGS__); break;                  \
+      case 321: FN<3, 2, 1>(__VA_ARGS__); break;                  \
+      case 322: FN<3, 2, 2>(__VA_ARGS__); break;                  \
+      default: break;                                             \
+    }                                                             \
+  } while (0)
+
+// `ch` must describe ONE beta (nb == 1).
+void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz,
+                          const DeviceBatch &b, hipStream_t s) {
+  if (b.n_blk == 0) return;
+  const int nspec = sf.n_elements;
+  TA_DISPATCH_V2(fwd_t, sf, ch, b, s);
+}
+
+void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
+                        const DeviceBatch &b, hipStream_t s) {
+  if (b.n_blk == 0) return;
+  const int nspec = sf.n_elements;
+  const int f = first ? 1 : 0;
+  TA_DISPATCH_V2(bwd_t, sf, ch, b, f, s);
+}
+
+}  // namespace ta

@@ -5,7 +5,9 @@
 // part of `tf.gradients` that flows through it, plus the min-max scaling of
 // nn/atomic/atomic.py:157-195 and the squeeze to atomic energies :250-264.
 //
-// One wavefront owns 16 atoms (the M dimension of the 16x16x4 tile). Layer
+// One workgroup (4 wavefronts) owns 16 atoms (the M dimension of the 16x16x4
+// tile); wavefront w computes the 16-column output tiles w, w+4, ... so the
+// four SIMDs of a CU work on one layer together. Layer
 // inputs live in LDS as [16][width] row-major (A operand: lane l reads
 // X[l & 15][4 kk + (l >> 4)]); weights stream from L2 (B operand: lane l reads
 // W[4 kk + (l >> 4)][16 nt + (l & 15)], 16 consecutive doubles per k row). The
@@ -25,38 +27,51 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kRows = 16;
 
 // Z[16][np] = X[16][kp] . W[kp][np] (+ bias), result handed to `emit(row, col, z)`.
+// Column tiles are dealt round-robin to the workgroup's wavefronts; the B
+// operands of 8 k-steps are fetched before their MFMAs so one L2 latency
+// covers 8 matrix instructions.
 template <typename Emit>
 __device__ __forceinline__ void tile_gemm(const double *X, int xstride, const double *W, int kp,
-                                          int np, const double *bias, int lane, Emit emit) {
+                                          int np, const double *bias, int lane, int wave,
+                                          int nwaves, Emit emit) {
   const int m = lane & 15, kq = lane >> 4;
-  for (int nt = 0; nt < np / 16; ++nt) {
+  for (int nt = wave; nt < np / 16; nt += nwaves) {
     const int col = 16 * nt + m;
     const double b0 = bias ? bias[col] : 0.0;
     double4_t acc = {b0, b0, b0, b0};
-    for (int kk = 0; kk < kp / 4; ++kk) {
-      const double a = X[m * xstride + 4 * kk + kq];
-      const double w = W[(size_t)(4 * kk + kq) * np + col];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, w, acc, 0, 0, 0);
+    const int nk = kp / 4;  // kp is a multiple of 16 -> nk is a multiple of 4
+    for (int kk0 = 0; kk0 < nk; kk0 += 4) {
+      double a[4], w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[j] = W[(size_t)(4 * (kk0 + j) + kq) * np + col];
+        a[j] = X[m * xstride + 4 * (kk0 + j) + kq];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], w[j], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) emit(kq + 4 * r, col, acc[r]);
   }
 }
 
-__global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
+constexpr int kMlpThreads = 256;
+
+__global__ __launch_bounds__(kMlpThreads) void mlp_kernel(MlpDev mlp, int act, int ndim,
                                                  const int32_t *atoms, int n_atoms,
                                                  const double *G, double *dEdG, double *eatom,
                                                  double *scratch, int stride) {
   extern __shared__ double lds[];
   double *buf0 = lds, *buf1 = lds + kRows * stride;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = kMlpThreads / 64;
   const int a0 = blockIdx.x * kRows;
   const int L = mlp.n_layers;
   double *da = scratch + (size_t)blockIdx.x * L * kRows * stride;
 
   // layer-0 input: (optionally min-max scaled) descriptors, zero padded
   const int kp0 = mlp.layer[0].kp;
-  for (int idx = lane; idx < kRows * kp0; idx += 64) {
+  for (int idx = tid; idx < kRows * kp0; idx += kMlpThreads) {
     const int row = idx / kp0, k = idx - row * kp0;
     double x = 0.0;
     if (a0 + row < n_atoms && k < ndim) {
@@ -74,7 +89,7 @@ __global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
   for (int l = 0; l < L; ++l) {
     const MlpLayerDev ly = mlp.layer[l];
     double *dal = da + (size_t)l * kRows * stride;
-    tile_gemm(cur, stride, ly.w, ly.kp, ly.np, ly.b, lane, [&](int row, int col, double z) {
+    tile_gemm(cur, stride, ly.w, ly.kp, ly.np, ly.b, lane, wave, nwaves, [&](int row, int col, double z) {
       double h = z, dh = 1.0;
       if (ly.act) activation_fn(act, z, h, dh);
       if (ly.res) h += cur[row * stride + col];  // convolutional.py:272-273
@@ -87,12 +102,12 @@ __global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
     nxt = t;
   }
   // atomic energies: column 0 of the (padded) output layer
-  if (lane < kRows && a0 + lane < n_atoms) eatom[atoms[a0 + lane]] = cur[lane * stride];
+  if (tid < kRows && a0 + tid < n_atoms) eatom[atoms[a0 + tid]] = cur[tid * stride];
   __syncthreads();
 
   // backward: delta = dE_atom / d(layer output); start from the output column
   const int npL = mlp.layer[L - 1].np;
-  for (int idx = lane; idx < kRows * npL; idx += 64) {
+  for (int idx = tid; idx < kRows * npL; idx += kMlpThreads) {
     const int row = idx / npL, col = idx - row * npL;
     cur[row * stride + col] = (col == 0) ? 1.0 : 0.0;
   }
@@ -102,12 +117,12 @@ __global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
     const double *dal = da + (size_t)l * kRows * stride;
     // dz = delta * act'(z), in place; keep delta for the skip connection
     if (ly.res) {
-      for (int idx = lane; idx < kRows * ly.np; idx += 64) {
+      for (int idx = tid; idx < kRows * ly.np; idx += kMlpThreads) {
         const int row = idx / ly.np, col = idx - row * ly.np;
         nxt[row * stride + col] = cur[row * stride + col];
       }
     }
-    for (int idx = lane; idx < kRows * ly.np; idx += 64) {
+    for (int idx = tid; idx < kRows * ly.np; idx += kMlpThreads) {
       const int row = idx / ly.np, col = idx - row * ly.np;
       cur[row * stride + col] *= dal[row * stride + col];
     }
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
     // delta_prev[16][kp] = dz[16][np] . W^T[np][kp]  (+ delta when skip)
     const bool res = ly.res != 0;
     double *dst = nxt;
-    tile_gemm(cur, stride, ly.wt, ly.np, ly.kp, nullptr, lane, [&](int row, int col, double z) {
+    tile_gemm(cur, stride, ly.wt, ly.np, ly.kp, nullptr, lane, wave, nwaves, [&](int row, int col, double z) {
       const double skip = res ? dst[row * stride + col] : 0.0;
       dst[row * stride + col] = z + skip;
     });
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(64) void mlp_kernel(MlpDev mlp, int act, int ndim,
     cur = nxt;
     nxt = t;
   }
-  for (int idx = lane; idx < kRows * ndim; idx += 64) {
+  for (int idx = tid; idx < kRows * ndim; idx += kMlpThreads) {
     const int row = idx / ndim, k = idx - row * ndim;
     if (a0 + row >= n_atoms) continue;
     double d = cur[row * stride + k];
@@ -151,7 +166,7 @@ void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t 
   const int stride = w + 2;
   const size_t lds = 2 * (size_t)kRows * stride * sizeof(double);
   const unsigned blocks = (unsigned)((n_atoms + kRows - 1) / kRows);
-  hipLaunchKernelGGL(mlp_kernel, dim3(blocks), dim3(64), lds, s, mlp, activation, ndim, atoms,
+  hipLaunchKernelGGL(mlp_kernel, dim3(blocks), dim3(kMlpThreads), lds, s, mlp, activation, ndim, atoms,
                      n_atoms, b.G, b.dEdG, b.eatom, scratch, stride);
 }
 
