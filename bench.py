@@ -101,7 +101,9 @@ def main():
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = torch = None
-    if world > 1:
+    # TA_BENCH_FORCE_DIST=1 rehearses the multi-rank code path with a single rank
+    use_dist = world > 1 or os.environ.get("TA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         # torch first: its bundled HIP runtime must be the one the process shares
         import torch
         import torch.distributed as dist
@@ -122,22 +124,28 @@ def main():
     D = int(info.descriptor_dim)
 
     ebuf = None
-    if world > 1:
+    inflight = [None, None]
+    if use_dist:
         ebuf = torch.zeros(2, dtype=torch.float64, device=f"cuda:{local_rank}")
+        # kernels go onto torch's current stream so the collective is ordered
+        # behind them by stream semantics: no host synchronisation per step
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step(k):
+        if use_dist and inflight[k % 2] is not None:
+            inflight[k % 2].wait()  # stream-level wait before the slot is overwritten
         eng.compute(want)
-        if world > 1:
-            # batch energy -> torch buffer on the engine's stream, then one RCCL all-reduce
+        if use_dist:
+            # batch energy -> torch buffer, then ONE RCCL all-reduce of 8 bytes
             slot = ebuf[k % 2:k % 2 + 1]
             eng.copy_batch_energy(slot.data_ptr())
-            eng.synchronize()
-            return dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
+            inflight[k % 2] = dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
+            return inflight[k % 2]
         return None
 
     def sync_all():
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -154,7 +162,7 @@ def main():
             w.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -239,7 +247,7 @@ def main():
             "event_ms_per_step": ev_total_ms / max(5, min(args.steps, 20)),
             "neighbor_list_host_s": t_nl,
         }
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

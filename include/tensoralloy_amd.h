@@ -161,6 +161,12 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial,
 int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want,
             double *energy, double *forces, double *virial, double *atomic);
 
+/* Enqueue all further work of this handle on `stream` (a hipStream_t of the
+ * handle's device owned by the caller, e.g. the stream a RCCL collective is
+ * ordered against); NULL restores the handle's own stream. Drains the old
+ * stream first. */
+int ta_set_stream(ta_handle h, void *stream);
+
 /* blocks until the handle's stream is idle */
 int ta_synchronize(ta_handle h);
 

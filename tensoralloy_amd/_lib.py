@@ -36,7 +36,7 @@ KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "back
 # every symbol include/tensoralloy_amd.h declares
 EXPORTED_SYMBOLS = [
     "ta_device_count", "ta_create", "ta_destroy", "ta_last_error", "ta_set_frames",
-    "ta_compute", "ta_get_results", "ta_eval", "ta_synchronize", "ta_time_compute",
+    "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
 ]
 
@@ -117,6 +117,7 @@ def load():
     lib.ta_get_results.argtypes = [H, _dp, _dp, _dp, _dp, _dp]
     lib.ta_eval.argtypes = [H, C.c_int32, C.POINTER(Frame), C.c_uint32, _dp, _dp, _dp, _dp]
     lib.ta_synchronize.argtypes = [H]
+    lib.ta_set_stream.argtypes = [H, C.c_void_p]
     lib.ta_time_compute.argtypes = [H, C.c_uint32, C.c_int32, C.c_int32, _dp, _dp]
     lib.ta_batch_energy_device_ptr.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.ta_copy_batch_energy.argtypes = [H, C.c_void_p]

@@ -72,7 +72,8 @@ struct ChunkPlan {
 
 struct ta_context {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // stream all work is enqueued on
+  hipStream_t own_stream = nullptr;  // created by ta_create
   int kind = 0;
   int n_elements = 0;
   int activation = 0;
@@ -492,7 +493,8 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       throw HipError(std::string("device is ") + prop.gcnArchName +
                      ", this library is built for gfx950 only");
-    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     for (auto &e : h->ev) HIP_CHECK(hipEventCreate(&e));
     if (model->kind == TA_MODEL_SF_MLP) {
       build_sf_model(h, model);
@@ -532,7 +534,7 @@ int ta_destroy(ta_handle h) {
   h->blk_center.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return TA_OK;
 }
@@ -709,6 +711,14 @@ int ta_batch_energy_device_ptr(ta_handle h, void **dptr) {
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
   *dptr = h->db.batch_energy;
   return TA_OK;
+}
+
+int ta_set_stream(ta_handle h, void *stream) {
+  if (!h) return TA_ERR_INVALID;
+  return guarded(h, [&]() {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+  });
 }
 
 int ta_copy_batch_energy(ta_handle h, void *dst_device) {

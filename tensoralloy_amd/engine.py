@@ -77,6 +77,10 @@ class Engine:
     def compute(self, want: int):
         self._check(self._lib.ta_compute(self._handle, int(want)))
 
+    def set_stream(self, stream_ptr):
+        """Run on a caller-owned hipStream_t (int pointer); None = the engine's own."""
+        self._check(self._lib.ta_set_stream(self._handle, C.c_void_p(stream_ptr or 0)))
+
     def synchronize(self):
         self._check(self._lib.ta_synchronize(self._handle))
 
