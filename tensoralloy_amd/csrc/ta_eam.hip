@@ -1,17 +1,321 @@
-// EAM / ADP kernels (placeholder until the analytic-potential kernels land).
+// EAM / ADP kernels with the analytic Zhou-Johnson-Wadley and Mishin functions.
+//
+// Replaces, for `custom_potentials = 'zjw04'` (+ 'mishinh' dipole/quadrupole):
+//   EamAlloyNN._build_rho_nn        reference nn/eam/alloy.py:128-196
+//   EamNN._build_embed_nn           reference nn/eam/eam.py:401-449
+//   EamNN._build_phi_nn             reference nn/eam/eam.py:300-362
+//   AdpNN._build_dipole_nn          reference nn/eam/adp.py:315-392
+//   AdpNN._build_quadrupole_nn      reference nn/eam/adp.py:394-498
+//   Zjw04.rho / phi / embed         reference nn/eam/potentials/zjw04.py:187-389
+//   mishin_polar / mishin_cutoff    reference nn/eam/potentials/generic.py:52-84
+// and the tf.gradients that give forces and virial (nn/basic.py:277-331).
+//
+// Two passes over the packed pair list:
+//   eam_atom_kernel  one wavefront per atom: rho_i, sum phi, and (ADP) the
+//                    dipole / quadrupole moments per neighbour species; lane 0
+//                    applies the embedding function and stores F'(rho_i).
+//   eam_pair_kernel  one lane per directed pair: dE/dD from the centre's F',
+//                    moments and the pair functions' derivatives.
+// Forces / virial / energy then use the same force_gather and frame_reduce
+// kernels as the symmetry-function path.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 
 #include "ta_device.h"
+#include "ta_math.h"
 
 namespace ta {
-struct EamModel {};
-EamModel *eam_create(const ta_model_desc *, std::string &err) {
-  err = "EAM/ADP models are not implemented yet";
-  return nullptr;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxEamElements = 5;  // keeps EamParams + DeviceBatch inside the 4 KB kernarg limit
+constexpr int kMaxPairTypes = kMaxEamElements * (kMaxEamElements + 1) / 2;
+
+struct EamParams {
+  int nel;
+  int adp;
+  double el[kMaxEamElements][20];  // ZJW04_KEYS order (tensoralloy_amd/eam.py)
+  double pair[kMaxPairTypes][8];  // d1 d2 d3 q1 q2 q3 h rc
+};
+
+enum { R_EQ, F_EQ, RHO_E, RHO_S, ALPHA, BETA, PA, PB, KAPPA, LAMDA, FN0, FN1, FN2, FN3, F0, F1, F2, F3, ETA, FE };
+
+__device__ __forceinline__ int pair_type(int s1, int s2, int nel) {
+  int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
+  return a * nel - (a * (a - 1)) / 2 + (b - a);
 }
-void eam_destroy(EamModel *m) { delete m; }
-void eam_ensure(EamModel *, const DeviceBatch &) {}
-void eam_compute(EamModel *, const DeviceBatch &, uint32_t, hipStream_t, hipEvent_t *) {}
+
+// f(r) = a exp(-b (r/re - 1)) / (1 + (r/re - c)^20)   (generic.py:102-117)
+__device__ __forceinline__ void zhou_exp(double r, double a, double b, double c, double re,
+                                         double &f, double &df) {
+  const double x = r / re;
+  const double t = x - c;
+  const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+  const double t20 = t16 * t4, t19 = t16 * t2 * t;
+  const double den = 1.0 / (1.0 + t20);
+  f = a * ta_exp(-b * (x - 1.0)) * den;
+  df = f * (-b - 20.0 * t19 * den) / re;
+}
+
+__device__ __forceinline__ void zjw_rho(const double *p, double r, double &f, double &df) {
+  zhou_exp(r, p[F_EQ], p[BETA], p[LAMDA], p[R_EQ], f, df);
+}
+__device__ __forceinline__ void zjw_phi_aa(const double *p, double r, double &f, double &df) {
+  double fa, dfa, fb, dfb;
+  zhou_exp(r, p[PA], p[ALPHA], p[KAPPA], p[R_EQ], fa, dfa);
+  zhou_exp(r, p[PB], p[BETA], p[LAMDA], p[R_EQ], fb, dfb);
+  f = fa - fb;
+  df = dfa - dfb;
+}
+// phi_AB = 0.5 (rho_A/rho_B phi_BB + rho_B/rho_A phi_AA)   (zjw04.py:229-243)
+__device__ __forceinline__ void zjw_phi(const EamParams &P, int sa, int sb, double r, double &f,
+                                        double &df) {
+  if (sa == sb) {
+    zjw_phi_aa(P.el[sa], r, f, df);
+    return;
+  }
+  double pha, dpha, phb, dphb, ra, dra, rb, drb;
+  zjw_phi_aa(P.el[sa], r, pha, dpha);
+  zjw_phi_aa(P.el[sb], r, phb, dphb);
+  zjw_rho(P.el[sa], r, ra, dra);
+  zjw_rho(P.el[sb], r, rb, drb);
+  const double q1 = ra / rb, q2 = rb / ra;
+  const double dq1 = (dra * rb - ra * drb) / (rb * rb);
+  const double dq2 = (drb * ra - rb * dra) / (ra * ra);
+  f = 0.5 * (q1 * phb + q2 * pha);
+  df = 0.5 * (dq1 * phb + q1 * dphb + dq2 * pha + q2 * dpha);
+}
+
+// piecewise embedding energy, thresholds 0.85 rho_e and 1.15 rho_e (zjw04.py:319-386)
+__device__ __forceinline__ void zjw_embed(const double *p, double rho, double &F, double &dF) {
+  const double rho_n = 0.85 * p[RHO_E], rho_0 = 1.15 * p[RHO_E];
+  if (rho < rho_n) {
+    const double x = rho / rho_n - 1.0;
+    F = p[FN0] + x * (p[FN1] + x * (p[FN2] + x * p[FN3]));
+    dF = (p[FN1] + x * (2.0 * p[FN2] + 3.0 * p[FN3] * x)) / rho_n;
+  } else if (rho < rho_0) {
+    const double x = rho / p[RHO_E] - 1.0;
+    F = p[F0] + x * (p[F1] + x * (p[F2] + x * p[F3]));
+    dF = (p[F1] + x * (2.0 * p[F2] + 3.0 * p[F3] * x)) / p[RHO_E];
+  } else {
+    const double x = rho / p[RHO_S];
+    const double lnx = log(x);
+    const double xe = pow(x, p[ETA]);
+    F = p[FE] * (1.0 - p[ETA] * lnx) * xe;
+    dF = -p[FE] * p[ETA] * p[ETA] * lnx * xe / x / p[RHO_S];
+  }
+}
+
+// (p1 exp(-p2 r) + p3) psi((r - rc)/h), psi(x) = x^4/(1+x^4) for x < 0  (generic.py:52-84)
+__device__ __forceinline__ void mishin_polar(double r, double p1, double p2, double p3, double rc,
+                                             double h, double &f, double &df) {
+  const double z = (r - rc) / h;
+  if (z >= 0.0) {
+    f = 0.0;
+    df = 0.0;
+    return;
+  }
+  const double zz = -z, z2 = zz * zz, z4 = z2 * z2;
+  const double den = 1.0 / (1.0 + z4);
+  const double psi = z4 * den;
+  const double dpsi = -4.0 * z2 * zz * den * den / h;
+  const double e = ta_exp(-p2 * r);
+  const double left = fma(p1, e, p3);
+  f = left * psi;
+  df = -p1 * p2 * e * psi + left * dpsi;
+}
+
+// moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
+// in the order xx yy zz yz xz xy
+__global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
+                                                          double *mom) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= b.n_atoms) return;
+  const int nel = P.nel;
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  double rho = 0.0, phis = 0.0, eadp = 0.0;
+  for (int sb = 0; sb < nel; ++sb) {
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double *pp = P.pair[pair_type(sA, sb, nel)];
+    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+      const double *rec = b.rec + kRecDoubles * (size_t)q;
+      const double r = sqrt(rec[3]);
+      double f, df;
+      zjw_rho(P.el[sb], r, f, df);  // density function of the NEIGHBOUR's element (alloy.py:176)
+      rho += f;
+      zjw_phi(P, sA, sb, r, f, df);
+      phis += f;
+      if (P.adp) {
+        const double dx = rec[0], dy = rec[1], dz = rec[2];
+        double u, du, w, dw;
+        mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        m[0] = fma(u, dx, m[0]);
+        m[1] = fma(u, dy, m[1]);
+        m[2] = fma(u, dz, m[2]);
+        m[3] = fma(w * dx, dx, m[3]);
+        m[4] = fma(w * dy, dy, m[4]);
+        m[5] = fma(w * dz, dz, m[5]);
+        m[6] = fma(w * dy, dz, m[6]);
+        m[7] = fma(w * dx, dz, m[7]);
+        m[8] = fma(w * dx, dy, m[8]);
+      }
+    }
+    if (P.adp) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) m[k] = wave_sum(m[k]);
+      if (lane == 0) {
+        const double nu = m[3] + m[4] + m[5];
+        // 1/2 |mu|^2 + 1/2 sum_ab lambda_ab^2 - 1/6 (tr lambda)^2, per k-body term (adp.py:371-392, :458-492)
+        eadp += 0.5 * (m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) +
+                0.5 * (m[3] * m[3] + m[4] * m[4] + m[5] * m[5] +
+                       2.0 * (m[6] * m[6] + m[7] * m[7] + m[8] * m[8])) -
+                nu * nu / 6.0;
+        double *dst = mom + ((size_t)i * nel + sb) * 9;
+        dst[0] = m[0];
+        dst[1] = m[1];
+        dst[2] = m[2];
+        dst[3] = m[3] - nu / 3.0;
+        dst[4] = m[4] - nu / 3.0;
+        dst[5] = m[5] - nu / 3.0;
+        dst[6] = m[6];
+        dst[7] = m[7];
+        dst[8] = m[8];
+      }
+    }
+  }
+  rho = wave_sum(rho);
+  phis = wave_sum(phis);
+  if (lane == 0) {
+    double F, d;
+    zjw_embed(P.el[sA], rho, F, d);
+    b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
+    dF[i] = d;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBatch b,
+                                                          const double *dF, const double *mom) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= b.n_pairs) return;
+  const int nel = P.nel;
+  const int i = b.pair_i[p];
+  const int sA = b.species[i], sa = b.species[b.pair_j[p]];
+  const double *rec = b.rec + kRecDoubles * (size_t)p;
+  const double dx = rec[0], dy = rec[1], dz = rec[2], inv_r = rec[4];
+  const double r = sqrt(rec[3]);
+  double f, drho, dphi;
+  zjw_rho(P.el[sa], r, f, drho);
+  zjw_phi(P, sA, sa, r, f, dphi);
+  // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
+  double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
+  double gx = c * dx, gy = c * dy, gz = c * dz;
+  if (P.adp) {
+    const double *pp = P.pair[pair_type(sA, sa, nel)];
+    const double *m = mom + ((size_t)i * nel + sa) * 9;
+    double u, du, w, dw;
+    mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+    mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+    const double muD = m[0] * dx + m[1] * dy + m[2] * dz;
+    const double lx = m[3] * dx + m[8] * dy + m[7] * dz;
+    const double ly = m[8] * dx + m[4] * dy + m[6] * dz;
+    const double lz = m[7] * dx + m[6] * dy + m[5] * dz;
+    const double DLD = dx * lx + dy * ly + dz * lz;
+    const double k = (muD * du + DLD * dw) * inv_r;
+    gx += k * dx + u * m[0] + 2.0 * w * lx;
+    gy += k * dy + u * m[1] + 2.0 * w * ly;
+    gz += k * dz + u * m[2] + 2.0 * w * lz;
+  }
+  b.g[p] = gx;
+  b.g[b.n_pairs + p] = gy;
+  b.g[2 * b.n_pairs + p] = gz;
+}
+
+}  // namespace
+
+struct EamModel {
+  EamParams p;
+  double *dF = nullptr, *mom = nullptr;
+  size_t cap_atoms = 0;
+};
+
+EamModel *eam_create(const ta_model_desc *m, std::string &err) {
+  const int nel = m->n_elements;
+  const bool adp = m->kind == TA_MODEL_EAM_ADP;
+  const int npair = nel * (nel + 1) / 2;
+  const int need = nel * 20 + (adp ? npair * 8 : 0);
+  if (!m->eam_params || m->n_eam_params != need) {
+    err = "eam_params must hold " + std::to_string(need) + " doubles for this model";
+    return nullptr;
+  }
+  if (!(m->rcut > 0.0)) {
+    err = "rcut must be positive";
+    return nullptr;
+  }
+  if (nel > kMaxEamElements) {
+    err = "EAM/ADP models support at most 5 elements";
+    return nullptr;
+  }
+  EamModel *e = new EamModel();
+  std::memset(&e->p, 0, sizeof(e->p));
+  e->p.nel = nel;
+  e->p.adp = adp ? 1 : 0;
+  for (int k = 0; k < nel; ++k)
+    for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 20 + c];
+  for (int k = 0; k < npair; ++k) {
+    for (int c = 0; c < 8; ++c) e->p.pair[k][c] = adp ? m->eam_params[nel * 20 + k * 8 + c] : 0.0;
+    if (!adp || e->p.pair[k][6] == 0.0) e->p.pair[k][6] = 1.0;  // h: avoid 0/0 for absent terms
+  }
+  for (int k = 0; k < nel; ++k)
+    if (!(e->p.el[k][R_EQ] > 0.0) || !(e->p.el[k][RHO_E] > 0.0) || !(e->p.el[k][RHO_S] > 0.0)) {
+      delete e;
+      err = "r_eq, rho_e and rho_s must be positive";
+      return nullptr;
+    }
+  return e;
+}
+
+void eam_destroy(EamModel *m) {
+  if (!m) return;
+  if (m->dF) (void)hipFree(m->dF);
+  if (m->mom) (void)hipFree(m->mom);
+  delete m;
+}
+
+void eam_ensure(EamModel *m, const DeviceBatch &b) {
+  const size_t n = (size_t)b.n_atoms;
+  if (n <= m->cap_atoms) return;
+  if (m->dF) (void)hipFree(m->dF);
+  if (m->mom) (void)hipFree(m->mom);
+  m->dF = m->mom = nullptr;
+  const size_t cap = n + n / 8 + 64;
+  if (hipMalloc((void **)&m->dF, cap * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&m->mom, cap * (size_t)m->p.nel * 9 * sizeof(double)) != hipSuccess)
+    throw std::bad_alloc();
+  m->cap_atoms = cap;
+}
+
+void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {
+  if (b.n_atoms == 0) return;
+  SFParams sf;
+  std::memset(&sf, 0, sizeof(sf));
+  sf.n_elements = m->p.nel;
+  sf.eps = 1e-14;
+  launch_pair_geometry(sf, b, s);
+  hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);
+  if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
+    hipLaunchKernelGGL(eam_pair_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);
+    launch_force_gather(sf, b, s);
+  } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
+    launch_force_gather(sf, b, s);
+  }
+}
+
 }  // namespace ta

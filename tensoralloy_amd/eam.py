@@ -1,0 +1,271 @@
+"""
+EAM / ADP model descriptions mirroring the reference's model classes for the
+analytic-potential hot path:
+
+  EamAlloyNN  <- reference tensoralloy/nn/eam/alloy.py:24-127 (+ EamNN, eam.py:78-130)
+  AdpNN       <- reference tensoralloy/nn/eam/adp.py (dipole / quadrupole terms)
+
+Supported potentials (the ones BASELINE.json config 4 names): `zjw04` for
+rho / embed / phi (nn/eam/potentials/zjw04.py) and `mishinh` for ADP dipole /
+quadrupole (nn/eam/potentials/mishin.py:269-315). "nn" potentials (MLP-based
+rho / phi / embed) and the other empirical parameterisations are out of scope
+and raise `ValueError`.
+
+Flat parameter block handed to the C ABI (`ta_model_desc.eam_params`):
+  per element (sorted), 20 doubles in `ZJW04_KEYS` order;
+  for ADP, per unordered element pair (a <= b, row-major upper triangle),
+  8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = no angular term).
+"""
+from __future__ import annotations
+
+import json
+import os
+from datetime import datetime
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+from . import _lib
+from .utils import get_elements_from_kbody_term, get_kbody_terms
+
+ZJW04_KEYS = ["r_eq", "f_eq", "rho_e", "rho_s", "alpha", "beta", "A", "B", "kappa", "lamda",
+              "Fn0", "Fn1", "Fn2", "Fn3", "F0", "F1", "F2", "F3", "eta", "Fe"]
+
+# Zhou, Johnson, Wadley, Phys. Rev. B 69, 144113 (2004): published constants
+# (same values as the table at reference nn/eam/potentials/zjw04.py:19-152).
+ZJW04_DEFAULTS = {
+    "Al": [2.863924, 1.403115, 20.418205, 23.19574, 6.613165, 3.527021, 0.314873, 0.365551, 0.379846, 0.759692, -2.807602, -0.301435, 1.258562, -1.247604, -2.83, 0.0, 0.622245, -2.488244, 0.785902, -2.824528],
+    "Cu": [2.556162, 1.554485, 21.175871, 21.175395, 8.12762, 4.334731, 0.39662, 0.548085, 0.308782, 0.756515, -2.170269, -0.263788, 1.088878, -0.817603, -2.19, 0.0, 0.56183, -2.100595, 0.31049, -2.186568],
+    "Ni": [2.488746, 2.007018, 27.562015, 27.93041, 8.383453, 4.471175, 0.429046, 0.633531, 0.443599, 0.820658, -2.693513, -0.076445, 0.241442, -2.375626, -2.7, 0.0, 0.26539, -0.152856, 0.469, -2.699486],
+    "Ag": [2.891814, 1.106232, 14.6041, 14.604144, 9.13201, 4.870405, 0.277758, 0.419611, 0.33971, 0.750758, -1.729364, -0.255882, 0.91205, -0.561432, -1.75, 0.0, 0.744561, -1.15065, 0.783924, -1.748423],
+    "Mo": [2.7281, 2.72371, 29.354065, 29.354065, 8.393531, 4.47655, 0.708787, 1.120373, 0.13764, 0.27528, -3.692913, -0.178812, 0.38045, -3.13365, -3.71, 0.0, 0.875874, 0.776222, 0.790879, -3.712093],
+    "Co": [2.505979, 1.975299, 27.206789, 27.206789, 8.679625, 4.629134, 0.421378, 0.640107, 0.5, 1.0, -2.541799, -0.219415, 0.733381, -1.589003, -2.56, 0.0, 0.705845, -0.68714, 0.694608, -2.559307],
+    "Mg": [3.196291, 0.544323, 7.1326, 7.1326, 10.228708, 5.455311, 0.137518, 0.22593, 0.5, 1.0, -0.896473, -0.044291, 0.162232, -0.68995, -0.9, 0.0, 0.122838, -0.22601, 0.431425, -0.899702],
+    "Fe": [2.481987, 1.885957, 20.041463, 20.041463, 9.81827, 5.236411, 0.392811, 0.646243, 0.170306, 0.340613, -2.534992, -0.059605, 0.193065, -2.282322, -2.54, 0.0, 0.200269, -0.14877, 0.39175, -2.539945],
+    "Pd": [2.750897, 1.595417, 21.335246, 21.940073, 8.697397, 4.638612, 0.406763, 0.59888, 0.397263, 0.754799, -2.321006, -0.473983, 1.615343, -0.231681, -2.36, 0.0, 1.481742, -1.675615, 1.13, -2.352753],
+    "W": [2.74084, 3.48734, 37.234847, 37.234847, 8.900114, 4.746728, 0.882435, 1.394592, 0.139209, 0.278417, -4.946281, -0.148818, 0.365057, -4.432406, -4.96, 0.0, 0.661935, 0.348147, -0.582714, -4.961306],
+    "Ta": [2.860082, 3.086341, 33.787168, 33.787168, 8.489528, 4.527748, 0.611679, 1.032101, 0.176977, 0.353954, -5.103845, -0.405524, 1.112997, -3.585325, -5.14, 0.0, 1.640098, 0.221375, 0.848843, -5.141526],
+    "Zr": [3.199978, 2.230909, 30.879991, 30.879991, 8.55919, 4.564902, 0.424667, 0.640054, 0.5, 1.0, -4.485793, -0.293129, 0.990148, -3.202516, -4.51, 0.0, 0.928602, -0.98187, 0.597133, -4.509025],
+}
+
+ADP_KEYS = ["d1", "d2", "d3", "q1", "q2", "q3", "h", "rc"]
+# Mishin's ADP constants (reference nn/eam/potentials/mishin.py:62-76)
+_NINI = [4.4657e-3, -1.3702e0, -0.9611e-1, 6.4502e0, 0.2608e-1, -6.0208e0, 3.323, 5.168]
+MISHINH_DEFAULTS = {
+    "NiNi": _NINI,
+    "FeFe": [1.9135e-1, -1.0796e0, -0.8928e-1, -5.8954e-2, -1.3872e0, 2.4790e0, 6.202, 5.055],
+    "MoMo": _NINI, "MoNi": _NINI, "BeBe": _NINI,
+}
+
+
+class EamAlloyNN:
+    """`eam/alloy` model with analytic potentials: E_i = F(rho_i) + 1/2 sum_j phi(r_ij)."""
+
+    scope = "EAM"
+    tag = "alloy"
+    _kind = _lib.TA_MODEL_EAM_ALLOY
+
+    def __init__(self, elements: Sequence[str], custom_potentials=None, hidden_sizes=None,
+                 fixed_functions=None, minimize_properties=("energy", "forces"),
+                 export_properties=("energy", "forces", "stress"), parameters=None):
+        self._elements = sorted(list(elements))
+        self._fixed_functions = list(fixed_functions or [])
+        self._minimize_properties = list(minimize_properties)
+        self._export_properties = list(export_properties)
+        self._hidden_sizes = hidden_sizes
+        kbody = get_kbody_terms(self._elements, angular=False)[1]
+        unique = []
+        for el in self._elements:
+            for term in kbody[el]:
+                a, b = get_elements_from_kbody_term(term)
+                ab = "".join(sorted([a, b]))
+                if ab not in unique:
+                    unique.append(ab)
+        self._unique_kbody_terms = unique
+        self._custom_potentials = custom_potentials
+        self._potentials = self._setup_potentials(custom_potentials)
+        # overrides of the default constants: {"Ni": {"r_eq": ...}, "NiNi": {"d1": ...}}
+        self._parameters = {k: dict(v) for k, v in (parameters or {}).items()}
+        self._transformer = None
+
+    # ------------------------------------------------------------------
+    def _extra_functions(self):
+        return ()
+
+    def _setup_potentials(self, custom):
+        if custom is None:
+            raise ValueError("nn-EAM ('nn' potentials) is not implemented by tensoralloy_amd; "
+                             "pass custom_potentials='zjw04'")
+        pots = {}
+        if isinstance(custom, str):
+            for el in self._elements:
+                pots[el] = {"rho": custom, "embed": custom}
+            for term in self._unique_kbody_terms:
+                pots[term] = {"phi": custom}
+                for fn in self._extra_functions():
+                    pots[term][fn] = custom
+        else:
+            for el in self._elements:
+                pots[el] = {"rho": custom.get(el, {}).get("rho", "nn"),
+                            "embed": custom.get(el, {}).get("embed", "nn")}
+            for term in self._unique_kbody_terms:
+                sec = custom.get(term, {})
+                pots[term] = {"phi": sec.get("phi", "nn")}
+                for fn in self._extra_functions():
+                    pots[term][fn] = sec.get(fn, "nn")
+        for key, sec in pots.items():
+            for fn, name in sec.items():
+                ok = {"rho": ("zjw04",), "embed": ("zjw04",), "phi": ("zjw04",),
+                      "dipole": ("mishinh",), "quadrupole": ("mishinh",)}[fn]
+                if str(name).lower() not in ok:
+                    raise ValueError(f"potential '{name}' for {key}/{fn} is not implemented by "
+                                     f"tensoralloy_amd (available: {ok})")
+        return pots
+
+    # -- reference-compatible surface ----------------------------------------------
+    @property
+    def elements(self):
+        return self._elements
+
+    @property
+    def unique_kbody_terms(self):
+        return self._unique_kbody_terms
+
+    @property
+    def potentials(self):
+        return self._potentials
+
+    @property
+    def predict_properties(self):
+        return self._export_properties
+
+    @property
+    def variational_energy(self):
+        return "energy"
+
+    @property
+    def is_finite_temperature(self):
+        return False
+
+    @property
+    def transformer(self):
+        return self._transformer
+
+    def attach_transformer(self, clf):
+        if clf.angular:
+            raise ValueError("EAM models need a radial-only transformer (angular=False)")
+        self._transformer = clf
+
+    def as_dict(self):
+        return {"class": self.__class__.__name__, "elements": self._elements,
+                "custom_potentials": self._potentials, "hidden_sizes": self._hidden_sizes,
+                "fixed_functions": self._fixed_functions,
+                "minimize_properties": self._minimize_properties,
+                "export_properties": self._export_properties,
+                "parameters": self._parameters}
+
+    # -- parameters ---------------------------------------------------------------------
+    def element_parameters(self, el: str) -> Dict[str, float]:
+        if el not in ZJW04_DEFAULTS:
+            raise ValueError(f"zjw04 has no parameters for element {el}")
+        p = dict(zip(ZJW04_KEYS, ZJW04_DEFAULTS[el]))
+        p.update(self._parameters.get(el, {}))
+        return p
+
+    def pair_parameters(self, term: str):
+        return None
+
+    def flat_parameters(self) -> np.ndarray:
+        out = []
+        for el in self._elements:
+            p = self.element_parameters(el)
+            out.extend(p[k] for k in ZJW04_KEYS)
+        return np.array(out, dtype=np.float64)
+
+    def to_desc(self):
+        clf = self._transformer
+        if clf is None:
+            raise ValueError("A descriptor transformer must be attached.")
+        keep = []
+        params = np.ascontiguousarray(self.flat_parameters())
+        keep.append(params)
+        desc = _lib.ModelDesc()
+        desc.kind = self._kind
+        desc.n_elements = len(self._elements)
+        desc.rcut = float(clf.rcut)
+        desc.acut = float(clf.rcut)
+        desc.angular = 0
+        desc.n_eam_params = len(params)
+        desc.eam_params = _lib.as_dp(params)
+        return desc, keep
+
+    def export(self, output_graph_path: str, **_ignored):
+        from .model import API_VERSION, _model_stem
+        if self._transformer is None:
+            raise ValueError("A transformer must be attached before exporting to a pb file.")
+        stem = _model_stem(output_graph_path)
+        props = {"energy": "Output/Energy/energy:0", "energy/atom": "Output/Energy/atomic:0"}
+        want = set(self._export_properties)
+        if want & {"forces", "stress", "total_pressure"}:
+            props["forces"] = "Output/Forces/forces:0"
+        if "stress" in want:
+            props["stress"] = "Output/Stress/Voigt/stress:0"
+            props["virial"] = "Output/Stress/Full/virial:0"
+            props["total_pressure"] = "Output/Stress/pressure/GPa:0"
+        for unsupported in ("hessian", "elastic"):
+            if unsupported in want:
+                raise ValueError(f"'{unsupported}' is not implemented by tensoralloy_amd")
+        meta = {
+            "format": "tensoralloy_amd/1",
+            "Transformer/params": self._transformer.as_dict(),
+            "Metadata/timestamp": str(datetime.today()),
+            "Metadata/precision": "high",
+            "Metadata/variational_energy": "energy",
+            "Metadata/is_finite_temperature": 0,
+            "Metadata/api": API_VERSION,
+            "Metadata/ops": props,
+            "nn": self.as_dict(),
+            "weights": None,
+        }
+        with open(stem + ".json", "w") as fp:
+            json.dump(meta, fp, indent=1)
+        return stem + ".json"
+
+
+class AdpNN(EamAlloyNN):
+    """`eam/adp`: EAM plus Mishin's dipole and quadrupole terms (nn/eam/adp.py)."""
+
+    tag = "adp"
+    _kind = _lib.TA_MODEL_EAM_ADP
+
+    def _extra_functions(self):
+        return ("dipole", "quadrupole")
+
+    def pair_parameters(self, term: str):
+        a, b = get_elements_from_kbody_term(term)
+        key = "".join(sorted([a, b]))
+        base = MISHINH_DEFAULTS.get(key)
+        over = self._parameters.get(key, {})
+        if base is None and not over:
+            return None
+        p = dict(zip(ADP_KEYS, base if base is not None else [0.0] * 6 + [1.0, 0.0]))
+        p.update(over)
+        return p
+
+    def flat_parameters(self) -> np.ndarray:
+        out = list(EamAlloyNN.flat_parameters(self))
+        n = len(self._elements)
+        for i in range(n):
+            for j in range(i, n):
+                term = self._elements[i] + self._elements[j]
+                p = self.pair_parameters(term)
+                if p is None:
+                    raise ValueError(f"mishinh has no dipole/quadrupole parameters for {term}")
+                out.extend(p[k] for k in ADP_KEYS)
+        return np.array(out, dtype=np.float64)
+
+
+def nn_from_dict(cls_name: str, cfg: dict):
+    cfg = dict(cfg)
+    cls = {"EamAlloyNN": EamAlloyNN, "AdpNN": AdpNN}[cls_name]
+    return cls(**cfg)

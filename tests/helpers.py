@@ -58,3 +58,41 @@ def oracle_eval(nn, atoms, want_forces=True):
     from oracle.sf import evaluate
     return evaluate(oracle_model(nn), atoms.get_chemical_symbols(), atoms.positions,
                     np.asarray(atoms.get_cell(complete=True)), atoms.pbc, want_forces=want_forces)
+
+
+def make_eam(elements, rcut=6.5, adp=False):
+    from tensoralloy_amd.eam import EamAlloyNN, AdpNN
+    clf = UniversalTransformer(elements, rcut=rcut, angular=False)
+    if adp:
+        pots = {el: {"rho": "zjw04", "embed": "zjw04"} for el in elements}
+        nn = AdpNN(elements, custom_potentials=None if False else _adp_pots(elements))
+    else:
+        nn = EamAlloyNN(elements, custom_potentials="zjw04")
+    nn.attach_transformer(clf)
+    return nn
+
+
+def _adp_pots(elements):
+    els = sorted(elements)
+    pots = {el: {"rho": "zjw04", "embed": "zjw04"} for el in els}
+    for i, a in enumerate(els):
+        for b in els[i:]:
+            pots[a + b] = {"phi": "zjw04", "dipole": "mishinh", "quadrupole": "mishinh"}
+    return pots
+
+
+def oracle_eam_eval(nn, atoms):
+    """Oracle counterpart of an EamAlloyNN / AdpNN (test infrastructure only)."""
+    from oracle.eam import EamModel, evaluate
+    from tensoralloy_amd.eam import AdpNN, ADP_KEYS
+    adp = None
+    if isinstance(nn, AdpNN):
+        adp = {}
+        els = nn.elements
+        for i, a in enumerate(els):
+            for b in els[i:]:
+                adp[a + b] = nn.pair_parameters(a + b)
+    m = EamModel(nn.elements, nn.transformer.rcut,
+                 params={el: nn.element_parameters(el) for el in nn.elements}, adp=adp)
+    return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc)

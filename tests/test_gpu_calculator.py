@@ -1,0 +1,84 @@
+"""The drop-in boundary on a real GPU: TensorAlloyCalculator behaves like the
+reference's ASE calculator (tensoralloy/calculator.py:31-383)."""
+import numpy as np
+import pytest
+
+from tests.helpers import fcc, pd3o2, make_nn, make_eam, oracle_eval, oracle_eam_eval
+
+pytestmark = pytest.mark.gpu
+
+
+def test_calculator_pd3o2_roundtrip(lib, tmp_path):
+    from tensoralloy_amd import TensorAlloyCalculator
+    nn = make_nn(["Pd", "O"], 6.5, True, [32, 32], minmax=True, static_energy={"Pd": -1.5, "O": -0.5})
+    path = nn.export(str(tmp_path / "pd3o2.pb"))
+    calc = TensorAlloyCalculator(path)
+    assert calc.elements == ["O", "Pd"]
+    assert set(calc.predict_properties) >= {"energy", "forces", "stress", "energy/atom"}
+    atoms = pd3o2()
+    o = oracle_eval(nn, atoms)
+    e = calc.get_potential_energy(atoms)
+    f = calc.get_forces(atoms)          # caller's (ASE) order
+    s = calc.get_stress(atoms)
+    assert abs(e - o["energy"]) < 1e-6
+    assert np.abs(f - o["forces"]).max() < 1e-5
+    assert np.abs(s - o["stress_voigt"]).max() < 1e-8
+    assert np.abs(calc.get_atomic(atoms) - o["atomic"]).max() < 1e-6
+    assert abs(calc.get_total_pressure(atoms) - o["total_pressure"]) < 1e-5
+    assert calc.get_stress(atoms, voigt=False).shape == (3, 3)
+    # results are GSL-ordered (element-sorted: O, O, Pd, Pd, Pd), virtual row stripped
+    calc.calculate(atoms, properties=["forces", "energy/atom"])
+    assert np.abs(calc.results["forces"] - o["forces"][[3, 4, 0, 1, 2]]).max() < 1e-5
+    assert np.abs(calc.results["energy/atom"] - o["atomic"][[3, 4, 0, 1, 2]]).max() < 1e-6
+    assert set(calc.results) == {"forces", "energy/atom"}   # calculator.py:358-369
+    n0 = calc.ncalls
+    calc.set_prerequisite_properties(["energy", "forces", "stress"])
+    calc.calculate(atoms, properties=["energy"])
+    assert set(calc.results) == {"energy", "forces", "stress"}
+    assert calc.ncalls == n0 + 1
+    calc.reset_call_counter()
+    assert calc.ncalls == 0
+    with pytest.raises(KeyError):
+        calc.calculate(atoms, properties=["hessian"])
+    assert calc.get_magnetic_moment(atoms) is None
+
+
+def test_calculator_permuted_atoms_and_absent_element(lib, tmp_path):
+    from tensoralloy_amd import TensorAlloyCalculator, Atoms
+    nn = make_nn(["Pd", "O"], 6.5, True, [16, 16])
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "m.json")))
+    a = pd3o2()
+    perm = [0, 1, 3, 4, 2]  # Pd2O2Pd of the reference tests (test_utils.py:57-66)
+    b = Atoms(symbols=[a.get_chemical_symbols()[k] for k in perm], positions=a.positions[perm],
+              cell=np.asarray(a.get_cell()), pbc=a.pbc)
+    fa, fb = calc.get_forces(a), calc.get_forces(b)
+    assert np.abs(fa[perm] - fb).max() < 1e-9
+    assert abs(calc.get_potential_energy(a) - calc.get_potential_energy(b)) < 1e-9
+    # a structure without oxygen still has one (masked) O row in GSL order
+    pd = Atoms(symbols=["Pd"] * 3, positions=a.positions[:3], cell=np.asarray(a.get_cell()), pbc=a.pbc)
+    calc.calculate(pd, properties=["forces"])
+    assert calc.results["forces"].shape == (4, 3)
+    assert np.all(calc.results["forces"][0] == 0.0)
+    assert calc.get_forces(pd).shape == (3, 3)
+
+
+def test_calculator_eam(lib, tmp_path):
+    from tensoralloy_amd import TensorAlloyCalculator
+    nn = make_eam(["Ni"], 6.5)
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "Ni.zhou04.pb")))
+    atoms = fcc(rep=(2, 2, 2), a=3.52, jitter=0.0)
+    e = calc.get_potential_energy(atoms)
+    # E/atom of Zjw04 Ni for bulk('Ni', cubic=True)*[2,2,2], rc = 6.5 (SURVEY §8c pin 7)
+    assert abs(e / len(atoms) + 4.44999667) < 1e-7
+    atoms = fcc(rep=(2, 2, 2), a=3.52, jitter=0.05)
+    o = oracle_eam_eval(nn, atoms)
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < 1e-5
+    assert np.abs(calc.get_stress(atoms) - o["stress_voigt"]).max() < 1e-8
+
+
+def test_unsupported_model_file(lib, tmp_path):
+    from tensoralloy_amd import TensorAlloyCalculator
+    p = tmp_path / "frozen.pb"
+    p.write_bytes(b"\x0a\x00")
+    with pytest.raises(ValueError):
+        TensorAlloyCalculator(str(p))
