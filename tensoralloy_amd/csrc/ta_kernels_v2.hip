@@ -5,9 +5,10 @@
 // _apply_g4_functions, transformer/universal.py:622-694, nn/atomic/sf.py:121-182,
 // and their tf.gradients, nn/basic.py:277-331).
 //
-// Work decomposition. A workgroup is ONE wavefront and owns a run of WHOLE
+// Work decomposition. A workgroup (min(cap, 256) lanes) owns a run of WHOLE
 // centre atoms whose neighbour counts sum to <= cap (packed on the host, cap =
-// 192 or the largest neighbour count); their pair records are
+// 192 or the largest neighbour count, so normally one lane per directed pair
+// and 3 wavefronts per workgroup); their pair records are
 // staged in LDS as structure-of-arrays {x, y, z, r^2, 1/r, H, G} (H = exp(-beta
 // u) fc(u), G = (dH/dr)/r for this launch's beta, computed while staging) so a
 // wavefront's per-lane reads of consecutive neighbours are bank-conflict free.
@@ -35,7 +36,7 @@
 namespace ta {
 namespace {
 
-constexpr int kBlock = 64;
+constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
 constexpr int kNF = 7;  // x y z r2 inv_r H G
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &c
 
 __device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
                                       const Fields &f, int s0, int M) {
-  for (int item = threadIdx.x; item < M; item += kBlock) {
+  for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)(s0 + item));
     const double2 v0 = src[0], v1 = src[1], v2 = src[2];
     f.x[item] = v0.x;
@@ -145,9 +146,12 @@ __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, c
   return mask;
 }
 
-template <int NSPEC, int NG, int NZ, int HD>
+// DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
+// nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
 __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
                                                                DeviceBatch b) {
+  static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   extern __shared__ double lds[];
   const Fields f = carve(lds, b.cap);
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   const double beta = ch.beta[0];
   stage(sf, beta, b, f, s0, M);
 
-  for (int item = threadIdx.x; item < M; item += kBlock) {
+  for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -194,10 +198,15 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 #pragma unroll
           for (int iz = 0; iz < NZ; ++iz) {
             double pw;
-            if (ch.zeta_int[iz] > 0)
-              pw = pow_int_m1(basev, ch.zeta_int[iz]) * basev;
-            else
-              pw = pow(basev, ch.zeta[iz]);
+            if constexpr (DEFZ) {
+              const double b2 = basev * basev;
+              pw = (iz == 0) ? basev : b2 * b2;
+            } else {
+              if (ch.zeta_int[iz] > 0)
+                pw = pow_int_m1(basev, ch.zeta_int[iz]) * basev;
+              else
+                pw = pow(basev, ch.zeta[iz]);
+            }
             const double v = pw * common;
 #pragma unroll
             for (int sp = 0; sp < NSPEC; ++sp)
@@ -218,9 +227,10 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   }
 }
 
-template <int NSPEC, int NG, int NZ, int HD>
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
 __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChunk ch,
                                                              DeviceBatch b, int first) {
+  static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   extern __shared__ double lds[];
   const int kCap = b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
@@ -230,11 +240,11 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
   const double beta = ch.beta[0];
-  for (int k = threadIdx.x; k < 3 * kCap; k += kBlock) gacc[k] = 0.0;
+  for (int k = threadIdx.x; k < 3 * kCap; k += blockDim.x) gacc[k] = 0.0;
   stage(sf, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
-  for (int item = threadIdx.x; item < M; item += kBlock) {
+  for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -246,7 +256,8 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     const int sa = f.sp[item];
 
     // dE/dG of the channels of term (sa, sp) for every partner species sp
-    double w[NSPEC][NG][NZ];
+    // w = dE/dG 2^(1-zeta); wd = w zeta gamma (factor of the derivative of (1 + gamma c)^zeta)
+    double w[NSPEC][NG][NZ], wd[NSPEC][NG][NZ];
 #pragma unroll
     for (int sp = 0; sp < NSPEC; ++sp) {
       const double *wsrc = b.dEdG + (size_t)i * sf.ndim + sf.n_radial_dim +
@@ -254,7 +265,10 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
 #pragma unroll
       for (int ig = 0; ig < NG; ++ig)
 #pragma unroll
-        for (int iz = 0; iz < NZ; ++iz) w[sp][ig][iz] = wsrc[ch.chan[ig * NZ + iz]] * ch.kz[iz];
+        for (int iz = 0; iz < NZ; ++iz) {
+          w[sp][ig][iz] = wsrc[ch.chan[ig * NZ + iz]] * ch.kz[iz];
+          wd[sp][ig][iz] = w[sp][ig][iz] * ch.zeta[iz] * ch.gamma[ig];
+        }
     }
 
     double gx = 0.0, gy = 0.0, gz = 0.0;
@@ -285,16 +299,30 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
           const double basev = fma(ch.gamma[ig], cth, 1.0);
 #pragma unroll
           for (int iz = 0; iz < NZ; ++iz) {
-            double pm1;
-            if (ch.zeta_int[iz] > 0)
-              pm1 = pow_int_m1(basev, ch.zeta_int[iz]);
-            else
-              pm1 = pow(basev, ch.zeta[iz] - 1.0);
-            double ws = w[0][ig][iz];
+            double ws = w[0][ig][iz], wds = wd[0][ig][iz];
 #pragma unroll
-            for (int sp = 1; sp < NSPEC; ++sp) ws = (sb == sp) ? w[sp][ig][iz] : ws;
-            S0 = fma(ws, pm1 * basev, S0);
-            S1 = fma(ws * ch.zeta[iz] * ch.gamma[ig], pm1, S1);
+            for (int sp = 1; sp < NSPEC; ++sp) {
+              ws = (sb == sp) ? w[sp][ig][iz] : ws;
+              wds = (sb == sp) ? wd[sp][ig][iz] : wds;
+            }
+            if constexpr (DEFZ) {
+              if (iz == 0) {  // zeta = 1: P = base, P' = gamma
+                S0 = fma(ws, basev, S0);
+                S1 += wds;
+              } else {        // zeta = 4: P = base^4, P' = 4 gamma base^3
+                const double b2 = basev * basev;
+                S0 = fma(ws, b2 * b2, S0);
+                S1 = fma(wds, b2 * basev, S1);
+              }
+            } else {
+              double pm1;
+              if (ch.zeta_int[iz] > 0)
+                pm1 = pow_int_m1(basev, ch.zeta_int[iz]);
+              else
+                pm1 = pow(basev, ch.zeta[iz] - 1.0);
+              S0 = fma(ws, pm1 * basev, S0);
+              S1 = fma(wds, pm1, S1);
+            }
           }
         }
         // (dV/dr_a)/r_a, (dV/dr_b)/r_b, (dV/dr_jk)/r_jk for V = sum_c w_c v_c
@@ -315,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     atomicAdd(&gacc[2 * kCap + item], gz);
   }
   __syncthreads();
-  for (int item = threadIdx.x; item < M; item += kBlock) {
+  for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const int64_t p = (int64_t)s0 + item;
     double gx = gacc[item], gy = gacc[kCap + item], gz = gacc[2 * kCap + item];
     if (first) {
@@ -353,25 +381,37 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
 
 template <int NSPEC, int NG, int NZ>
 void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, hipStream_t s) {
-  const dim3 grid((unsigned)b.n_blk), block(kBlock);
+  const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = v2_lds_bytes(false, b.cap);
+  if constexpr (NZ == 2) {
+    if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b);
+      return;
+    }
+  }
   if (ch.n_hd == 16)
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b);
   else if (ch.n_hd == 24)
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b);
   else
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b);
 }
 template <int NSPEC, int NG, int NZ>
 void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int first, hipStream_t s) {
-  const dim3 grid((unsigned)b.n_blk), block(kBlock);
+  const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = v2_lds_bytes(true, b.cap);
+  if constexpr (NZ == 2) {
+    if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+      hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, first);
+      return;
+    }
+  }
   if (ch.n_hd == 16)
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, first);
   else if (ch.n_hd == 24)
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, first);
   else
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 0>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b, first);
 }
 
 }  // namespace
