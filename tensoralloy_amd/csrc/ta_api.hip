@@ -15,8 +15,9 @@
 
 namespace ta {
 size_t mlp_scratch_doubles(const MlpDev &mlp);
-void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
-                     const DeviceBatch &b, double *scratch, hipStream_t s);
+void launch_mlp_impl(const SFParams &sf, const MlpDev &mlp, int activation, int ndim,
+                     const int32_t *atoms, int n_atoms, const DeviceBatch &b, double *scratch,
+                     bool fused, hipStream_t s);
 // EAM / ADP (ta_eam.hip)
 struct EamModel;
 EamModel *eam_create(const ta_model_desc *m, std::string &err);
@@ -246,6 +247,7 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
   const double *wsrc = m->weights;
   for (int el = 0; el < nel; ++el) {
     MlpDev &md = h->mlp[el];
+    const double *wsrc_begin = wsrc;
     const int L = m->n_layers[el];
     if (L < 1 || L > kMaxLayers) throw std::domain_error("MLP depth out of range (1..8 layers)");
     if (sizes[0] != sf.ndim)
@@ -280,6 +282,49 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
       ly.b = upload(h, bb);
       md.max_np = std::max(md.max_np, ly.np);
       md.max_kp = std::max(md.max_kp, ly.kp);
+    }
+    {
+      // LDS plan: row stride = width (+16 when a multiple of 32) so that k-rows r and r+1 of a
+      // 32-lane ds_read_b64 group land on disjoint banks
+      int off = 0;
+      for (int l = 0; l < L; ++l) {
+        MlpLayerDev &ly = md.layer[l];
+        ly.ws = ly.np + ((ly.np % 32 == 0) ? 16 : 0);
+        ly.wts = ly.kp + ((ly.kp % 32 == 0) ? 16 : 0);
+        ly.lds_w = off;
+        off += ly.kp * ly.ws;
+        ly.lds_wt = off;
+        off += ly.np * ly.wts;
+      }
+      off += off & 1;
+      const int w = std::max(md.max_np, md.max_kp);
+      const size_t act_doubles = 2 * 16 * (size_t)(w + 2), da_doubles = (size_t)L * 16 * (w + 2);
+      md.lds_w_doubles = off;
+      md.w_in_lds = ((size_t)off + act_doubles) * sizeof(double) <= 150 * 1024 ? 1 : 0;
+      // measured: streaming the weights from L2 (small LDS footprint, more workgroups per CU)
+      // beats the LDS-resident copy; TA_MLP_WLDS=1 re-enables it (tuning switch)
+      if (!(std::getenv("TA_MLP_WLDS") && std::getenv("TA_MLP_WLDS")[0] == '1')) md.w_in_lds = 0;
+      if (!md.w_in_lds) md.da_in_lds = 0;
+      md.da_in_lds = (md.w_in_lds && ((size_t)off + act_doubles + da_doubles) * sizeof(double) <= 150 * 1024) ? 1 : 0;
+      if (!md.w_in_lds) md.da_in_lds = 0;
+      if (md.w_in_lds) {
+        std::vector<double> image((size_t)off, 0.0);
+        const double *src = m->weights;
+        // walk this element's layers again to fill the padded image
+        const double *wp = wsrc_begin;
+        for (int l = 0; l < L; ++l) {
+          MlpLayerDev &ly = md.layer[l];
+          for (int k = 0; k < ly.k; ++k)
+            for (int n = 0; n < ly.n; ++n) {
+              const double v = wp[(size_t)k * ly.n + n];
+              image[(size_t)ly.lds_w + (size_t)k * ly.ws + n] = v;
+              image[(size_t)ly.lds_wt + (size_t)n * ly.wts + k] = v;
+            }
+          wp += (size_t)ly.k * ly.n + ly.n;
+        }
+        (void)src;
+        md.lds_image = upload(h, image);
+      }
     }
     if (m->minmax_scale) {
       if (!m->xlo || !m->xhi) throw std::invalid_argument("minmax_scale set but xlo/xhi missing");
@@ -367,29 +412,43 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   bool used[TA_N_KERNEL_SLOTS] = {false};
 
   if (h->kind == TA_MODEL_SF_MLP) {
-    begin(TA_K_PAIR_GEOMETRY);
-    launch_pair_geometry(h->sf, db, s);
-    end(TA_K_PAIR_GEOMETRY);
-    used[TA_K_PAIR_GEOMETRY] = true;
+    if (!h->use_v2) {
+      // second-generation forward kernels compute the pair geometry while staging
+      begin(TA_K_PAIR_GEOMETRY);
+      launch_pair_geometry(h->sf, db, s);
+      end(TA_K_PAIR_GEOMETRY);
+      used[TA_K_PAIR_GEOMETRY] = true;
+    }
     if (h->sf.angular) {
       begin(TA_K_G4_FORWARD);
-      if (h->use_v2)
-        for (const ChunkPlan &cp : h->chunks_v2) launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, db, s);
-      else
+      if (h->use_v2) {
+        bool geometry = true;
+        for (const ChunkPlan &cp : h->chunks_v2) {
+          launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
+          geometry = false;
+        }
+      } else
         for (const ChunkPlan &cp : h->chunks) launch_g4_forward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, db, s);
       end(TA_K_G4_FORWARD);
       used[TA_K_G4_FORWARD] = true;
     }
-    begin(TA_K_DESCRIPTOR_REDUCE);
+    // the descriptor assembly (G2 + per-pair G4 partial sums -> G) can be the MLP kernel's prologue
+    // when TA_MLP_FUSED=1 (tuning switch); by default it is its own kernel
     h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
-    launch_descriptor_reduce(h->sf, db, s);
-    end(TA_K_DESCRIPTOR_REDUCE);
-    used[TA_K_DESCRIPTOR_REDUCE] = true;
+    // measured on MI355X: the separate wave-per-atom reduce kernel is faster, both for one
+    // frame and in batches (profiles/r01_tuning_notes.md)
+    static const bool fused = std::getenv("TA_MLP_FUSED") && std::getenv("TA_MLP_FUSED")[0] == '1';
+    if (!fused) {
+      begin(TA_K_DESCRIPTOR_REDUCE);
+      launch_descriptor_reduce(h->sf, db, s);
+      end(TA_K_DESCRIPTOR_REDUCE);
+      used[TA_K_DESCRIPTOR_REDUCE] = true;
+    }
     begin(TA_K_MLP);
     for (int el = 0; el < h->n_elements; ++el) {
       const int n_el = db.elem_start[el + 1] - db.elem_start[el];
-      launch_mlp_impl(h->mlp[el], h->activation, h->sf.ndim, db.elem_atoms + db.elem_start[el], n_el,
-                      db, h->mlp_scratch.ptr, s);
+      launch_mlp_impl(h->sf, h->mlp[el], h->activation, h->sf.ndim,
+                      db.elem_atoms + db.elem_start[el], n_el, db, h->mlp_scratch.ptr, fused, s);
     }
     end(TA_K_MLP);
     used[TA_K_MLP] = true;

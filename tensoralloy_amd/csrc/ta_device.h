@@ -88,12 +88,18 @@ struct MlpLayerDev {
   double *b;       // [np]
   int act;         // apply activation
   int res;         // resnet skip
+  int ws, wts;     // LDS row strides of W and W^T (padded against bank conflicts)
+  int lds_w, lds_wt;  // offsets (doubles) of the LDS copies
 };
 struct MlpDev {
   int n_layers = 0;  // incl. output layer
   MlpLayerDev layer[kMaxLayers];
   double *xlo = nullptr, *xhi = nullptr;  // [D] or null
   int max_np = 0, max_kp = 0;
+  int w_in_lds = 0;        // all layers' W and W^T fit in LDS beside the activations
+  int da_in_lds = 0;       // ... and so do the activation derivatives
+  int lds_w_doubles = 0;   // size of the LDS image (even)
+  double *lds_image = nullptr;  // device copy of the padded W / W^T image
 };
 
 void launch_pair_geometry(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
@@ -111,7 +117,7 @@ size_t g4_lds_bytes(int nnl_max);
 
 // second-generation angular kernels (ta_kernels_v2.hip); `ch` holds one beta
 size_t v2_lds_bytes(bool backward, int cap);
-void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz,
+void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           const DeviceBatch &b, hipStream_t s);
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);

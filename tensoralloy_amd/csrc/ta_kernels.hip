@@ -26,6 +26,7 @@
 
 #include "ta_device.h"
 #include "ta_math.h"
+#include "ta_reduce.h"
 
 namespace ta {
 
@@ -178,49 +179,8 @@ __global__ __launch_bounds__(kBlock) void descriptor_reduce_kernel(SFParams sf, 
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
-  const int nel = sf.n_elements;
-  const int sA = b.species[i];
-  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
   double *Gi = b.G + (size_t)i * sf.ndim;
-
-  for (int sb = 0; sb < nel; ++sb) {
-    const int tr = radial_term(sA, sb);
-    for (int c = 0; c < sf.n_rad; ++c) {
-      const double eta = sf.eta[c], omega = sf.omega[c];
-      double acc = 0.0;
-      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
-        const double r2 = b.rec[kRecDoubles * (size_t)q + 3];
-        const double u = r2 * sf.inv_rc2;
-        if (u < 1.0) {
-          const double r = sqrt(r2);
-          const double f = cutoff_u_value(sf.cutoff, u);
-          const double dr = r - omega;
-          // exp(-eta (r - omega)^2 / rc^2) fc(r)   (sf.py:101-108)
-          acc += ta_exp(-eta * dr * dr * sf.inv_rc2) * f;
-        }
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) Gi[tr * sf.n_rad + c] = acc;
-    }
-  }
-  if (sf.angular) {
-    for (int s1 = 0; s1 < nel; ++s1)
-      for (int s2 = s1; s2 < nel; ++s2) {
-        const int t = angular_term(s1, s2, nel);
-        for (int c = 0; c < sf.n_ang; ++c) {
-          double acc = 0.0;
-          const double *col = b.part4 + (size_t)(s2 * sf.n_ang + c) * b.n_pairs;
-          for (int q = seg[s1] + lane; q < seg[s1 + 1]; q += 64) acc += col[q];
-          if (s1 != s2) {
-            const double *col2 = b.part4 + (size_t)(s1 * sf.n_ang + c) * b.n_pairs;
-            for (int q = seg[s2] + lane; q < seg[s2 + 1]; q += 64) acc += col2[q];
-          }
-          acc = wave_sum(acc);
-          // v1 kernels visit every unordered {j, k} from both sides (ang_scale = 0.5)
-          if (lane == 0) Gi[sf.n_radial_dim + t * sf.n_ang + c] = sf.ang_scale * acc;
-        }
-      }
-  }
+  atom_descriptors<64>(sf, b, i, lane, true, [&](int c, double v) { Gi[c] = v; });
 }
 
 // --------------------------------------------------------------------------
@@ -380,34 +340,55 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(SFParams sf, AngChunk 
 //   W_i = sum_{p in N(i)} g[p] (x) D[p]            (== -F^T R + (dE/dh)^T h, basic.py:306-316)
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (i >= b.n_atoms) return;
+  // 16 lanes (one DPP row) per atom: the 12 sums are VALU row rotations, no LDS shuffles
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
+  const bool active = i < b.n_atoms;
   const int64_t P = b.n_pairs;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int q = b.pair_start[i] + lane; q < b.pair_start[i + 1]; q += 64) {
-    const int r = b.pair_rev[q];
-    const double gx = b.g[q], gy = b.g[P + q], gz = b.g[2 * P + q];
-    f[0] += gx - b.g[r];
-    f[1] += gy - b.g[P + r];
-    f[2] += gz - b.g[2 * P + r];
-    const double *rec = b.rec + kRecDoubles * (size_t)q;
-    const double dx = rec[0], dy = rec[1], dz = rec[2];
-    w[0] = fma(gx, dx, w[0]);
-    w[1] = fma(gx, dy, w[1]);
-    w[2] = fma(gx, dz, w[2]);
-    w[3] = fma(gy, dx, w[3]);
-    w[4] = fma(gy, dy, w[4]);
-    w[5] = fma(gy, dz, w[5]);
-    w[6] = fma(gz, dx, w[6]);
-    w[7] = fma(gz, dy, w[7]);
-    w[8] = fma(gz, dz, w[8]);
+  const int q0 = active ? b.pair_start[i] : 0, q1 = active ? b.pair_start[i + 1] : 0;
+  // batches of 4 strided pairs: the 4 reverse indices, then all 4 x 9 operands, are in flight
+  // together, so a batch costs two memory latencies instead of eight
+  for (int qb = q0 + lane; qb < q1; qb += 64) {
+    int r[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = qb + 16 * k;
+      ok[k] = q < q1;
+      r[k] = ok[k] ? b.pair_rev[q] : 0;
+    }
+    double gq[4][3], gr[4][3], d[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = ok[k] ? qb + 16 * k : q0;
+      const double2 *rec = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)q);
+      const double2 v0 = rec[0], v1 = rec[1];
+      d[k][0] = v0.x;
+      d[k][1] = v0.y;
+      d[k][2] = v1.x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gq[k][c] = b.g[c * P + q];
+        gr[k][c] = b.g[c * P + r[k]];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f[c] += gq[k][c] - gr[k][c];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[3 * c + e] = fma(gq[k][c], d[k][e], w[3 * c + e]);
+      }
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) f[k] = wave_sum(f[k]);
+  for (int k = 0; k < 3; ++k) f[k] = row16_sum(f[k]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wave_sum(w[k]);
-  if (lane == 0) {
+  for (int k = 0; k < 9; ++k) w[k] = row16_sum(w[k]);
+  if (lane == 0 && active) {
     for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
     for (int k = 0; k < 9; ++k) b.wat[9 * (size_t)i + k] = w[k];
   }
@@ -538,7 +519,7 @@ void launch_backward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int
 
 void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  hipLaunchKernelGGL(force_gather_kernel, dim3(blocks_for(b.n_atoms * 64, kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(force_gather_kernel, dim3(blocks_for(b.n_atoms * 16, kBlock)), dim3(kBlock), 0,
                      s, b);
 }
 

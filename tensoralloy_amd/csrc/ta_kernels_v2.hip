@@ -49,6 +49,7 @@ __device__ __forceinline__ int radial_term2(int center, int other) {
 
 struct Fields {
   double *x, *y, *z, *r2, *inv, *H, *G;
+  float *xf, *yf, *zf;  // single-precision copies for the candidate scan
   unsigned char *sp;
 };
 
@@ -61,7 +62,10 @@ __device__ __forceinline__ Fields carve(double *lds, int cap) {
   f.inv = f.r2 + cap;
   f.H = f.inv + cap;
   f.G = f.H + cap;
-  f.sp = reinterpret_cast<unsigned char *>(f.G + cap);
+  f.xf = reinterpret_cast<float *>(f.G + cap);
+  f.yf = f.xf + cap;
+  f.zf = f.yf + cap;
+  f.sp = reinterpret_cast<unsigned char *>(f.zf + cap);
   return f;
 }
 
@@ -100,14 +104,44 @@ __device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &c
   }
 }
 
+// `geom` != 0: the pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps, 1/r
+// (reference calculate_rij, transformer/universal.py:448-474) is computed here
+// and the pair record written for the later kernels; otherwise it is read.
 __device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
-                                      const Fields &f, int s0, int M) {
+                                      const Fields &f, int s0, int M, int geom = 0) {
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
-    const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)(s0 + item));
-    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    double2 v0, v1, v2;
+    if (geom) {
+      const int64_t p = (int64_t)s0 + item;
+      const int i = b.pair_i[p], j = b.pair_j[p];
+      const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
+      const double sx = (double)b.pair_shift[3 * p], sy = (double)b.pair_shift[3 * p + 1],
+                   sz = (double)b.pair_shift[3 * p + 2];
+      const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+      const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+      const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+      const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+      const double r2 = dx * dx + dy * dy + dz * dz + sf.eps;
+      v0 = make_double2(dx, dy);
+      v1 = make_double2(dz, r2);
+      v2 = make_double2(1.0 / sqrt(r2), 0.0);
+      double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)p);
+      dst[0] = v0;
+      dst[1] = v1;
+      dst[2] = v2;
+      dst[3] = make_double2(0.0, 0.0);
+    } else {
+      const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)(s0 + item));
+      v0 = src[0];
+      v1 = src[1];
+      v2 = src[2];
+    }
     f.x[item] = v0.x;
     f.y[item] = v0.y;
     f.z[item] = v1.x;
+    f.xf[item] = (float)v0.x;
+    f.yf[item] = (float)v0.y;
+    f.zf[item] = (float)v1.x;
     f.r2[item] = v1.y;
     f.inv[item] = v2.x;
     const double u = v1.y * sf.inv_ac2;
@@ -126,19 +160,25 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
   __syncthreads();
 }
 
-// validity mask of the partners a + s, s in [sc, sc + 63]
+// Candidate mask of the partners a + s, s in [sc, sc + 63]. The scan runs in
+// single precision (half the issue cost of fp64, 4-byte LDS reads) with a
+// relative margin far above the fp32 rounding of r_jk^2; the double-precision
+// test u < 1 is repeated on every candidate before it contributes, so the mask
+// only has to be a superset.
 __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, const Fields &f,
                                                            int base, int n, int a, int sc, int smax,
-                                                           double ax, double ay, double az) {
+                                                           int item) {
   unsigned long long mask = 0ull;
   const int send = (smax < sc + 63) ? smax : sc + 63;
+  const float ax = f.xf[item], ay = f.yf[item], az = f.zf[item];
+  const float lim = (float)(sf.acut * sf.acut) * 1.0001f;
   for (int s = sc; s <= send; ++s) {
     int bl = a + s;
     if (bl >= n) bl -= n;
     const int q = base + bl;
-    const double ex = f.x[q] - ax, ey = f.y[q] - ay, ez = f.z[q] - az;
-    const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
-    bool v = (d2 * sf.inv_ac2 < 1.0) && (f.H[q] != 0.0);
+    const float ex = f.xf[q] - ax, ey = f.yf[q] - ay, ez = f.zf[q] - az;
+    const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+    bool v = d2 < lim;
     // even n: the antipodal partner is shared by two lanes, the lower one keeps it
     if (2 * s == n && a >= s) v = false;
     mask |= (unsigned long long)(v ? 1u : 0u) << (s - sc);
@@ -150,7 +190,7 @@ __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, c
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
 __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
-                                                               DeviceBatch b) {
+                                                               DeviceBatch b, int geom) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   extern __shared__ double lds[];
   const Fields f = carve(lds, b.cap);
@@ -158,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
   const double beta = ch.beta[0];
-  stage(sf, beta, b, f, s0, M);
+  stage(sf, beta, b, f, s0, M, geom);
 
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const int64_t p = (int64_t)s0 + item;
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, ax, ay, az);
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, item);
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -189,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
         const double ex = f.x[q] - ax, ey = f.y[q] - ay, ez = f.z[q] - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
+        if (!(u < 1.0)) continue;  // exact test (the mask is a superset); H_b = 0 adds nothing
         const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ra * f.inv[q];
         const double common = Ha * f.H[q] * hd_value<HD>(sf, ch, beta, u);
         const int sb = f.sp[q];
@@ -234,8 +275,8 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
   extern __shared__ double lds[];
   const int kCap = b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
-  // partner accumulators sit behind the species bytes, 8-byte aligned
-  double *gacc = lds + kNF * kCap + kCap / 8;
+  // partner accumulators sit behind the float copies and species bytes, 8-byte aligned
+  double *gacc = lds + kNF * kCap + (3 * kCap) / 2 + kCap / 8;
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
@@ -274,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     double gx = 0.0, gy = 0.0, gz = 0.0;
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, ax, ay, az);
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, item);
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -285,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
         const double ex = bx - ax, ey = by - ay, ez = bz - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
+        if (!(u < 1.0)) continue;  // exact test (the mask is a superset)
         const double inv_rb = f.inv[q];
         const double inv_ab = inv_ra * inv_rb;
         const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ab;
@@ -380,21 +422,21 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
 }
 
 template <int NSPEC, int NG, int NZ>
-void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, hipStream_t s) {
+void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geom, hipStream_t s) {
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = v2_lds_bytes(false, b.cap);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b);
+      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
   }
   if (ch.n_hd == 16)
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, geom);
   else if (ch.n_hd == 24)
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, geom);
   else
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b, geom);
 }
 template <int NSPEC, int NG, int NZ>
 void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int first, hipStream_t s) {
@@ -417,7 +459,8 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 }  // namespace
 
 size_t v2_lds_bytes(bool backward, int cap) {
-  return (size_t)cap * kNF * sizeof(double) + cap + (backward ? 3 * (size_t)cap * sizeof(double) : 0);
+  return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)cap * sizeof(float) + cap +
+         (backward ? 3 * (size_t)cap * sizeof(double) : 0);
 }
 
 #define TA_DISPATCH_V2(FN, ...)                                   \
@@ -441,11 +484,12 @@ size_t v2_lds_bytes(bool backward, int cap) {
   } while (0)
 
 // `ch` must describe ONE beta (nb == 1).
-void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz,
+void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           const DeviceBatch &b, hipStream_t s) {
   if (b.n_blk == 0) return;
   const int nspec = sf.n_elements;
-  TA_DISPATCH_V2(fwd_t, sf, ch, b, s);
+  const int geom = geometry ? 1 : 0;
+  TA_DISPATCH_V2(fwd_t, sf, ch, b, geom, s);
 }
 
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,

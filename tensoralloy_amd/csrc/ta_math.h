@@ -122,9 +122,27 @@ __device__ __forceinline__ double pow_int_m1(double base, int zi) {
   return r;
 }
 
+// Cross-lane sums. Inside a row of 16 lanes the data moves with DPP row
+// rotations on the VALU (no LDS traffic, unlike ds_bpermute-based shuffles):
+// after rotations by 8, 4, 2, 1 every lane of the row holds the row's total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_move<0x128>(v);  // row_ror:8
+  v += dpp_move<0x124>(v);  // row_ror:4
+  v += dpp_move<0x122>(v);  // row_ror:2
+  v += dpp_move<0x121>(v);  // row_ror:1
+  return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 

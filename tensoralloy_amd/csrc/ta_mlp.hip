@@ -18,6 +18,7 @@
 
 #include "ta_device.h"
 #include "ta_math.h"
+#include "ta_reduce.h"
 
 namespace ta {
 namespace {
@@ -31,8 +32,8 @@ constexpr int kRows = 16;
 // operands of 8 k-steps are fetched before their MFMAs so one L2 latency
 // covers 8 matrix instructions.
 template <typename Emit>
-__device__ __forceinline__ void tile_gemm(const double *X, int xstride, const double *W, int kp,
-                                          int np, const double *bias, int lane, int wave,
+__device__ __forceinline__ void tile_gemm(const double *X, int xstride, const double *W, int wstride,
+                                          int kp, int np, const double *bias, int lane, int wave,
                                           int nwaves, Emit emit) {
   const int m = lane & 15, kq = lane >> 4;
   for (int nt = wave; nt < np / 16; nt += nwaves) {
@@ -44,7 +45,7 @@ __device__ __forceinline__ void tile_gemm(const double *X, int xstride, const do
       double a[4], w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        w[j] = W[(size_t)(4 * (kk0 + j) + kq) * np + col];
+        w[j] = W[(size_t)(4 * (kk0 + j) + kq) * wstride + col];
         a[j] = X[m * xstride + 4 * (kk0 + j) + kq];
       }
 #pragma unroll
@@ -57,25 +58,50 @@ __device__ __forceinline__ void tile_gemm(const double *X, int xstride, const do
 
 constexpr int kMlpThreads = 256;
 
-__global__ __launch_bounds__(kMlpThreads) void mlp_kernel(MlpDev mlp, int act, int ndim,
+// `fused` != 0: the workgroup first assembles the descriptors of its 16 atoms
+// (16 lanes per atom) instead of reading them from G; G is still written.
+__global__ __launch_bounds__(kMlpThreads) void mlp_kernel(SFParams sf, DeviceBatch db, MlpDev mlp,
+                                                 int act, int ndim,
                                                  const int32_t *atoms, int n_atoms,
-                                                 const double *G, double *dEdG, double *eatom,
-                                                 double *scratch, int stride) {
+                                                 double *G, double *dEdG, double *eatom,
+                                                 double *scratch, int stride, int fused) {
   extern __shared__ double lds[];
   double *buf0 = lds, *buf1 = lds + kRows * stride;
+  double *wl = lds + 2 * kRows * stride;  // LDS copy of every layer's W and W^T (when it fits)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = kMlpThreads / 64;
   const int a0 = blockIdx.x * kRows;
   const int L = mlp.n_layers;
-  double *da = scratch + (size_t)blockIdx.x * L * kRows * stride;
+  // activation derivatives: LDS when the plan has room for them, else a global scratch slab
+  double *da = mlp.da_in_lds ? wl + mlp.lds_w_doubles
+                             : scratch + (size_t)blockIdx.x * L * kRows * stride;
 
+  if (mlp.w_in_lds) {
+    // one streaming copy of the host-prepared LDS image (all layers' W and W^T, rows padded so
+    // that the two k-rows a 32-lane LDS access touches fall on different banks)
+    const double2 *src = reinterpret_cast<const double2 *>(mlp.lds_image);
+    double2 *dst = reinterpret_cast<double2 *>(wl);
+    for (int idx = tid; idx < mlp.lds_w_doubles / 2; idx += kMlpThreads) dst[idx] = src[idx];
+  }
+  if (fused) {
+    const int row = tid >> 4, l = tid & 15;
+    const bool active = a0 + row < n_atoms;
+    const int64_t i = active ? atoms[a0 + row] : 0;
+    double *Gi = G + (size_t)i * ndim;
+    double *Gl = buf1 + row * stride;  // raw descriptors handed over through LDS
+    atom_descriptors<16>(sf, db, i, l, active, [&](int c, double v) {
+      Gi[c] = v;
+      Gl[c] = v;
+    });
+    __syncthreads();
+  }
   // layer-0 input: (optionally min-max scaled) descriptors, zero padded
   const int kp0 = mlp.layer[0].kp;
   for (int idx = tid; idx < kRows * kp0; idx += kMlpThreads) {
     const int row = idx / kp0, k = idx - row * kp0;
     double x = 0.0;
     if (a0 + row < n_atoms && k < ndim) {
-      x = G[(size_t)atoms[a0 + row] * ndim + k];
+      x = fused ? buf1[row * stride + k] : G[(size_t)atoms[a0 + row] * ndim + k];
       if (mlp.xlo) {
         const double den = mlp.xhi[k] - mlp.xlo[k];
         x = (den != 0.0) ? (mlp.xhi[k] - x) / den : 0.0;  // div_no_nan, atomic.py:195
@@ -89,7 +115,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_kernel(MlpDev mlp, int act, i
   for (int l = 0; l < L; ++l) {
     const MlpLayerDev ly = mlp.layer[l];
     double *dal = da + (size_t)l * kRows * stride;
-    tile_gemm(cur, stride, ly.w, ly.kp, ly.np, ly.b, lane, wave, nwaves, [&](int row, int col, double z) {
+    const double *Wsrc = mlp.w_in_lds ? wl + ly.lds_w : ly.w;
+    const int wstride = mlp.w_in_lds ? ly.ws : ly.np;
+    tile_gemm(cur, stride, Wsrc, wstride, ly.kp, ly.np, ly.b, lane, wave, nwaves, [&](int row, int col, double z) {
       double h = z, dh = 1.0;
       if (ly.act) activation_fn(act, z, h, dh);
       if (ly.res) h += cur[row * stride + col];  // convolutional.py:272-273
@@ -130,7 +158,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_kernel(MlpDev mlp, int act, i
     // delta_prev[16][kp] = dz[16][np] . W^T[np][kp]  (+ delta when skip)
     const bool res = ly.res != 0;
     double *dst = nxt;
-    tile_gemm(cur, stride, ly.wt, ly.np, ly.kp, nullptr, lane, wave, nwaves, [&](int row, int col, double z) {
+    const double *Wtsrc = mlp.w_in_lds ? wl + ly.lds_wt : ly.wt;
+    const int wtstride = mlp.w_in_lds ? ly.wts : ly.kp;
+    tile_gemm(cur, stride, Wtsrc, wtstride, ly.np, ly.kp, nullptr, lane, wave, nwaves, [&](int row, int col, double z) {
       const double skip = res ? dst[row * stride + col] : 0.0;
       dst[row * stride + col] = z + skip;
     });
@@ -159,15 +189,17 @@ size_t mlp_scratch_doubles(const MlpDev &mlp) {
   return (size_t)mlp.n_layers * kRows * (w + 2);
 }
 
-void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
-                     const DeviceBatch &b, double *scratch, hipStream_t s) {
+void launch_mlp_impl(const SFParams &sf, const MlpDev &mlp, int activation, int ndim,
+                     const int32_t *atoms, int n_atoms, const DeviceBatch &b, double *scratch,
+                     bool fused, hipStream_t s) {
   if (n_atoms == 0) return;
   const int w = mlp.max_np > mlp.max_kp ? mlp.max_np : mlp.max_kp;
   const int stride = w + 2;
-  const size_t lds = 2 * (size_t)kRows * stride * sizeof(double);
+  const size_t lds = (2 * (size_t)kRows * stride + (mlp.w_in_lds ? mlp.lds_w_doubles : 0) +
+                      (mlp.da_in_lds ? (size_t)mlp.n_layers * kRows * stride : 0)) * sizeof(double);
   const unsigned blocks = (unsigned)((n_atoms + kRows - 1) / kRows);
-  hipLaunchKernelGGL(mlp_kernel, dim3(blocks), dim3(kMlpThreads), lds, s, mlp, activation, ndim, atoms,
-                     n_atoms, b.G, b.dEdG, b.eatom, scratch, stride);
+  hipLaunchKernelGGL(mlp_kernel, dim3(blocks), dim3(kMlpThreads), lds, s, sf, b, mlp, activation,
+                     ndim, atoms, n_atoms, b.G, b.dEdG, b.eatom, scratch, stride, fused ? 1 : 0);
 }
 
 }  // namespace ta
