@@ -370,7 +370,7 @@ void upload_batch(ta_context *h) {
   h->G.ensure(N * D);
   h->dEdG.ensure(N * D);
   h->eatom.ensure(N);
-  h->g.ensure(3 * P);
+  h->g.ensure(4 * P);
   h->forces.ensure(3 * N);
   h->wat.ensure(9 * N);
   h->energy.ensure(F);

@@ -71,7 +71,7 @@ struct DeviceBatch {
   double *G = nullptr;      // [N][D]
   double *dEdG = nullptr;   // [N][D]
   double *eatom = nullptr;  // [N]
-  double *g = nullptr;      // [3][P]  dE/dD per directed pair
+  double *g = nullptr;      // [P][4]  dE/dD per directed pair (x, y, z, pad)
   double *forces = nullptr; // [N][3]
   double *wat = nullptr;    // [N][9] per-atom virial
   double *energy = nullptr; // [F]

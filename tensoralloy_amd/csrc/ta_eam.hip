@@ -231,9 +231,9 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
     gy += k * dy + u * m[1] + 2.0 * w * ly;
     gz += k * dz + u * m[2] + 2.0 * w * lz;
   }
-  b.g[p] = gx;
-  b.g[b.n_pairs + p] = gy;
-  b.g[2 * b.n_pairs + p] = gz;
+  b.g[4 * (size_t)p] = gx;
+  b.g[4 * (size_t)p + 1] = gy;
+  b.g[4 * (size_t)p + 2] = gz;
 }
 
 }  // namespace

@@ -216,9 +216,9 @@ __global__ __launch_bounds__(kBlock) void g2_backward_kernel(SFParams sf, Device
   double s;
   radial_backward(sf, b, i, sa, ra[3], ra[4], s);
   s *= ra[4];
-  b.g[p] = s * ra[0];
-  b.g[b.n_pairs + p] = s * ra[1];
-  b.g[2 * b.n_pairs + p] = s * ra[2];
+  b.g[4 * (size_t)p] = s * ra[0];
+  b.g[4 * (size_t)p + 1] = s * ra[1];
+  b.g[4 * (size_t)p + 2] = s * ra[2];
 }
 
 template <int NB, int NG, int NZ>
@@ -324,13 +324,13 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(SFParams sf, AngChunk 
     gy = fma(s, ay, gy);
     gz = fma(s, az, gz);
   } else {
-    gx += b.g[p];
-    gy += b.g[b.n_pairs + p];
-    gz += b.g[2 * b.n_pairs + p];
+    gx += b.g[4 * (size_t)p];
+    gy += b.g[4 * (size_t)p + 1];
+    gz += b.g[4 * (size_t)p + 2];
   }
-  b.g[p] = gx;
-  b.g[b.n_pairs + p] = gy;
-  b.g[2 * b.n_pairs + p] = gz;
+  b.g[4 * (size_t)p] = gx;
+  b.g[4 * (size_t)p + 1] = gy;
+  b.g[4 * (size_t)p + 2] = gz;
 }
 
 // --------------------------------------------------------------------------
@@ -344,7 +344,6 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
   const int lane = threadIdx.x & 15;
   const bool active = i < b.n_atoms;
-  const int64_t P = b.n_pairs;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int q0 = active ? b.pair_start[i] : 0, q1 = active ? b.pair_start[i + 1] : 0;
   // batches of 4 strided pairs: the 4 reverse indices, then all 4 x 9 operands, are in flight
@@ -367,11 +366,16 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
       d[k][0] = v0.x;
       d[k][1] = v0.y;
       d[k][2] = v1.x;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        gq[k][c] = b.g[c * P + q];
-        gr[k][c] = b.g[c * P + r[k]];
-      }
+      // g is stored as [P][4] (x, y, z, pad): one 32-byte sector per reverse-pair access
+      const double2 *gqp = reinterpret_cast<const double2 *>(b.g + 4 * (size_t)q);
+      const double2 *grp = reinterpret_cast<const double2 *>(b.g + 4 * (size_t)r[k]);
+      const double2 a0 = gqp[0], a1 = gqp[1], c0 = grp[0], c1 = grp[1];
+      gq[k][0] = a0.x;
+      gq[k][1] = a0.y;
+      gq[k][2] = a1.x;
+      gr[k][0] = c0.x;
+      gr[k][1] = c0.y;
+      gr[k][2] = c1.x;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

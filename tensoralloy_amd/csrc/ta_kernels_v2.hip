@@ -411,13 +411,13 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
       gy = fma(s, f.y[item], gy);
       gz = fma(s, f.z[item], gz);
     } else {
-      gx += b.g[p];
-      gy += b.g[b.n_pairs + p];
-      gz += b.g[2 * b.n_pairs + p];
+      gx += b.g[4 * (size_t)p];
+      gy += b.g[4 * (size_t)p + 1];
+      gz += b.g[4 * (size_t)p + 2];
     }
-    b.g[p] = gx;
-    b.g[b.n_pairs + p] = gy;
-    b.g[2 * b.n_pairs + p] = gz;
+    b.g[4 * (size_t)p] = gx;
+    b.g[4 * (size_t)p + 1] = gy;
+    b.g[4 * (size_t)p + 2] = gz;
   }
 }
 
