@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""
+Parity + throughput of every BASELINE.json config on one MI355X (not the driver's bench line:
+that is bench.py). Prints one JSON object; run through gpurun and keep the output under profiles/.
+
+  C1  snap_Ni_id11.extxyz, G2-only rc=6.0, 1 hidden layer, energy only
+  C2  4000-atom Ni, G2+G4 rc=6.5, 2x64 MLP, E+F+virial                (= bench.py)
+  C3  Ni-Mo binary alloy (3920 atoms, 8:2), cross-element G2/G4, 2x128 MLP, E+F+virial
+  C4  EAM (zjw04) and ADP (zjw04 + mishinh) for 4000-atom Ni, E+F+virial
+  C5  batch of independent 4000-atom frames on one GPU (the per-GPU share of the 512-frame job)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bench import ni_frame, ni_model, oracle_sfmodel, host_cores  # noqa: E402
+from tensoralloy_amd import (Atoms, AtomicNN, Engine, SymmetryFunction, UniversalTransformer,  # noqa: E402
+                             _lib)
+from tensoralloy_amd.eam import AdpNN, EamAlloyNN  # noqa: E402
+from tensoralloy_amd.io import read_extxyz  # noqa: E402
+
+WANT = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
+
+
+def timeit(eng, want, steps=30, warmup=3):
+    total_ms, slots = eng.time_compute(want, warmup, steps)
+    return total_ms / steps, {k: v for k, v in slots.items() if v > 0}
+
+
+def sf_parity(nn, atoms, res):
+    from oracle import csf
+    m = oracle_sfmodel(nn)
+    if nn._minmax_scale:
+        m.minmax = nn.minmax
+    prep = csf.prepare(m, atoms.get_chemical_symbols(), atoms.positions,
+                       np.asarray(atoms.get_cell(complete=True)), atoms.pbc)
+    t0 = time.perf_counter()
+    ref = csf.run(m, prep, True, host_cores(), csf.make_cmodel(m))
+    dt = time.perf_counter() - t0
+    out = {"dE_eV": abs(ref["energy"] - res["energy"]), "cpu_oracle_s": dt}
+    if "forces" in res:
+        out["dF_max"] = float(np.abs(ref["forces"] - res["forces"]).max())
+        out["dW_max"] = float(np.abs(ref["virial"] - res["virial"]).max())
+    return out
+
+
+def nimo_frame(seed=611):
+    """7x7x8 conventional Ni4Mo-like cells: fcc sites, 2 of every 10 atoms Mo (3920 atoms)."""
+    a = 3.6
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
+    rep = (7, 7, 20)
+    pts = np.array([base + np.array([x, y, z]) * a for x in range(rep[0]) for y in range(rep[1])
+                    for z in range(rep[2])]).reshape(-1, 3)
+    rng = np.random.RandomState(seed)
+    pts = pts + rng.normal(0.0, 0.05, pts.shape)
+    syms = np.array(["Ni"] * len(pts), dtype=object)
+    syms[rng.permutation(len(pts))[: len(pts) // 5]] = "Mo"
+    return Atoms(symbols=list(syms), positions=pts, cell=np.diag([a * r for r in rep]), pbc=True)
+
+
+def main():
+    _lib.build()
+    out = {}
+
+    # ---- C1
+    atoms = read_extxyz(os.path.join(ROOT, "tests", "golden", "snap_Ni_id11.extxyz"))[0]
+    clf = UniversalTransformer(["Ni"], rcut=6.0, angular=False)
+    nn = AtomicNN(["Ni"], SymmetryFunction(["Ni"]), hidden_sizes=[64], activation="softplus",
+                  minmax_scale=False, export_properties=("energy",))
+    nn.attach_transformer(clf)
+    nn.initialize(seed=611)
+    with Engine(nn) as eng:
+        want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC
+        r = eng.evaluate([atoms], want=want)[0]
+        ms, slots = timeit(eng, want, steps=100)
+        out["C1"] = {"atoms": len(atoms), "pairs": int(eng.info.n_pairs), "ms_per_eval": ms,
+                     "atom_steps_per_s": len(atoms) / ms * 1e3, "parity": sf_parity(nn, atoms, r),
+                     "note": "6-atom cell: launch-latency bound by construction"}
+
+    # ---- C2 / C5
+    nn = ni_model()
+    with Engine(nn) as eng:
+        atoms = ni_frame(611)
+        r = eng.evaluate([atoms])[0]
+        ms, slots = timeit(eng, WANT)
+        out["C2"] = {"atoms": len(atoms), "pairs": int(eng.info.n_pairs),
+                     "triples": int(eng.info.n_triples), "ms_per_eval": ms,
+                     "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+                     "parity": sf_parity(nn, atoms, r)}
+        frames = [ni_frame(611 + k) for k in range(64)]
+        eng.set_frames(frames)
+        ms, slots = timeit(eng, WANT, steps=5, warmup=1)
+        out["C5_per_gpu_share"] = {"frames": 64, "atoms": 64 * 4000, "ms_per_batch": ms,
+                                   "atom_steps_per_s": 64 * 4000 / ms * 1e3, "kernel_ms": slots}
+
+    # ---- C3
+    atoms = nimo_frame()
+    clf = UniversalTransformer(["Ni", "Mo"], rcut=6.5, angular=True)
+    nn = AtomicNN(["Ni", "Mo"], SymmetryFunction(["Ni", "Mo"]), hidden_sizes=[128, 128],
+                  activation="softplus", minmax_scale=False,
+                  export_properties=("energy", "forces", "stress"))
+    nn.attach_transformer(clf)
+    nn.initialize(seed=611)
+    with Engine(nn) as eng:
+        r = eng.evaluate([atoms])[0]
+        ms, slots = timeit(eng, WANT)
+        out["C3"] = {"atoms": len(atoms), "pairs": int(eng.info.n_pairs),
+                     "triples": int(eng.info.n_triples), "D": nn.ndim(), "ms_per_eval": ms,
+                     "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+                     "parity": sf_parity(nn, atoms, r)}
+
+    # ---- C4
+    from oracle.eam import EamModel, evaluate as eam_eval
+    atoms = ni_frame(611)
+    for tag, cls, pots in (("C4_eam", EamAlloyNN, "zjw04"),
+                           ("C4_adp", AdpNN, {"Ni": {"rho": "zjw04", "embed": "zjw04"},
+                                              "NiNi": {"phi": "zjw04", "dipole": "mishinh",
+                                                       "quadrupole": "mishinh"}})):
+        for rc in (6.0, 6.5):
+            nn = cls(["Ni"], custom_potentials=pots)
+            nn.attach_transformer(UniversalTransformer(["Ni"], rcut=rc))
+            with Engine(nn) as eng:
+                r = eng.evaluate([atoms])[0]
+                ms, slots = timeit(eng, WANT, steps=100)
+                adp = {"NiNi": nn.pair_parameters("NiNi")} if cls is AdpNN else None
+                o = eam_eval(EamModel(["Ni"], rc, adp=adp), atoms.get_chemical_symbols(),
+                             atoms.positions, np.asarray(atoms.get_cell()), atoms.pbc)
+                out[f"{tag}_rc{rc}"] = {
+                    "atoms": len(atoms), "pairs": int(eng.info.n_pairs), "ms_per_eval": ms,
+                    "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+                    "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
+                               "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
+                               "dW_max": float(np.abs(o["virial"] - r["virial"]).max())}}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
