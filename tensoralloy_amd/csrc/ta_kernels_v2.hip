@@ -38,6 +38,7 @@ namespace {
 
 constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
 constexpr int kNF = 7;  // x y z r2 inv_r H G
+constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
   int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
@@ -49,7 +50,9 @@ __device__ __forceinline__ int radial_term2(int center, int other) {
 
 struct Fields {
   double *x, *y, *z, *r2, *inv, *H, *G;
-  float *xf, *yf, *zf;  // single-precision copies for the candidate scan
+  float *xf, *yf, *zf;  // single-precision ring copies for the candidate scan: the n neighbours of
+                        // a centre are stored twice in a row (2 * base + k and + n), so partner
+                        // a + s needs no wrap-around arithmetic
   unsigned char *sp;
 };
 
@@ -63,9 +66,9 @@ __device__ __forceinline__ Fields carve(double *lds, int cap) {
   f.H = f.inv + cap;
   f.G = f.H + cap;
   f.xf = reinterpret_cast<float *>(f.G + cap);
-  f.yf = f.xf + cap;
-  f.zf = f.yf + cap;
-  f.sp = reinterpret_cast<unsigned char *>(f.zf + cap);
+  f.yf = f.xf + (2 * cap + kRingPad);
+  f.zf = f.yf + (2 * cap + kRingPad);
+  f.sp = reinterpret_cast<unsigned char *>(f.zf + (2 * cap + kRingPad));
   return f;
 }
 
@@ -139,9 +142,14 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
     f.x[item] = v0.x;
     f.y[item] = v0.y;
     f.z[item] = v1.x;
-    f.xf[item] = (float)v0.x;
-    f.yf[item] = (float)v0.y;
-    f.zf[item] = (float)v1.x;
+    {
+      const int ci = b.pair_i[s0 + item];
+      const int cbase = b.pair_start[ci] - s0, cn = b.pair_start[ci + 1] - b.pair_start[ci];
+      const int k0 = 2 * cbase + (item - cbase);
+      f.xf[k0] = f.xf[k0 + cn] = (float)v0.x;
+      f.yf[k0] = f.yf[k0 + cn] = (float)v0.y;
+      f.zf[k0] = f.zf[k0 + cn] = (float)v1.x;
+    }
     f.r2[item] = v1.y;
     f.inv[item] = v2.x;
     const double u = v1.y * sf.inv_ac2;
@@ -161,28 +169,34 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
 }
 
 // Candidate mask of the partners a + s, s in [sc, sc + 63]. The scan runs in
-// single precision (half the issue cost of fp64, 4-byte LDS reads) with a
-// relative margin far above the fp32 rounding of r_jk^2; the double-precision
+// single precision (half the issue cost of fp64, 4-byte LDS reads at immediate
+// offsets from the lane's ring position, fully unrolled in groups of 16) with
+// a relative margin far above the fp32 rounding of r_jk^2; the double-precision
 // test u < 1 is repeated on every candidate before it contributes, so the mask
 // only has to be a superset.
 __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, const Fields &f,
-                                                           int base, int n, int a, int sc, int smax,
-                                                           int item) {
-  unsigned long long mask = 0ull;
-  const int send = (smax < sc + 63) ? smax : sc + 63;
-  const float ax = f.xf[item], ay = f.yf[item], az = f.zf[item];
+                                                           int base, int n, int a, int sc, int smax) {
+  const int ring = 2 * base + a;
+  const float ax = f.xf[ring], ay = f.yf[ring], az = f.zf[ring];
   const float lim = (float)(sf.acut * sf.acut) * 1.0001f;
-  for (int s = sc; s <= send; ++s) {
-    int bl = a + s;
-    if (bl >= n) bl -= n;
-    const int q = base + bl;
-    const float ex = f.xf[q] - ax, ey = f.yf[q] - ay, ez = f.zf[q] - az;
-    const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
-    bool v = d2 < lim;
-    // even n: the antipodal partner is shared by two lanes, the lower one keeps it
-    if (2 * s == n && a >= s) v = false;
-    mask |= (unsigned long long)(v ? 1u : 0u) << (s - sc);
+  unsigned long long mask = 0ull;
+  const int count = smax - sc + 1;  // candidates wanted in this block of 64 (may exceed 64)
+  for (int g = 0; g < 4 && 16 * g < count; ++g) {
+    const float *px = f.xf + ring + sc + 16 * g, *py = f.yf + ring + sc + 16 * g,
+                *pz = f.zf + ring + sc + 16 * g;
+    unsigned m = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float ex = px[k] - ax, ey = py[k] - ay, ez = pz[k] - az;
+      const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+      m |= (d2 < lim) ? (1u << k) : 0u;
+    }
+    mask |= (unsigned long long)m << (16 * g);
   }
+  if (count < 64) mask &= (1ull << count) - 1ull;
+  // even n: the antipodal partner is shared by two lanes, the lower one keeps it
+  const int half = n >> 1;
+  if (!(n & 1) && a >= half && half >= sc && half < sc + 64) mask &= ~(1ull << (half - sc));
   return mask;
 }
 
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, item);
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax);
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
   const int kCap = b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
   // partner accumulators sit behind the float copies and species bytes, 8-byte aligned
-  double *gacc = lds + kNF * kCap + (3 * kCap) / 2 + kCap / 8;
+  double *gacc = lds + kNF * kCap + (3 * (2 * kCap + kRingPad)) / 2 + kCap / 8;
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     double gx = 0.0, gy = 0.0, gz = 0.0;
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax, item);
+      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax);
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -459,7 +473,7 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 }  // namespace
 
 size_t v2_lds_bytes(bool backward, int cap) {
-  return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)cap * sizeof(float) + cap +
+  return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
          (backward ? 3 * (size_t)cap * sizeof(double) : 0);
 }
 
