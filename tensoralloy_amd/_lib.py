@@ -19,7 +19,7 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_mlp.hip", "ta_eam.hip",
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_mlp.hip", "ta_eam.hip",
            "ta_neighbor.cpp"]
 
 TA_OK = 0

@@ -83,6 +83,7 @@ struct ta_context {
   std::vector<ChunkPlan> chunks;     // first-generation kernels: up to 2 betas per launch
   std::vector<ChunkPlan> chunks_v2;  // second-generation kernels: one beta per launch
   bool use_v2 = false;
+  bool use_v3 = false;               // wavefront-balanced kernels (subset of the v2 conditions)
   ta::MlpDev mlp[ta::kMaxElements];
   std::vector<void *> model_allocs;
   ta::EamModel *eam = nullptr;
@@ -424,7 +425,10 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       if (h->use_v2) {
         bool geometry = true;
         for (const ChunkPlan &cp : h->chunks_v2) {
-          launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
+          if (h->use_v3)
+            launch_g4_forward_v3(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
+          else
+            launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
           geometry = false;
         }
       } else
@@ -458,7 +462,10 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
         bool first = true;
         if (h->use_v2)
           for (const ChunkPlan &cp : h->chunks_v2) {
-            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+            if (h->use_v3)
+              launch_backward_v3(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+            else
+              launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
             first = false;
           }
         else
@@ -635,17 +642,23 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
                 h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
     const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
     h->db.cap = cap;
+    // wavefront-balanced variant: measured no faster than the per-lane kernels on MI355X
+    // (profiles/r01_tuning_notes.md), kept selectable with TA_USE_V3=1
+    h->use_v3 = h->use_v2 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
+                std::getenv("TA_USE_V3")[0] == '1';
     std::vector<int32_t> blk;
     if (h->use_v2) {
       blk.push_back(0);
-      int32_t load = 0;
+      int32_t load = 0, ncent = 0;
       for (size_t i = 0; i < N; ++i) {
         const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
-        if (load + cnt > cap) {
+        if (load + cnt > cap || ncent >= ta::kMaxCentersPerBlock) {
           blk.push_back((int32_t)i);
           load = 0;
+          ncent = 0;
         }
         load += cnt;
+        ++ncent;
       }
       if (N) blk.push_back((int32_t)N);
       h->db.n_blk = (int)blk.size() - 1;

@@ -15,6 +15,7 @@ constexpr int kRecDoubles = 8;    // pair record = 64 bytes
 constexpr int kMaxLayers = 8;
 constexpr int kCapMin = 192;      // pair records one v2 workgroup (one wavefront) stages in LDS
 constexpr int kCapMax = 1024;
+constexpr int kMaxCentersPerBlock = 16;  // v3 kernels keep per-centre weight tables in LDS
 constexpr int kMaxHd = 24;        // coefficients of the Hd(u) expansion
 
 // Symmetry-function constants, passed by value to every kernel.
@@ -120,6 +121,13 @@ size_t v2_lds_bytes(bool backward, int cap);
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           const DeviceBatch &b, hipStream_t s);
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
+                        const DeviceBatch &b, hipStream_t s);
+
+// third-generation (wavefront-balanced) angular kernels (ta_kernels_v3.hip): cap <= 256,
+// at most kMaxCentersPerBlock centres per workgroup
+void launch_g4_forward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
+                          const DeviceBatch &b, hipStream_t s);
+void launch_backward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
 
 }  // namespace ta
