@@ -95,6 +95,7 @@ struct ta_context {
 
   DevBuf<double> pos, cells, rec, part4, G, dEdG, eatom, g, forces, wat, energy, virial, benergy,
       mlp_scratch;
+  DevBuf<unsigned long long> masks;
   DevBuf<int32_t> species, frame_of_atom, atom_start, pair_start, seg_start, pair_i, pair_j,
       pair_shift, pair_rev, elem_atoms, blk_center;
 
@@ -367,7 +368,11 @@ void upload_batch(ta_context *h) {
 
   const int D = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 1;
   h->rec.ensure(P * kRecDoubles);
-  if (h->kind == TA_MODEL_SF_MLP && h->sf.angular) h->part4.ensure((size_t)nel * h->sf.n_ang * P);
+  if (h->kind == TA_MODEL_SF_MLP && h->sf.angular) {
+    h->part4.ensure((size_t)nel * h->sf.n_ang * P);
+    // one 64-bit candidate mask per pair and per block of 64 rotation steps (n/2 steps in all)
+    h->masks.ensure((size_t)((hp.nnl_max / 2 + 63) / 64 + 1) * P);
+  }
   h->G.ensure(N * D);
   h->dEdG.ensure(N * D);
   h->eatom.ensure(N);
@@ -388,6 +393,7 @@ void upload_batch(ta_context *h) {
   db.pair_rev = h->pair_rev.ptr;
   db.rec = h->rec.ptr;
   db.part4 = h->part4.ptr;
+  db.masks = h->masks.ptr;
   db.G = h->G.ptr;
   db.dEdG = h->dEdG.ptr;
   db.eatom = h->eatom.ptr;
@@ -598,6 +604,7 @@ int ta_destroy(ta_handle h) {
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release(); h->elem_atoms.release();
   h->blk_center.release();
+  h->masks.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -69,6 +69,7 @@ struct DeviceBatch {
   // work buffers
   double *rec = nullptr;    // [P][8]  {Dx,Dy,Dz,r2,1/r,H0,H1,H2}
   double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
+  unsigned long long *masks = nullptr;  // [ceil(nnl_max/128)][P] candidate masks, forward -> backward
   double *G = nullptr;      // [N][D]
   double *dEdG = nullptr;   // [N][D]
   double *eatom = nullptr;  // [N]

@@ -234,6 +234,8 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
       unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax);
+      // the candidate mask is geometry only: keep it for the backward kernel
+      if (b.masks) b.masks[(size_t)(sc >> 6) * b.n_pairs + p] = mask;
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     double gx = 0.0, gy = 0.0, gz = 0.0;
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax);
+      unsigned long long mask = b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
+                                        : partner_mask(sf, f, base, n, a, sc, smax);
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
