@@ -177,10 +177,16 @@ def main():
     if rank == 0:
         # ---- per-kernel durations with HIP events on the engine's stream ----
         ev_total_ms, slots = eng.time_compute(want, 2, max(5, min(args.steps, 20)))
-        # dominant kernel = backward sweep over ordered triples: SURVEY §8(d) prices one
-        # pass over the packed records at 32 B / pair + 60 B / triple
-        bwd_bytes = 32.0 * P + 60.0 * T
-        bwd_ms = slots["backward"]
+        # dominant kernel. SURVEY §8(d) prices one pass over the packed records at 32 B / pair +
+        # 60 B / triple; the fused kernel makes both passes (descriptors, then dE/dD) in one
+        # launch, the separate backward kernel one.
+        if slots.get("fused", 0.0) > 0:
+            dom_name, dom_key, passes = "sf_fused_kernel<1,2,2,16,true>", "sf_fused_kernel", 2.0
+            bwd_ms = slots["fused"]
+        else:
+            dom_name, dom_key, passes = "backward_v2_kernel<1,2,2,16,true>", "backward_v2_kernel", 1.0
+            bwd_ms = slots["backward"]
+        bwd_bytes = passes * (32.0 * P + 60.0 * T)
         achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
         eval_bytes = 2.0 * (32.0 * P + 60.0 * T) + n_atoms * 8.0 * (3 * D + 4) + 72.0 * fpg
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this
@@ -192,11 +198,11 @@ def main():
             try:
                 with open(tpath) as fp:
                     for name, rec in json.load(fp).items():
-                        if name.startswith("backward_v2_kernel"):
+                        if name.startswith(dom_key):
                             traffic = rec["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "backward_v2_kernel<1,2,2,16,true>", "achieved": achieved,
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
                     "algorithmic_bytes_per_launch": bwd_bytes,

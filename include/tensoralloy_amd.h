@@ -118,12 +118,13 @@ typedef struct {
 } ta_batch_info;
 
 /* number of kernel-timing slots filled by ta_time_compute */
-#define TA_N_KERNEL_SLOTS 8
+#define TA_N_KERNEL_SLOTS 10
 /* slot ids */
 enum {
   TA_K_PAIR_GEOMETRY = 0, TA_K_G4_FORWARD = 1, TA_K_DESCRIPTOR_REDUCE = 2,
   TA_K_MLP = 3, TA_K_BACKWARD = 4, TA_K_FORCE_GATHER = 5, TA_K_FRAME_REDUCE = 6,
-  TA_K_EAM = 7
+  TA_K_EAM = 7,
+  TA_K_FUSED = 8 /* geometry + descriptors + MLP + dE/dD in one launch; slot 9 reserved */
 };
 
 int ta_device_count(void);

@@ -19,7 +19,7 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_mlp.hip", "ta_eam.hip",
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip",
            "ta_neighbor.cpp"]
 
 TA_OK = 0
@@ -29,9 +29,9 @@ TA_MODEL_SF_MLP, TA_MODEL_EAM_ALLOY, TA_MODEL_EAM_ADP = 1, 2, 3
 TA_CUTOFF = {"cosine": 0, "polynomial": 1}
 TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
           "sigmoid": 5, "softsign": 6, "elu": 7}
-TA_N_KERNEL_SLOTS = 8
+TA_N_KERNEL_SLOTS = 10
 KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
-                "force_gather", "frame_reduce", "eam"]
+                "force_gather", "frame_reduce", "eam", "fused", "reserved"]
 
 # every symbol include/tensoralloy_amd.h declares
 EXPORTED_SYMBOLS = [

@@ -15,9 +15,8 @@
 
 namespace ta {
 size_t mlp_scratch_doubles(const MlpDev &mlp);
-void launch_mlp_impl(const SFParams &sf, const MlpDev &mlp, int activation, int ndim,
-                     const int32_t *atoms, int n_atoms, const DeviceBatch &b, double *scratch,
-                     bool fused, hipStream_t s);
+void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
+                     const DeviceBatch &b, double *scratch, hipStream_t s);
 // EAM / ADP (ta_eam.hip)
 struct EamModel;
 EamModel *eam_create(const ta_model_desc *m, std::string &err);
@@ -84,6 +83,9 @@ struct ta_context {
   std::vector<ChunkPlan> chunks_v2;  // second-generation kernels: one beta per launch
   bool use_v2 = false;
   bool use_v3 = false;               // wavefront-balanced kernels (subset of the v2 conditions)
+  bool use_fused = false;            // one-launch per-centre kernel (subset of the v2 conditions)
+  ta::FusedPlan fplan;
+  ta::MlpDev *mlp_dev = nullptr;     // device copy of mlp[0..n_elements)
   ta::MlpDev mlp[ta::kMaxElements];
   std::vector<void *> model_allocs;
   ta::EamModel *eam = nullptr;
@@ -236,6 +238,7 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
         }
   }
   const int n_aterms = m->angular ? nel * (nel + 1) / 2 : 0;
+  (void)0;
   sf.ndim = sf.n_radial_dim + n_aterms * sf.n_ang;
   h->rmax = std::max(sf.rcut, sf.acut);
 
@@ -249,7 +252,6 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
   const double *wsrc = m->weights;
   for (int el = 0; el < nel; ++el) {
     MlpDev &md = h->mlp[el];
-    const double *wsrc_begin = wsrc;
     const int L = m->n_layers[el];
     if (L < 1 || L > kMaxLayers) throw std::domain_error("MLP depth out of range (1..8 layers)");
     if (sizes[0] != sf.ndim)
@@ -285,49 +287,6 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
       md.max_np = std::max(md.max_np, ly.np);
       md.max_kp = std::max(md.max_kp, ly.kp);
     }
-    {
-      // LDS plan: row stride = width (+16 when a multiple of 32) so that k-rows r and r+1 of a
-      // 32-lane ds_read_b64 group land on disjoint banks
-      int off = 0;
-      for (int l = 0; l < L; ++l) {
-        MlpLayerDev &ly = md.layer[l];
-        ly.ws = ly.np + ((ly.np % 32 == 0) ? 16 : 0);
-        ly.wts = ly.kp + ((ly.kp % 32 == 0) ? 16 : 0);
-        ly.lds_w = off;
-        off += ly.kp * ly.ws;
-        ly.lds_wt = off;
-        off += ly.np * ly.wts;
-      }
-      off += off & 1;
-      const int w = std::max(md.max_np, md.max_kp);
-      const size_t act_doubles = 2 * 16 * (size_t)(w + 2), da_doubles = (size_t)L * 16 * (w + 2);
-      md.lds_w_doubles = off;
-      md.w_in_lds = ((size_t)off + act_doubles) * sizeof(double) <= 150 * 1024 ? 1 : 0;
-      // measured: streaming the weights from L2 (small LDS footprint, more workgroups per CU)
-      // beats the LDS-resident copy; TA_MLP_WLDS=1 re-enables it (tuning switch)
-      if (!(std::getenv("TA_MLP_WLDS") && std::getenv("TA_MLP_WLDS")[0] == '1')) md.w_in_lds = 0;
-      if (!md.w_in_lds) md.da_in_lds = 0;
-      md.da_in_lds = (md.w_in_lds && ((size_t)off + act_doubles + da_doubles) * sizeof(double) <= 150 * 1024) ? 1 : 0;
-      if (!md.w_in_lds) md.da_in_lds = 0;
-      if (md.w_in_lds) {
-        std::vector<double> image((size_t)off, 0.0);
-        const double *src = m->weights;
-        // walk this element's layers again to fill the padded image
-        const double *wp = wsrc_begin;
-        for (int l = 0; l < L; ++l) {
-          MlpLayerDev &ly = md.layer[l];
-          for (int k = 0; k < ly.k; ++k)
-            for (int n = 0; n < ly.n; ++n) {
-              const double v = wp[(size_t)k * ly.n + n];
-              image[(size_t)ly.lds_w + (size_t)k * ly.ws + n] = v;
-              image[(size_t)ly.lds_wt + (size_t)n * ly.wts + k] = v;
-            }
-          wp += (size_t)ly.k * ly.n + ly.n;
-        }
-        (void)src;
-        md.lds_image = upload(h, image);
-      }
-    }
     if (m->minmax_scale) {
       if (!m->xlo || !m->xhi) throw std::invalid_argument("minmax_scale set but xlo/xhi missing");
       std::vector<double> lo(m->xlo + (size_t)el * sf.ndim, m->xlo + (size_t)(el + 1) * sf.ndim);
@@ -336,6 +295,10 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
       md.xhi = upload(h, hi);
     }
     sizes += L + 1;
+  }
+  {
+    std::vector<MlpDev> all(h->mlp, h->mlp + nel);
+    h->mlp_dev = upload(h, all);
   }
 }
 
@@ -418,7 +381,19 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   };
   bool used[TA_N_KERNEL_SLOTS] = {false};
 
-  if (h->kind == TA_MODEL_SF_MLP) {
+  if (h->kind == TA_MODEL_SF_MLP && h->use_fused) {
+    begin(TA_K_FUSED);
+    launch_sf_fused(h->sf, h->chunks_v2[0].ch, h->chunks_v2[0].ng, h->chunks_v2[0].nz, db, h->fplan,
+                    h->mlp_dev, h->activation, need_forces, h->mlp_scratch.ptr, s);
+    end(TA_K_FUSED);
+    used[TA_K_FUSED] = true;
+    if (need_forces) {
+      begin(TA_K_FORCE_GATHER);
+      launch_force_gather(h->sf, db, s);
+      end(TA_K_FORCE_GATHER);
+      used[TA_K_FORCE_GATHER] = true;
+    }
+  } else if (h->kind == TA_MODEL_SF_MLP) {
     if (!h->use_v2) {
       // second-generation forward kernels compute the pair geometry while staging
       begin(TA_K_PAIR_GEOMETRY);
@@ -442,23 +417,16 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       end(TA_K_G4_FORWARD);
       used[TA_K_G4_FORWARD] = true;
     }
-    // the descriptor assembly (G2 + per-pair G4 partial sums -> G) can be the MLP kernel's prologue
-    // when TA_MLP_FUSED=1 (tuning switch); by default it is its own kernel
     h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
-    // measured on MI355X: the separate wave-per-atom reduce kernel is faster, both for one
-    // frame and in batches (profiles/r01_tuning_notes.md)
-    static const bool fused = std::getenv("TA_MLP_FUSED") && std::getenv("TA_MLP_FUSED")[0] == '1';
-    if (!fused) {
-      begin(TA_K_DESCRIPTOR_REDUCE);
-      launch_descriptor_reduce(h->sf, db, s);
-      end(TA_K_DESCRIPTOR_REDUCE);
-      used[TA_K_DESCRIPTOR_REDUCE] = true;
-    }
+    begin(TA_K_DESCRIPTOR_REDUCE);
+    launch_descriptor_reduce(h->sf, db, s);
+    end(TA_K_DESCRIPTOR_REDUCE);
+    used[TA_K_DESCRIPTOR_REDUCE] = true;
     begin(TA_K_MLP);
     for (int el = 0; el < h->n_elements; ++el) {
       const int n_el = db.elem_start[el + 1] - db.elem_start[el];
-      launch_mlp_impl(h->sf, h->mlp[el], h->activation, h->sf.ndim,
-                      db.elem_atoms + db.elem_start[el], n_el, db, h->mlp_scratch.ptr, fused, s);
+      launch_mlp_impl(h->mlp[el], h->activation, h->sf.ndim, db.elem_atoms + db.elem_start[el], n_el,
+                      db, h->mlp_scratch.ptr, s);
     }
     end(TA_K_MLP);
     used[TA_K_MLP] = true;
@@ -651,6 +619,19 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     h->db.cap = cap;
     // wavefront-balanced variant: measured no faster than the per-lane kernels on MI355X
     // (profiles/r01_tuning_notes.md), kept selectable with TA_USE_V3=1
+    {
+      int stride_max = 0;
+      for (int e = 0; e < h->n_elements; ++e) {
+        const int w = std::max(h->mlp[e].max_np, h->mlp[e].max_kp);
+        stride_max = std::max(stride_max, w + 2);
+      }
+      // one-launch variant: measured on MI355X at parity for one frame and slower in batches
+      // (every workgroup pays a 16-row MFMA tile for its ~2 centres), so it is opt-in
+      h->use_fused = h->use_v2 && h->chunks_v2.size() == 1 && h->hp.nnl_max <= 128 &&
+                     std::getenv("TA_USE_FUSED") != nullptr && std::getenv("TA_USE_FUSED")[0] == '1' &&
+                     ta::fused_plan(h->sf, h->n_elements, h->chunks_v2[0].ng, h->chunks_v2[0].nz, cap,
+                                    stride_max, h->fplan);
+    }
     h->use_v3 = h->use_v2 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
                 std::getenv("TA_USE_V3")[0] == '1';
     std::vector<int32_t> blk;
@@ -696,6 +677,7 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
         const size_t tiles = (size_t)(h->db.elem_start[e + 1] - h->db.elem_start[e] + 15) / 16;
         need = std::max(need, tiles * ta::mlp_scratch_doubles(h->mlp[e]));
       }
+      if (h->use_fused) need = std::max(need, ta::fused_scratch_doubles(h->fplan, h->db.n_blk));
       h->mlp_scratch.ensure(need);
     } else {
       ta::eam_ensure(h->eam, h->db);

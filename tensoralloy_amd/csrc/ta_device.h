@@ -90,18 +90,12 @@ struct MlpLayerDev {
   double *b;       // [np]
   int act;         // apply activation
   int res;         // resnet skip
-  int ws, wts;     // LDS row strides of W and W^T (padded against bank conflicts)
-  int lds_w, lds_wt;  // offsets (doubles) of the LDS copies
 };
 struct MlpDev {
   int n_layers = 0;  // incl. output layer
   MlpLayerDev layer[kMaxLayers];
   double *xlo = nullptr, *xhi = nullptr;  // [D] or null
   int max_np = 0, max_kp = 0;
-  int w_in_lds = 0;        // all layers' W and W^T fit in LDS beside the activations
-  int da_in_lds = 0;       // ... and so do the activation derivatives
-  int lds_w_doubles = 0;   // size of the LDS image (even)
-  double *lds_image = nullptr;  // device copy of the padded W / W^T image
 };
 
 void launch_pair_geometry(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
@@ -123,6 +117,23 @@ void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz
                           const DeviceBatch &b, hipStream_t s);
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
+
+// fused per-centre kernel (ta_fused.hip): geometry -> descriptors -> MLP -> dE/dD in one launch
+struct FusedPlan {  // LDS offsets in doubles, computed on the host
+  int cap;
+  int npart;      // per-item partial sums: NSPEC*NG*NZ + n_rad
+  int stride;     // MLP row stride
+  int off_tab;    // gtab[16][ndim], dtab[16][ndim], segs (ints)
+  int off_b;      // phase-dependent region: P / buf1 / gacc
+  int off_buf0;
+  int total;      // doubles
+};
+bool fused_plan(const SFParams &sf, int nspec, int ng, int nz, int cap, int mlp_stride_max,
+                FusedPlan &pl);
+size_t fused_scratch_doubles(const FusedPlan &pl, int n_blk);
+void launch_sf_fused(const SFParams &sf, const AngChunk &ch, int ng, int nz, const DeviceBatch &b,
+                     const FusedPlan &pl, const MlpDev *mlps, int act, bool want_forces,
+                     double *scratch, hipStream_t s);
 
 // third-generation (wavefront-balanced) angular kernels (ta_kernels_v3.hip): cap <= 256,
 // at most kMaxCentersPerBlock centres per workgroup

@@ -147,3 +147,24 @@ def test_mid_neighbour_count_three_passes(lib, monkeypatch):
     monkeypatch.setenv("TA_USE_V3", "1")
     nn = make_nn(["Ni"], 8.0, True, [16], sf_kwargs=dict(eta=[0.5, 4.0]))
     _compare(nn, [fcc(rep=(2, 2, 2), a=3.5)])
+
+
+def test_fused_one_launch_kernel(lib, monkeypatch):
+    """TA_USE_FUSED runs geometry + descriptors + MLP + dE/dD in one launch (opt-in variant)."""
+    monkeypatch.setenv("TA_USE_FUSED", "1")
+    nn = make_nn(["Ni", "Mo"], 6.5, True, [32, 32], minmax=True)
+    _compare(nn, [_alloy(["Ni", "Mo"], rep=(2, 2, 2)), fcc(rep=(2, 2, 2))])
+    nn = make_nn(["Al", "Cu", "Ni"], 5.0, True, [16, 16], activation="tanh", resnet=True)
+    _compare(nn, [_alloy(["Al", "Cu", "Ni"], rep=(2, 2, 2))])
+
+
+def test_energy_only(lib, monkeypatch):
+    from tensoralloy_amd import Engine, _lib
+    nn = make_nn(["Ni"], 6.5, True, [64, 64])
+    atoms = fcc(rep=(2, 2, 2))
+    with Engine(nn) as eng:
+        r = eng.evaluate([atoms], want=_lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC)[0]
+    o = oracle_eval(nn, atoms, want_forces=False)
+    assert abs(r["energy"] - o["energy"]) < E_TOL
+    assert np.abs(r["atomic"] - o["atomic"]).max() < E_TOL
+    assert "forces" not in r
