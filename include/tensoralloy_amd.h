@@ -115,6 +115,10 @@ typedef struct {
   int64_t n_triples;       /* sum_i n_i (n_i - 1) / 2               (= nijk)     */
   int32_t nnl_max;         /* max neighbours of one centre                       */
   int32_t descriptor_dim;  /* D per atom                                         */
+  int32_t nl_on_device;    /* 1: neighbour list built by the GPU kernels, 0: host */
+  int32_t reserved_;
+  double nl_ms;            /* wall time of the neighbour-list part of ta_set_frames */
+  double set_frames_ms;    /* wall time of the whole ta_set_frames call          */
 } ta_batch_info;
 
 /* number of kernel-timing slots filled by ta_time_compute */

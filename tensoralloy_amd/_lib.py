@@ -19,7 +19,7 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip",
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip",
            "ta_neighbor.cpp"]
 
 TA_OK = 0
@@ -66,7 +66,9 @@ class Frame(C.Structure):
 
 class BatchInfo(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("n_atoms", C.c_int64), ("n_pairs", C.c_int64),
-                ("n_triples", C.c_int64), ("nnl_max", C.c_int32), ("descriptor_dim", C.c_int32)]
+                ("n_triples", C.c_int64), ("nnl_max", C.c_int32), ("descriptor_dim", C.c_int32),
+                ("nl_on_device", C.c_int32), ("reserved_", C.c_int32),
+                ("nl_ms", C.c_double), ("set_frames_ms", C.c_double)]
 
 
 def hipcc_path() -> str:

@@ -2,6 +2,7 @@
 // Declarations and the reference interfaces they replace: include/tensoralloy_amd.h
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,11 @@ struct ta_context {
   DevBuf<unsigned long long> masks;
   DevBuf<int32_t> species, frame_of_atom, atom_start, pair_start, seg_start, pair_i, pair_j,
       pair_shift, pair_rev, elem_atoms, blk_center;
+  // device neighbour list (ta_nlist.hip)
+  DevBuf<int32_t> nl_wrap, nl_binid, nl_bin_count, nl_bin_start, nl_bin_cursor, nl_bin_atoms, nl_counts;
+  DevBuf<unsigned long long> nl_stats;
+  DevBuf<ta::NlGrid> nl_grids;
+  bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
   std::string err;
@@ -320,14 +326,21 @@ void upload_batch(ta_context *h) {
       HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
                                hipMemcpyHostToDevice, h->stream));
   };
-  put(h->frame_of_atom, hp.frame_of_atom);
-  put(h->atom_start, hp.atom_start);
-  put(h->pair_start, hp.pair_start);
-  put(h->seg_start, hp.seg_start);
-  put(h->pair_i, hp.pair_i);
-  put(h->pair_j, hp.pair_j);
-  put(h->pair_shift, hp.pair_shift);
-  put(h->pair_rev, hp.pair_rev);
+  if (h->pairs_on_device) {
+    h->pair_i.ensure(P);
+    h->pair_j.ensure(P);
+    h->pair_shift.ensure(3 * P);
+    h->pair_rev.ensure(P);
+  } else {
+    put(h->frame_of_atom, hp.frame_of_atom);
+    put(h->atom_start, hp.atom_start);
+    put(h->pair_start, hp.pair_start);
+    put(h->seg_start, hp.seg_start);
+    put(h->pair_i, hp.pair_i);
+    put(h->pair_j, hp.pair_j);
+    put(h->pair_shift, hp.pair_shift);
+    put(h->pair_rev, hp.pair_rev);
+  }
 
   const int D = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 1;
   h->rec.ensure(P * kRecDoubles);
@@ -366,6 +379,79 @@ void upload_batch(ta_context *h) {
   db.energy = h->energy.ptr;
   db.virial = h->virial.ptr;
   db.batch_energy = h->benergy.ptr;
+}
+
+// Neighbour list on the device, part 1: bins, per-atom counts, segment offsets. Leaves the
+// counts in h->hp (n_pairs, n_triples, nnl_max, pair_start) for the sizing done by the caller.
+void build_pairs_on_device(ta_context *h, int n_frames, const ta_frame *frames,
+                           std::vector<ta::NlGrid> &grids, int n_bins) {
+  using namespace ta;
+  HostPairs &hp = h->hp;
+  hipStream_t s = h->stream;
+  size_t N = 0;
+  hp.atom_start.assign((size_t)n_frames + 1, 0);
+  for (int f = 0; f < n_frames; ++f) {
+    N += (size_t)frames[f].n_atoms;
+    hp.atom_start[f + 1] = (int32_t)N;
+  }
+  hp.frame_of_atom.resize(N);
+  for (int f = 0; f < n_frames; ++f)
+    std::fill(hp.frame_of_atom.begin() + hp.atom_start[f], hp.frame_of_atom.begin() + hp.atom_start[f + 1], f);
+  const int nel = h->n_elements;
+  auto put = [&](auto &buf, const auto &vec) {
+    buf.ensure(vec.size());
+    if (!vec.empty())
+      HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
+  };
+  put(h->frame_of_atom, hp.frame_of_atom);
+  put(h->atom_start, hp.atom_start);
+  put(h->nl_grids, grids);
+  h->nl_wrap.ensure(3 * N);
+  h->nl_binid.ensure(N);
+  h->nl_bin_count.ensure((size_t)n_bins + 1);
+  h->nl_bin_start.ensure((size_t)n_bins + 1);
+  h->nl_bin_cursor.ensure((size_t)n_bins + 1);
+  h->nl_bin_atoms.ensure(N);
+  h->nl_counts.ensure(N * (nel + 1) + 1);
+  h->seg_start.ensure(N * (nel + 1) + 1);
+  h->pair_start.ensure(N + 1);
+  h->nl_stats.ensure(4);
+  NlWork w{h->nl_wrap.ptr,       h->nl_binid.ptr,     h->nl_bin_count.ptr, h->nl_bin_start.ptr,
+           h->nl_bin_cursor.ptr, h->nl_bin_atoms.ptr, h->nl_counts.ptr,    h->seg_start.ptr,
+           h->nl_stats.ptr};
+  nl_count((int)N, n_bins, nel, h->rmax, h->pos.ptr, h->species.ptr, h->frame_of_atom.ptr,
+           h->nl_grids.ptr, w, h->pair_start.ptr, s);
+  HIP_CHECK(hipGetLastError());
+  unsigned long long stats[4];
+  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, s));
+  hp.pair_start.resize(N + 1);
+  HIP_CHECK(hipMemcpyAsync(hp.pair_start.data(), h->pair_start.ptr, (N + 1) * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  const int32_t *si = reinterpret_cast<const int32_t *>(stats);
+  if (si[4] < 0) throw std::runtime_error("batch too large for 32-bit pair indices");
+  hp.n_atoms = (int64_t)N;
+  hp.n_pairs = si[4];
+  hp.n_triples = (int64_t)stats[0];
+  hp.nnl_max = si[2];
+  hp.seg_start.clear();
+  hp.pair_i.clear();
+  hp.pair_j.clear();
+  hp.pair_shift.clear();
+  hp.pair_rev.clear();
+  h->pairs_on_device = true;
+}
+
+// part 2, after the pair buffers are sized: write the pairs and the reverse index
+void fill_pairs_on_device(ta_context *h) {
+  using namespace ta;
+  NlWork w{h->nl_wrap.ptr,       h->nl_binid.ptr,     h->nl_bin_count.ptr, h->nl_bin_start.ptr,
+           h->nl_bin_cursor.ptr, h->nl_bin_atoms.ptr, h->nl_counts.ptr,    h->seg_start.ptr,
+           h->nl_stats.ptr};
+  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->rmax, h->pos.ptr, h->species.ptr,
+          h->frame_of_atom.ptr, h->nl_grids.ptr, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
+          h->pair_rev.ptr, h->stream);
+  HIP_CHECK(hipGetLastError());
 }
 
 void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
@@ -573,6 +659,11 @@ int ta_destroy(ta_handle h) {
   h->pair_shift.release(); h->pair_rev.release(); h->elem_atoms.release();
   h->blk_center.release();
   h->masks.release();
+  for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
+                  &h->nl_bin_atoms, &h->nl_counts})
+    b->release();
+  h->nl_stats.release();
+  h->nl_grids.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -589,8 +680,9 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       if (fr.n_atoms < 0 || (fr.n_atoms > 0 && (!fr.species || !fr.positions)) || !fr.cell || !fr.pbc)
         throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
     }
-    ta::build_pairs(n_frames, frames, h->n_elements, h->rmax, h->hp);
-    const size_t N = (size_t)h->hp.n_atoms;
+    const auto t_begin = std::chrono::steady_clock::now();
+    size_t N = 0;
+    for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
     std::vector<double> pos(3 * N), cells(9 * (size_t)n_frames);
     std::vector<int32_t> species(N);
     size_t a = 0;
@@ -601,6 +693,44 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       std::memcpy(&cells[9 * (size_t)f], fr.cell, 9 * sizeof(double));
       a += fr.n_atoms;
     }
+    auto put = [&](auto &buf, const auto &vec) {
+      buf.ensure(vec.size());
+      if (!vec.empty())
+        HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
+                                 hipMemcpyHostToDevice, h->stream));
+    };
+    put(h->pos, pos);
+    put(h->cells, cells);
+    put(h->species, species);
+    // Neighbour list: on the device when every frame has >= 3 linked-cell bins along its
+    // periodic axes (ta_nlist.hip), otherwise the host builder (ta_neighbor.cpp).
+    const auto t_nl = std::chrono::steady_clock::now();
+    std::vector<ta::NlGrid> grids((size_t)n_frames);
+    int n_bins = 0;
+    bool device_nl = N > 0 && N < (1u << 30) &&
+                     !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');
+    for (int f = 0; f < n_frames && device_nl; ++f) {
+      device_nl = ta::nl_make_grid(frames[f], h->rmax, n_bins, grids[f]);
+      if (device_nl) n_bins += ta::nl_bins(grids[f]);
+      if (n_bins > (1 << 24)) device_nl = false;
+    }
+    if (device_nl) {
+      a = 0;
+      for (int f = 0; f < n_frames; ++f) {
+        for (size_t i = a; i < a + (size_t)frames[f].n_atoms; ++i) {
+          if (species[i] < 0 || species[i] >= h->n_elements)
+            throw std::runtime_error("frame " + std::to_string(f) + ": species index out of range");
+          if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
+            throw std::runtime_error("frame " + std::to_string(f) + ": non-finite position");
+        }
+        a += frames[f].n_atoms;
+      }
+      build_pairs_on_device(h, n_frames, frames, grids, n_bins);
+    } else {
+      h->pairs_on_device = false;
+      ta::build_pairs(n_frames, frames, h->n_elements, h->rmax, h->hp);
+    }
+    double nl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nl).count();
     // atoms grouped by element for the batched MLP
     std::vector<int32_t> elem_atoms(N);
     {
@@ -611,7 +741,15 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       std::vector<int32_t> fill(count.begin(), count.end() - 1);
       for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
     }
+    h->db.pos = h->pos.ptr;
+    h->db.species = h->species.ptr;
     upload_batch(h);
+    if (h->pairs_on_device) {
+      const auto t_fill = std::chrono::steady_clock::now();
+      fill_pairs_on_device(h);
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
+    }
     // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
     h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && h->n_elements <= 3 &&
                 h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
@@ -653,15 +791,6 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     } else {
       h->db.n_blk = 0;
     }
-    auto put = [&](auto &buf, const auto &vec) {
-      buf.ensure(vec.size());
-      if (!vec.empty())
-        HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
-                                 hipMemcpyHostToDevice, h->stream));
-    };
-    put(h->pos, pos);
-    put(h->cells, cells);
-    put(h->species, species);
     put(h->elem_atoms, elem_atoms);
     put(h->blk_center, blk);
     h->db.blk_center = h->blk_center.ptr;
@@ -683,6 +812,12 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       ta::eam_ensure(h->eam, h->db);
     }
     HIP_CHECK(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+    if (h->pairs_on_device) {
+      int32_t stats[8];
+      HIP_CHECK(hipMemcpy(stats, h->nl_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
+      if (stats[6] != 0)
+        throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
+    }
     h->have_batch = true;
     if (info) {
       info->n_frames = n_frames;
@@ -691,6 +826,11 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       info->n_triples = h->hp.n_triples;
       info->nnl_max = h->hp.nnl_max;
       info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 0;
+      info->nl_on_device = h->pairs_on_device ? 1 : 0;
+      info->reserved_ = 0;
+      info->nl_ms = nl_ms;
+      info->set_frames_ms =
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
   });
 }
@@ -825,6 +965,15 @@ int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift) {
   if (!h) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
   const size_t P = (size_t)h->hp.n_pairs;
+  if (h->pairs_on_device) {
+    return guarded(h, [&]() {
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (i && P) HIP_CHECK(hipMemcpy(i, h->db.pair_i, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (j && P) HIP_CHECK(hipMemcpy(j, h->db.pair_j, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (shift && P)
+        HIP_CHECK(hipMemcpy(shift, h->db.pair_shift, 3 * P * sizeof(int32_t), hipMemcpyDeviceToHost));
+    });
+  }
   if (i) std::memcpy(i, h->hp.pair_i.data(), P * sizeof(int32_t));
   if (j) std::memcpy(j, h->hp.pair_j.data(), P * sizeof(int32_t));
   if (shift) std::memcpy(shift, h->hp.pair_shift.data(), 3 * P * sizeof(int32_t));

@@ -142,4 +142,37 @@ void launch_g4_forward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz
 void launch_backward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
 
+// device-side neighbour list (ta_nlist.hip)
+struct NlGrid {  // linked-cell grid of one frame, in fractional coordinates
+  double h[9];
+  double hinv[9];
+  double lo[3];     // lower edge of the grid (0 on periodic axes)
+  double inv_w[3];  // bins per unit of fractional coordinate
+  int32_t nb[3];
+  int32_t pbc[3];
+  int32_t bin_offset;  // first bin of this frame in the batch-wide bin arrays
+  int32_t pad_;
+};
+struct NlWork {  // device work buffers, sized by the caller
+  int32_t *wrap;        // [3 N] integer wrap of each atom into its cell
+  int32_t *binid;       // [N]
+  int32_t *bin_count;   // [n_bins + 1]
+  int32_t *bin_start;   // [n_bins + 1]
+  int32_t *bin_cursor;  // [n_bins + 1]
+  int32_t *bin_atoms;   // [N]
+  int32_t *counts;      // [N (nel + 1) + 1]
+  int32_t *seg_start;   // [N (nel + 1) + 1]
+  // stats[0] = number of triples; as int32: [2] nnl_max, [4] number of pairs, [6] pairs
+  // without a reverse partner (must stay 0)
+  unsigned long long *stats;
+};
+bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g);
+int nl_bins(const NlGrid &g);
+void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
+              const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, int32_t *pair_start,
+              hipStream_t s);
+void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,
+             const int32_t *species, const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w,
+             int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, hipStream_t s);
+
 }  // namespace ta

@@ -1,0 +1,353 @@
+// Device-side neighbour list: positions -> packed pair buffers, entirely on the GPU.
+//
+// Replaces the host part of reference transformer/universal.py:46-112
+// (`get_radial_metadata`: ASE `neighbor_list('ijS', atoms, rc)` at :58 plus the
+// per-pair Python loops), which the reference's own profile shows to be 97 % of
+// its wall time (doc/papers/nn/figures/cpc_speed.py:13-16). Same semantics as
+// the host builder in ta_neighbor.cpp: full list, strict |Rj - Ri + S.h| < rc on
+// the positions as given, per-axis periodicity; output sorted by centre and
+// neighbour species with the reverse-pair index.
+//
+// Linked cells in fractional coordinates (bin width >= rc along every axis).
+// This path needs at least 3 bins along every periodic axis, so that the 27
+// neighbouring bins are distinct and each carries one image shift; frames
+// that do not qualify (cells thinner than 3 rc) are built on the host.
+//
+// Kernels: bin_atoms (wrap, bin id, histogram) -> scan_bins -> fill_bins (+ per-bin
+// sort by atom index: deterministic order) -> count_pairs (one wavefront per
+// atom, ballot + popcount per neighbour species) -> scan_counts -> fill_pairs
+// (same traversal, slots from the running popcounts) -> reverse_pairs.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "ta_device.h"
+#include "ta_internal.h"
+
+namespace ta {
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void bin_atoms_kernel(int n_atoms, const double *pos,
+                                                           const int32_t *frame_of_atom,
+                                                           const NlGrid *grids, int32_t *wrap,
+                                                           int32_t *binid, int32_t *bin_count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_atoms) return;
+  const NlGrid &g = grids[frame_of_atom[i]];
+  const double *r = pos + 3 * (size_t)i;
+  int b[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double f = r[0] * g.hinv[0 * 3 + a] + r[1] * g.hinv[1 * 3 + a] + r[2] * g.hinv[2 * 3 + a];
+    int w = 0;
+    if (g.pbc[a]) {
+      w = (int)floor(f);
+      f -= w;
+    }
+    wrap[3 * (size_t)i + a] = w;
+    int k = (int)floor((f - g.lo[a]) * g.inv_w[a]);
+    k = k < 0 ? 0 : (k >= g.nb[a] ? g.nb[a] - 1 : k);
+    b[a] = k;
+  }
+  const int id = g.bin_offset + (b[0] * g.nb[1] + b[1]) * g.nb[2] + b[2];
+  binid[i] = id;
+  atomicAdd(&bin_count[id], 1);
+}
+
+// exclusive scan of `n` ints by one workgroup (n is small: bins, or atoms x species)
+__global__ __launch_bounds__(1024) void scan_kernel(int n, const int32_t *in, int32_t *out,
+                                                    int32_t *total) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = t * chunk, hi = min(n, lo + chunk);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += in[k];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int k = lo; k < hi; ++k) {
+    const int v = in[k];
+    out[k] = run;
+    run += v;
+  }
+  if (t == 1023) {
+    out[n] = part[1023];
+    if (total) *total = part[1023];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_bins_kernel(int n_atoms, const int32_t *binid,
+                                                           const int32_t *bin_start,
+                                                           int32_t *bin_cursor, int32_t *bin_atoms) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int id = binid[i];
+  bin_atoms[bin_start[id] + atomicAdd(&bin_cursor[id], 1)] = i;
+}
+
+// insertion sort of every bin's atoms by index: removes the atomics' ordering noise
+__global__ __launch_bounds__(kBlock) void sort_bins_kernel(int n_bins, const int32_t *bin_start,
+                                                           int32_t *bin_atoms) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_bins) return;
+  const int lo = bin_start[k], hi = bin_start[k + 1];
+  for (int a = lo + 1; a < hi; ++a) {
+    const int v = bin_atoms[a];
+    int c = a - 1;
+    while (c >= lo && bin_atoms[c] > v) {
+      bin_atoms[c + 1] = bin_atoms[c];
+      --c;
+    }
+    bin_atoms[c + 1] = v;
+  }
+}
+
+// One wavefront per centre atom walks its 27 neighbouring bins. MODE 0 counts
+// the neighbours per species, MODE 1 writes them.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void pairs_kernel(int n_atoms, int nel, double rmax,
+                                                       const double *pos, const int32_t *species,
+                                                       const int32_t *frame_of_atom,
+                                                       const NlGrid *grids, const int32_t *wrap,
+                                                       const int32_t *binid, const int32_t *bin_start,
+                                                       const int32_t *bin_atoms, int32_t *counts,
+                                                       const int32_t *seg_start, int32_t *pair_i,
+                                                       int32_t *pair_j, int32_t *pair_shift) {
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n_atoms) return;
+  const NlGrid &g = grids[frame_of_atom[i]];
+  const int local = binid[i] - g.bin_offset;
+  const int bz = local % g.nb[2], by = (local / g.nb[2]) % g.nb[1], bx = local / (g.nb[2] * g.nb[1]);
+  const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
+  const int wix = wrap[3 * (size_t)i], wiy = wrap[3 * (size_t)i + 1], wiz = wrap[3 * (size_t)i + 2];
+  int running[kMaxElements];
+#pragma unroll
+  for (int s = 0; s < kMaxElements; ++s) running[s] = 0;
+  const int32_t *seg = seg_start ? seg_start + (size_t)i * (nel + 1) : nullptr;
+
+  for (int dx = -1; dx <= 1; ++dx) {
+    int cx = bx + dx, sx = 0;
+    if (cx < 0 || cx >= g.nb[0]) {
+      if (!g.pbc[0]) continue;
+      sx = cx < 0 ? -1 : 1;
+      cx -= sx * g.nb[0];
+    }
+    for (int dy = -1; dy <= 1; ++dy) {
+      int cy = by + dy, sy = 0;
+      if (cy < 0 || cy >= g.nb[1]) {
+        if (!g.pbc[1]) continue;
+        sy = cy < 0 ? -1 : 1;
+        cy -= sy * g.nb[1];
+      }
+      for (int dz = -1; dz <= 1; ++dz) {
+        int cz = bz + dz, sz = 0;
+        if (cz < 0 || cz >= g.nb[2]) {
+          if (!g.pbc[2]) continue;
+          sz = cz < 0 ? -1 : 1;
+          cz -= sz * g.nb[2];
+        }
+        const int bin = g.bin_offset + (cx * g.nb[1] + cy) * g.nb[2] + cz;
+        const int lo = bin_start[bin], hi = bin_start[bin + 1];
+        for (int c0 = lo; c0 < hi; c0 += 64) {
+          const int c = c0 + lane;
+          bool valid = false;
+          int j = 0, Sx = 0, Sy = 0, Sz = 0, sj = 0;
+          if (c < hi) {
+            j = bin_atoms[c];
+            // shift relative to the positions as given: S = s - w_j + w_i
+            Sx = sx - wrap[3 * (size_t)j] + wix;
+            Sy = sy - wrap[3 * (size_t)j + 1] + wiy;
+            Sz = sz - wrap[3 * (size_t)j + 2] + wiz;
+            const double Dx = pos[3 * (size_t)j] - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
+            const double Dy = pos[3 * (size_t)j + 1] - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
+            const double Dz = pos[3 * (size_t)j + 2] - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
+            const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
+            valid = (sqrt(r2) < rmax) && !(j == i && sx == 0 && sy == 0 && sz == 0);
+            sj = species[j];
+          }
+          for (int s = 0; s < nel; ++s) {
+            const unsigned long long m = __ballot(valid && sj == s);
+            if (MODE == 1 && valid && sj == s) {
+              const int slot = seg[s] + running[s] + __popcll(m & ((1ull << lane) - 1ull));
+              pair_i[slot] = i;
+              pair_j[slot] = j;
+              pair_shift[3 * (size_t)slot] = Sx;
+              pair_shift[3 * (size_t)slot + 1] = Sy;
+              pair_shift[3 * (size_t)slot + 2] = Sz;
+            }
+            running[s] += __popcll(m);
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 0 && lane == 0) {
+    for (int s = 0; s < nel; ++s) counts[(size_t)i * (nel + 1) + s] = running[s];
+    counts[(size_t)i * (nel + 1) + nel] = 0;  // slot so that seg_start has nel + 1 entries per atom
+  }
+}
+
+// seg_start (from the scan) -> pair_start, and per-atom statistics
+__global__ __launch_bounds__(kBlock) void finish_starts_kernel(int n_atoms, int nel,
+                                                               const int32_t *seg_start,
+                                                               int32_t *pair_start,
+                                                               unsigned long long *n_triples,
+                                                               int32_t *nnl_max) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_atoms) return;
+  if (i == n_atoms) {
+    pair_start[i] = seg_start[(size_t)n_atoms * (nel + 1)];
+    return;
+  }
+  const int a = seg_start[(size_t)i * (nel + 1)], b = seg_start[(size_t)(i + 1) * (nel + 1)];
+  pair_start[i] = a;
+  const int n = b - a;
+  atomicAdd(n_triples, (unsigned long long)n * (unsigned long long)(n - 1) / 2ull);
+  atomicMax(nnl_max, n);
+}
+
+// (i -> j, S) <-> (j -> i, -S): search j's segment of species(i)
+__global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, int nel,
+                                                               const int32_t *species,
+                                                               const int32_t *seg_start,
+                                                               const int32_t *pair_i,
+                                                               const int32_t *pair_j,
+                                                               const int32_t *pair_shift,
+                                                               int32_t *pair_rev, int32_t *n_missing) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int i = pair_i[p], j = pair_j[p];
+  const int sx = pair_shift[3 * p], sy = pair_shift[3 * p + 1], sz = pair_shift[3 * p + 2];
+  const int32_t *seg = seg_start + (size_t)j * (nel + 1);
+  const int si = species[i];
+  int found = -1;
+  for (int q = seg[si]; q < seg[si + 1]; ++q) {
+    if (pair_j[q] == i && pair_shift[3 * (size_t)q] == -sx && pair_shift[3 * (size_t)q + 1] == -sy &&
+        pair_shift[3 * (size_t)q + 2] == -sz) {
+      found = q;
+      break;
+    }
+  }
+  pair_rev[p] = found;
+  if (found < 0) atomicAdd(n_missing, 1);
+}
+
+inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+// Host: grid parameters of one frame. Returns false when the frame cannot use the device
+// builder (a periodic axis with fewer than 3 bins) or the cell is singular.
+bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g) {
+  for (int k = 0; k < 9; ++k) g.h[k] = fr.cell[k];
+  auto norm = [](const double *a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+  auto cross = [](const double *a, const double *b, double *c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  for (int a = 0; a < 3; ++a)  // incomplete cells (zero rows): leave to the host builder
+    if (g.h[3 * a] == 0.0 && g.h[3 * a + 1] == 0.0 && g.h[3 * a + 2] == 0.0) return false;
+  double c0[3], c1[3], c2[3];
+  cross(&g.h[3], &g.h[6], c0);
+  cross(&g.h[6], &g.h[0], c1);
+  cross(&g.h[0], &g.h[3], c2);
+  const double det = g.h[0] * c0[0] + g.h[1] * c0[1] + g.h[2] * c0[2];
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  for (int a = 0; a < 3; ++a) {
+    g.hinv[3 * a + 0] = c0[a] / det;
+    g.hinv[3 * a + 1] = c1[a] / det;
+    g.hinv[3 * a + 2] = c2[a] / det;
+  }
+  const double vol = std::fabs(det);
+  const double *cr[3] = {c0, c1, c2};
+  for (int a = 0; a < 3; ++a) {
+    g.pbc[a] = fr.pbc[a] != 0;
+    const double height = vol / norm(cr[a]);
+    const double wfrac = rmax / height;  // bin width in fractional units (perpendicular width = rmax)
+    if (g.pbc[a]) {
+      const int nb = (int)std::floor(1.0 / wfrac);
+      if (nb < 3) return false;
+      g.nb[a] = std::min(nb, 64);
+      g.lo[a] = 0.0;
+      g.inv_w[a] = (double)g.nb[a];
+    } else {
+      double mn = 1e300, mx = -1e300;
+      for (int i = 0; i < fr.n_atoms; ++i) {
+        const double *r = &fr.positions[3 * (size_t)i];
+        const double f = r[0] * g.hinv[0 * 3 + a] + r[1] * g.hinv[1 * 3 + a] + r[2] * g.hinv[2 * 3 + a];
+        if (!std::isfinite(f)) return false;
+        mn = std::min(mn, f);
+        mx = std::max(mx, f);
+      }
+      if (fr.n_atoms == 0) mn = mx = 0.0;
+      const double ext = mx - mn;
+      int nb = (ext > 0 && wfrac > 0) ? (int)std::floor(ext / wfrac) : 1;
+      nb = std::max(1, std::min(nb, 64));
+      g.nb[a] = nb;
+      g.lo[a] = mn;
+      g.inv_w[a] = ext > 0 ? nb / ext : 0.0;
+    }
+  }
+  g.bin_offset = bin_offset;
+  return true;
+}
+
+int nl_bins(const NlGrid &g) { return g.nb[0] * g.nb[1] * g.nb[2]; }
+
+// Device pipeline. All pointers are device buffers sized by the caller:
+// (see NlWork in ta_device.h); nl_count ends with the pair count in stats, the caller reads it,
+// sizes the pair buffers and calls nl_fill.
+void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
+              const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, int32_t *pair_start,
+              hipStream_t s) {
+  (void)hipMemsetAsync(w.bin_count, 0, (size_t)(n_bins + 1) * sizeof(int32_t), s);
+  (void)hipMemsetAsync(w.bin_cursor, 0, (size_t)(n_bins + 1) * sizeof(int32_t), s);
+  (void)hipMemsetAsync(w.stats, 0, 4 * sizeof(unsigned long long), s);
+  if (n_atoms == 0) return;
+  hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
+                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
+                     (int32_t *)nullptr);
+  hipLaunchKernelGGL(fill_bins_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms,
+                     w.binid, w.bin_start, w.bin_cursor, w.bin_atoms);
+  hipLaunchKernelGGL(sort_bins_kernel, dim3(nblk(n_bins, kBlock)), dim3(kBlock), 0, s, n_bins,
+                     w.bin_start, w.bin_atoms);
+  hipLaunchKernelGGL(pairs_kernel<0>, dim3(nblk((int64_t)n_atoms * 64, kBlock)), dim3(kBlock), 0, s,
+                     n_atoms, nel, rmax, pos, species, frame_of_atom, grids, w.wrap, w.binid,
+                     w.bin_start, w.bin_atoms, w.counts, (const int32_t *)nullptr, (int32_t *)nullptr,
+                     (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), w.counts,
+                     w.seg_start, reinterpret_cast<int32_t *>(w.stats) + 4);
+  hipLaunchKernelGGL(finish_starts_kernel, dim3(nblk(n_atoms + 1, kBlock)), dim3(kBlock), 0, s,
+                     n_atoms, nel, w.seg_start, pair_start, w.stats,
+                     reinterpret_cast<int32_t *>(w.stats) + 2);
+}
+
+void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,
+             const int32_t *species, const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w,
+             int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev,
+             hipStream_t s) {
+  if (n_atoms == 0) return;
+  hipLaunchKernelGGL(pairs_kernel<1>, dim3(nblk((int64_t)n_atoms * 64, kBlock)), dim3(kBlock), 0, s,
+                     n_atoms, nel, rmax, pos, species, frame_of_atom, grids, w.wrap, w.binid,
+                     w.bin_start, w.bin_atoms, (int32_t *)nullptr, w.seg_start, pair_i, pair_j,
+                     pair_shift);
+  if (n_pairs > 0)
+    hipLaunchKernelGGL(reverse_pairs_kernel, dim3(nblk(n_pairs, kBlock)), dim3(kBlock), 0, s, n_pairs,
+                       nel, species, w.seg_start, pair_i, pair_j, pair_shift, pair_rev,
+                       reinterpret_cast<int32_t *>(w.stats) + 6);
+}
+
+}  // namespace ta

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layouts_match_header(lib):
     from tensoralloy_amd import _lib
     assert C.sizeof(_lib.Frame) == 40
-    assert C.sizeof(_lib.BatchInfo) == 40
+    assert C.sizeof(_lib.BatchInfo) == 64 and _lib.BatchInfo.nl_ms.offset == 48
     assert _lib.ModelDesc.rcut.offset == 8 and _lib.ModelDesc.eta.offset == 56
     assert _lib.ModelDesc.eam_params.offset == C.sizeof(_lib.ModelDesc) - 8
 

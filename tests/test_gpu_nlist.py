@@ -1,0 +1,131 @@
+"""
+GPU neighbour list (tensoralloy_amd/csrc/ta_nlist.hip) against the oracle's
+list (oracle/neighbors.py, itself pinned on the reference's snap-Ni statistics):
+the sets of (i, j, S) must be identical -- integer work, bit-exact -- and the
+energies / forces must not depend on which builder produced the list.
+"""
+import numpy as np
+import pytest
+
+from oracle import neighbors as onl
+from tests.helpers import fcc, make_nn
+from tensoralloy_amd import Atoms
+
+pytestmark = pytest.mark.gpu
+
+
+def _triplets(i, j, S):
+    a = np.concatenate([np.asarray(i, np.int64)[:, None], np.asarray(j, np.int64)[:, None],
+                        np.asarray(S, np.int64).reshape(-1, 3)], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def _device_pairs(nn, atoms_list, expect_device=True):
+    from tensoralloy_amd import Engine
+    with Engine(nn) as eng:
+        info = eng.set_frames(atoms_list)
+        assert bool(info.nl_on_device) == expect_device
+        i, j, S = eng.pairs()
+        return info, _triplets(i, j, S)
+
+
+def _oracle_pairs(atoms_list, rc):
+    out, off = [], 0
+    for atoms in atoms_list:
+        i, j, S = onl.neighbor_list(atoms.positions, np.asarray(atoms.get_cell(complete=True)), atoms.pbc, rc)
+        out.append(_triplets(i + off, j + off, S))
+        off += len(atoms)
+    a = np.concatenate(out)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def _sheared(rep=(7, 7, 7), seed=5):
+    """Triclinic cell, atoms displaced far outside the cell (wrap shifts in S)."""
+    atoms = fcc(rep=rep, seed=seed)
+    cell = np.asarray(atoms.get_cell(complete=True)).copy()
+    cell[1, 0] = 0.3 * cell[0, 0]
+    cell[2, 1] = -0.2 * cell[1, 1]
+    cell[2, 0] = 0.15 * cell[0, 0]
+    frac = atoms.positions @ np.linalg.inv(np.diag(np.diag(cell)))
+    rng = np.random.RandomState(seed)
+    frac = frac + rng.randint(-2, 3, size=frac.shape)
+    return Atoms(symbols=["Ni"] * len(frac), positions=frac @ cell, cell=cell, pbc=True)
+
+
+def test_periodic_supercell_matches_oracle(lib):
+    nn = make_nn(["Ni"], 6.5, True, [16])
+    atoms = [fcc(rep=(6, 6, 6), seed=1)]
+    info, dev = _device_pairs(nn, atoms)
+    ref = _oracle_pairs(atoms, 6.5)
+    assert info.n_pairs == len(ref)
+    assert np.array_equal(dev, ref)
+    counts = np.bincount(ref[:, 0], minlength=len(atoms[0]))
+    assert info.nnl_max == counts.max()
+    assert info.n_triples == int((counts * (counts - 1) // 2).sum())
+
+
+def test_triclinic_wrapped_positions(lib):
+    nn = make_nn(["Ni"], 6.5, True, [16])
+    atoms = [_sheared()]
+    info, dev = _device_pairs(nn, atoms)
+    assert np.array_equal(dev, _oracle_pairs(atoms, 6.5))
+    assert np.abs(dev[:, 2:]).max() >= 2  # shifts really carry the wrap
+
+
+def test_slab_and_cluster_and_alloy_batch(lib):
+    nn = make_nn(["Mo", "Ni"], 6.0, True, [16])
+    slab = fcc(rep=(6, 6, 3), seed=2)
+    slab.pbc = [True, True, False]
+    cell = np.asarray(slab.get_cell(complete=True)).copy()
+    cell[2, 2] += 15.0
+    slab = Atoms(symbols=["Ni" if k % 3 else "Mo" for k in range(len(slab))], positions=slab.positions,
+                 cell=cell, pbc=[True, True, False])
+    cluster = fcc(rep=(5, 4, 3), seed=3)
+    cluster = Atoms(symbols=["Mo" if k % 2 else "Ni" for k in range(len(cluster))],
+                    positions=cluster.positions - 40.0, cell=np.eye(3) * 60.0, pbc=False)
+    bulk = fcc(rep=(6, 6, 7), seed=4)
+    bulk = Atoms(symbols=["Ni"] * len(bulk), positions=bulk.positions, cell=bulk.get_cell(complete=True),
+                 pbc=True)
+    frames = [slab, cluster, bulk]
+    info, dev = _device_pairs(nn, frames)
+    assert np.array_equal(dev, _oracle_pairs(frames, 6.0))
+
+
+def test_thin_cells_fall_back_to_host(lib):
+    nn = make_nn(["Ni"], 6.5, True, [16])
+    atoms = [fcc(rep=(2, 2, 2))]
+    info, dev = _device_pairs(nn, atoms, expect_device=False)
+    assert np.array_equal(dev, _oracle_pairs(atoms, 6.5))
+
+
+def test_results_do_not_depend_on_the_builder(lib, monkeypatch):
+    from tensoralloy_amd import Engine
+    nn = make_nn(["Mo", "Ni"], 6.5, True, [32, 32])
+    base = fcc(rep=(6, 6, 6), seed=9)
+    atoms = Atoms(symbols=["Mo" if k % 4 == 0 else "Ni" for k in range(len(base))],
+                  positions=base.positions, cell=base.get_cell(complete=True), pbc=True)
+    with Engine(nn) as eng:
+        dev = eng.evaluate([atoms])[0]
+        assert eng.info.nl_on_device == 1
+    monkeypatch.setenv("TA_HOST_NL", "1")
+    with Engine(nn) as eng:
+        host = eng.evaluate([atoms])[0]
+        assert eng.info.nl_on_device == 0
+    assert abs(dev["energy"] - host["energy"]) < 1e-9
+    assert np.abs(dev["forces"] - host["forces"]).max() < 1e-10
+    assert np.abs(dev["virial"] - host["virial"]).max() < 1e-8
+
+
+def test_eam_on_device_list(lib):
+    from tests.helpers import make_eam, oracle_eam_eval
+    from tensoralloy_amd import Engine
+    nn = make_eam(["Cu", "Ni"])
+    base = fcc(rep=(6, 6, 6), seed=11, a=3.57)
+    atoms = Atoms(symbols=["Cu" if k % 2 else "Ni" for k in range(len(base))],
+                  positions=base.positions, cell=base.get_cell(complete=True), pbc=True)
+    with Engine(nn) as eng:
+        r = eng.evaluate([atoms])[0]
+        assert eng.info.nl_on_device == 1
+    o = oracle_eam_eval(nn, atoms)
+    assert abs(r["energy"] - o["energy"]) < 1e-6
+    assert np.abs(r["forces"] - o["forces"]).max() < 1e-5
