@@ -2,6 +2,7 @@
 // Declarations and the reference interfaces they replace: include/tensoralloy_amd.h
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -64,6 +65,26 @@ struct DevBuf {
   }
 };
 
+// grow-only page-locked host buffer (staging for the packed uploads / downloads)
+struct PinnedBuf {
+  char *ptr = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (ptr) HIP_CHECK(hipHostFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 256;
+    HIP_CHECK(hipHostMalloc((void **)&ptr, want, hipHostMallocDefault));
+    cap = want;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
 struct ChunkPlan {
   ta::AngChunk ch;
   int nb, ng, nz;
@@ -96,15 +117,21 @@ struct ta_context {
   bool have_batch = false;
   uint32_t last_want = 0;
 
-  DevBuf<double> pos, cells, rec, part4, G, dEdG, eatom, g, forces, wat, energy, virial, benergy,
-      mlp_scratch;
+  // Inputs travel in one packed upload: [pos | cells | grids | species | frame_of_atom |
+  // atom_start | elem_atoms | blk_center]; results come back in one packed download:
+  // [energy F | virial 9F | atomic N | forces 3N].
+  PinnedBuf stage_in, stage_out;
+  DevBuf<char> inbuf;
+  DevBuf<double> results;
+  size_t o_blk = 0;  // byte offset of blk_center in the packed input
+  DevBuf<double> rec, part4, G, dEdG, g, wat, benergy, mlp_scratch;
   DevBuf<unsigned long long> masks;
-  DevBuf<int32_t> species, frame_of_atom, atom_start, pair_start, seg_start, pair_i, pair_j,
-      pair_shift, pair_rev, elem_atoms, blk_center;
+  DevBuf<int32_t> pair_start, seg_start, pair_i, pair_j, pair_shift, pair_rev;
+  ta::NlGrid *d_grids = nullptr;  // view into inbuf
   // device neighbour list (ta_nlist.hip)
   DevBuf<int32_t> nl_wrap, nl_binid, nl_bin_count, nl_bin_start, nl_bin_cursor, nl_bin_atoms, nl_counts;
   DevBuf<unsigned long long> nl_stats;
-  DevBuf<ta::NlGrid> nl_grids;
+  DevBuf<ta::NlRec> nl_recs;
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
@@ -314,10 +341,9 @@ void upload_batch(ta_context *h) {
   DeviceBatch &db = h->db;
   const size_t N = (size_t)hp.n_atoms, P = (size_t)hp.n_pairs;
   const int nel = h->n_elements;
-  const int F = (int)hp.atom_start.size() - 1;
+  const size_t F = (size_t)db.n_frames;
   db.n_atoms = hp.n_atoms;
   db.n_pairs = hp.n_pairs;
-  db.n_frames = F;
   db.nnl_max = hp.nnl_max;
 
   auto put = [&](auto &buf, const auto &vec) {
@@ -332,8 +358,6 @@ void upload_batch(ta_context *h) {
     h->pair_shift.ensure(3 * P);
     h->pair_rev.ensure(P);
   } else {
-    put(h->frame_of_atom, hp.frame_of_atom);
-    put(h->atom_start, hp.atom_start);
     put(h->pair_start, hp.pair_start);
     put(h->seg_start, hp.seg_start);
     put(h->pair_i, hp.pair_i);
@@ -351,16 +375,11 @@ void upload_batch(ta_context *h) {
   }
   h->G.ensure(N * D);
   h->dEdG.ensure(N * D);
-  h->eatom.ensure(N);
   h->g.ensure(4 * P);
-  h->forces.ensure(3 * N);
   h->wat.ensure(9 * N);
-  h->energy.ensure(F);
-  h->virial.ensure(9 * (size_t)F);
+  h->results.ensure(10 * F + 4 * N);
   h->benergy.ensure(1);
 
-  db.frame_of_atom = h->frame_of_atom.ptr;
-  db.atom_start = h->atom_start.ptr;
   db.pair_start = h->pair_start.ptr;
   db.seg_start = h->seg_start.ptr;
   db.pair_i = h->pair_i.ptr;
@@ -372,61 +391,50 @@ void upload_batch(ta_context *h) {
   db.masks = h->masks.ptr;
   db.G = h->G.ptr;
   db.dEdG = h->dEdG.ptr;
-  db.eatom = h->eatom.ptr;
   db.g = h->g.ptr;
-  db.forces = h->forces.ptr;
   db.wat = h->wat.ptr;
-  db.energy = h->energy.ptr;
-  db.virial = h->virial.ptr;
+  db.energy = h->results.ptr;
+  db.virial = h->results.ptr + F;
+  db.eatom = h->results.ptr + 10 * F;
+  db.forces = h->results.ptr + 10 * F + N;
   db.batch_energy = h->benergy.ptr;
+}
+
+ta::NlWork nl_work(ta_context *h) {
+  return ta::NlWork{h->nl_wrap.ptr,       h->nl_binid.ptr,     h->nl_bin_count.ptr, h->nl_bin_start.ptr,
+                    h->nl_bin_cursor.ptr, h->nl_bin_atoms.ptr, h->nl_recs.ptr,      h->nl_counts.ptr,
+                    h->seg_start.ptr,     h->nl_stats.ptr};
 }
 
 // Neighbour list on the device, part 1: bins, per-atom counts, segment offsets. Leaves the
 // counts in h->hp (n_pairs, n_triples, nnl_max, pair_start) for the sizing done by the caller.
-void build_pairs_on_device(ta_context *h, int n_frames, const ta_frame *frames,
-                           std::vector<ta::NlGrid> &grids, int n_bins) {
+// The packed input (positions, species, grids ...) is already on its way to the device.
+void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   using namespace ta;
   HostPairs &hp = h->hp;
   hipStream_t s = h->stream;
-  size_t N = 0;
-  hp.atom_start.assign((size_t)n_frames + 1, 0);
-  for (int f = 0; f < n_frames; ++f) {
-    N += (size_t)frames[f].n_atoms;
-    hp.atom_start[f + 1] = (int32_t)N;
-  }
-  hp.frame_of_atom.resize(N);
-  for (int f = 0; f < n_frames; ++f)
-    std::fill(hp.frame_of_atom.begin() + hp.atom_start[f], hp.frame_of_atom.begin() + hp.atom_start[f + 1], f);
   const int nel = h->n_elements;
-  auto put = [&](auto &buf, const auto &vec) {
-    buf.ensure(vec.size());
-    if (!vec.empty())
-      HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
-  };
-  put(h->frame_of_atom, hp.frame_of_atom);
-  put(h->atom_start, hp.atom_start);
-  put(h->nl_grids, grids);
   h->nl_wrap.ensure(3 * N);
   h->nl_binid.ensure(N);
   h->nl_bin_count.ensure((size_t)n_bins + 1);
   h->nl_bin_start.ensure((size_t)n_bins + 1);
   h->nl_bin_cursor.ensure((size_t)n_bins + 1);
   h->nl_bin_atoms.ensure(N);
+  h->nl_recs.ensure(N);
   h->nl_counts.ensure(N * (nel + 1) + 1);
   h->seg_start.ensure(N * (nel + 1) + 1);
   h->pair_start.ensure(N + 1);
   h->nl_stats.ensure(4);
-  NlWork w{h->nl_wrap.ptr,       h->nl_binid.ptr,     h->nl_bin_count.ptr, h->nl_bin_start.ptr,
-           h->nl_bin_cursor.ptr, h->nl_bin_atoms.ptr, h->nl_counts.ptr,    h->seg_start.ptr,
-           h->nl_stats.ptr};
-  nl_count((int)N, n_bins, nel, h->rmax, h->pos.ptr, h->species.ptr, h->frame_of_atom.ptr,
-           h->nl_grids.ptr, w, h->pair_start.ptr, s);
+  NlWork w = nl_work(h);
+  nl_count((int)N, n_bins, nel, h->rmax, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
+           h->pair_start.ptr, s);
   HIP_CHECK(hipGetLastError());
-  unsigned long long stats[4];
-  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, s));
-  hp.pair_start.resize(N + 1);
-  HIP_CHECK(hipMemcpyAsync(hp.pair_start.data(), h->pair_start.ptr, (N + 1) * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, s));
+  // counts and per-atom offsets come back through page-locked memory
+  h->stage_out.ensure(64 + (N + 1) * sizeof(int32_t));
+  unsigned long long *stats = reinterpret_cast<unsigned long long *>(h->stage_out.ptr);
+  int32_t *starts = reinterpret_cast<int32_t *>(h->stage_out.ptr + 64);
+  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(starts, h->pair_start.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   const int32_t *si = reinterpret_cast<const int32_t *>(stats);
   if (si[4] < 0) throw std::runtime_error("batch too large for 32-bit pair indices");
@@ -434,6 +442,7 @@ void build_pairs_on_device(ta_context *h, int n_frames, const ta_frame *frames,
   hp.n_pairs = si[4];
   hp.n_triples = (int64_t)stats[0];
   hp.nnl_max = si[2];
+  hp.pair_start.assign(starts, starts + N + 1);
   hp.seg_start.clear();
   hp.pair_i.clear();
   hp.pair_j.clear();
@@ -445,11 +454,9 @@ void build_pairs_on_device(ta_context *h, int n_frames, const ta_frame *frames,
 // part 2, after the pair buffers are sized: write the pairs and the reverse index
 void fill_pairs_on_device(ta_context *h) {
   using namespace ta;
-  NlWork w{h->nl_wrap.ptr,       h->nl_binid.ptr,     h->nl_bin_count.ptr, h->nl_bin_start.ptr,
-           h->nl_bin_cursor.ptr, h->nl_bin_atoms.ptr, h->nl_counts.ptr,    h->seg_start.ptr,
-           h->nl_stats.ptr};
-  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->rmax, h->pos.ptr, h->species.ptr,
-          h->frame_of_atom.ptr, h->nl_grids.ptr, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
+  NlWork w = nl_work(h);
+  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->rmax, h->db.pos, h->db.species,
+          h->db.frame_of_atom, h->d_grids, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
           h->pair_rev.ptr, h->stream);
   HIP_CHECK(hipGetLastError());
 }
@@ -651,19 +658,18 @@ int ta_destroy(ta_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->model_allocs) (void)hipFree(p);
   if (h->eam) ta::eam_destroy(h->eam);
-  h->pos.release(); h->cells.release(); h->rec.release(); h->part4.release(); h->G.release();
-  h->dEdG.release(); h->eatom.release(); h->g.release(); h->forces.release(); h->wat.release();
-  h->energy.release(); h->virial.release(); h->benergy.release(); h->mlp_scratch.release();
-  h->species.release(); h->frame_of_atom.release(); h->atom_start.release();
+  h->stage_in.release(); h->stage_out.release(); h->inbuf.release(); h->results.release();
+  h->rec.release(); h->part4.release(); h->G.release();
+  h->dEdG.release(); h->g.release(); h->wat.release();
+  h->benergy.release(); h->mlp_scratch.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
-  h->pair_shift.release(); h->pair_rev.release(); h->elem_atoms.release();
-  h->blk_center.release();
+  h->pair_shift.release(); h->pair_rev.release();
   h->masks.release();
   for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
                   &h->nl_bin_atoms, &h->nl_counts})
     b->release();
   h->nl_stats.release();
-  h->nl_grids.release();
+  h->nl_recs.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -683,72 +689,98 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     const auto t_begin = std::chrono::steady_clock::now();
     size_t N = 0;
     for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
-    std::vector<double> pos(3 * N), cells(9 * (size_t)n_frames);
-    std::vector<int32_t> species(N);
+    if (N >= (1u << 30)) throw std::runtime_error("batch too large for 32-bit atom indices");
+    const size_t F = (size_t)n_frames;
+    const int nel = h->n_elements;
+    // packed input, every section 16-byte aligned
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_pos = 0;
+    const size_t o_cells = align16(o_pos + 3 * N * sizeof(double));
+    const size_t o_grids = align16(o_cells + 9 * F * sizeof(double));
+    const size_t o_species = align16(o_grids + F * sizeof(ta::NlGrid));
+    const size_t o_foa = align16(o_species + N * sizeof(int32_t));
+    const size_t o_astart = align16(o_foa + N * sizeof(int32_t));
+    const size_t o_elem = align16(o_astart + (F + 1) * sizeof(int32_t));
+    const size_t o_blk = align16(o_elem + N * sizeof(int32_t));
+    const size_t total = align16(o_blk + (N + 2) * sizeof(int32_t));
+    h->stage_in.ensure(total);
+    h->inbuf.ensure(total);
+    char *hb = h->stage_in.ptr;
+    double *pos = reinterpret_cast<double *>(hb + o_pos);
+    double *cells = reinterpret_cast<double *>(hb + o_cells);
+    ta::NlGrid *grids = reinterpret_cast<ta::NlGrid *>(hb + o_grids);
+    int32_t *species = reinterpret_cast<int32_t *>(hb + o_species);
+    int32_t *foa = reinterpret_cast<int32_t *>(hb + o_foa);
+    int32_t *astart = reinterpret_cast<int32_t *>(hb + o_astart);
+    int32_t *elem_atoms = reinterpret_cast<int32_t *>(hb + o_elem);
     size_t a = 0;
+    astart[0] = 0;
     for (int f = 0; f < n_frames; ++f) {
       const ta_frame &fr = frames[f];
-      std::memcpy(&pos[3 * a], fr.positions, 3 * (size_t)fr.n_atoms * sizeof(double));
-      std::memcpy(&species[a], fr.species, (size_t)fr.n_atoms * sizeof(int32_t));
+      const size_t n = (size_t)fr.n_atoms;
+      if (n) {
+        std::memcpy(&pos[3 * a], fr.positions, 3 * n * sizeof(double));
+        std::memcpy(&species[a], fr.species, n * sizeof(int32_t));
+      }
       std::memcpy(&cells[9 * (size_t)f], fr.cell, 9 * sizeof(double));
-      a += fr.n_atoms;
+      for (size_t i = a; i < a + n; ++i) {
+        foa[i] = f;
+        if (species[i] < 0 || species[i] >= nel)
+          throw std::runtime_error("frame " + std::to_string(f) + ": species index out of range");
+        if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
+          throw std::runtime_error("frame " + std::to_string(f) + ": non-finite position");
+      }
+      a += n;
+      astart[f + 1] = (int32_t)a;
     }
-    auto put = [&](auto &buf, const auto &vec) {
-      buf.ensure(vec.size());
-      if (!vec.empty())
-        HIP_CHECK(hipMemcpyAsync(buf.ptr, vec.data(), vec.size() * sizeof(vec[0]),
-                                 hipMemcpyHostToDevice, h->stream));
-    };
-    put(h->pos, pos);
-    put(h->cells, cells);
-    put(h->species, species);
+    {  // atoms grouped by element for the batched MLP
+      std::vector<int32_t> count(nel + 1, 0);
+      for (size_t i = 0; i < N; ++i) count[species[i] + 1]++;
+      for (int e = 0; e < nel; ++e) count[e + 1] += count[e];
+      for (int e = 0; e <= nel; ++e) h->db.elem_start[e] = count[e];
+      std::vector<int32_t> fill(count.begin(), count.end() - 1);
+      for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
+    }
     // Neighbour list: on the device when every frame has >= 3 linked-cell bins along its
     // periodic axes (ta_nlist.hip), otherwise the host builder (ta_neighbor.cpp).
     const auto t_nl = std::chrono::steady_clock::now();
-    std::vector<ta::NlGrid> grids((size_t)n_frames);
     int n_bins = 0;
-    bool device_nl = N > 0 && N < (1u << 30) &&
-                     !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');
+    bool device_nl = N > 0 && !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');
     for (int f = 0; f < n_frames && device_nl; ++f) {
       device_nl = ta::nl_make_grid(frames[f], h->rmax, n_bins, grids[f]);
       if (device_nl) n_bins += ta::nl_bins(grids[f]);
       if (n_bins > (1 << 24)) device_nl = false;
     }
+    if (!device_nl) std::memset(static_cast<void *>(grids), 0, F * sizeof(ta::NlGrid));
+    // one upload for everything but blk_center (which needs the pair counts)
+    if (o_blk)
+      HIP_CHECK(hipMemcpyAsync(h->inbuf.ptr, hb, o_blk, hipMemcpyHostToDevice, h->stream));
+    char *db_ = h->inbuf.ptr;
+    h->db.n_frames = n_frames;
+    h->db.pos = reinterpret_cast<double *>(db_ + o_pos);
+    h->db.cells = reinterpret_cast<double *>(db_ + o_cells);
+    h->d_grids = reinterpret_cast<ta::NlGrid *>(db_ + o_grids);
+    h->db.species = reinterpret_cast<int32_t *>(db_ + o_species);
+    h->db.frame_of_atom = reinterpret_cast<int32_t *>(db_ + o_foa);
+    h->db.atom_start = reinterpret_cast<int32_t *>(db_ + o_astart);
+    h->db.elem_atoms = reinterpret_cast<int32_t *>(db_ + o_elem);
+    h->db.blk_center = reinterpret_cast<int32_t *>(db_ + o_blk);
     if (device_nl) {
-      a = 0;
-      for (int f = 0; f < n_frames; ++f) {
-        for (size_t i = a; i < a + (size_t)frames[f].n_atoms; ++i) {
-          if (species[i] < 0 || species[i] >= h->n_elements)
-            throw std::runtime_error("frame " + std::to_string(f) + ": species index out of range");
-          if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
-            throw std::runtime_error("frame " + std::to_string(f) + ": non-finite position");
-        }
-        a += frames[f].n_atoms;
-      }
-      build_pairs_on_device(h, n_frames, frames, grids, n_bins);
+      h->hp.atom_start.assign(astart, astart + F + 1);
+      h->hp.frame_of_atom.assign(foa, foa + N);
+      build_pairs_on_device(h, N, n_bins);
     } else {
       h->pairs_on_device = false;
-      ta::build_pairs(n_frames, frames, h->n_elements, h->rmax, h->hp);
+      ta::build_pairs(n_frames, frames, nel, h->rmax, h->hp);
     }
     double nl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nl).count();
-    // atoms grouped by element for the batched MLP
-    std::vector<int32_t> elem_atoms(N);
-    {
-      std::vector<int32_t> count(h->n_elements + 1, 0);
-      for (size_t i = 0; i < N; ++i) count[species[i] + 1]++;
-      for (int e = 0; e < h->n_elements; ++e) count[e + 1] += count[e];
-      for (int e = 0; e <= h->n_elements; ++e) h->db.elem_start[e] = count[e];
-      std::vector<int32_t> fill(count.begin(), count.end() - 1);
-      for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
-    }
-    h->db.pos = h->pos.ptr;
-    h->db.species = h->species.ptr;
     upload_batch(h);
+    const auto t_fill = std::chrono::steady_clock::now();
     if (h->pairs_on_device) {
-      const auto t_fill = std::chrono::steady_clock::now();
       fill_pairs_on_device(h);
-      HIP_CHECK(hipStreamSynchronize(h->stream));
-      nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
+      // "reverse pair missing" counter, read after the synchronisation below
+      HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 4 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, h->stream));
     }
     // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
     h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && h->n_elements <= 3 &&
@@ -772,32 +804,29 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     }
     h->use_v3 = h->use_v2 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
                 std::getenv("TA_USE_V3")[0] == '1';
-    std::vector<int32_t> blk;
-    if (h->use_v2) {
-      blk.push_back(0);
-      int32_t load = 0, ncent = 0;
-      for (size_t i = 0; i < N; ++i) {
-        const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
-        if (load + cnt > cap || ncent >= ta::kMaxCentersPerBlock) {
-          blk.push_back((int32_t)i);
-          load = 0;
-          ncent = 0;
+    {
+      int32_t *blk = reinterpret_cast<int32_t *>(hb + o_blk);
+      int nb = 0;
+      if (h->use_v2 && N) {
+        blk[nb++] = 0;
+        int32_t load = 0, ncent = 0;
+        for (size_t i = 0; i < N; ++i) {
+          const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
+          if (load + cnt > cap || ncent >= ta::kMaxCentersPerBlock) {
+            blk[nb++] = (int32_t)i;
+            load = 0;
+            ncent = 0;
+          }
+          load += cnt;
+          ++ncent;
         }
-        load += cnt;
-        ++ncent;
+        blk[nb++] = (int32_t)N;
       }
-      if (N) blk.push_back((int32_t)N);
-      h->db.n_blk = (int)blk.size() - 1;
-    } else {
-      h->db.n_blk = 0;
+      h->db.n_blk = nb ? nb - 1 : 0;
+      if (nb)
+        HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
+                                 h->stream));
     }
-    put(h->elem_atoms, elem_atoms);
-    put(h->blk_center, blk);
-    h->db.blk_center = h->blk_center.ptr;
-    h->db.pos = h->pos.ptr;
-    h->db.cells = h->cells.ptr;
-    h->db.species = h->species.ptr;
-    h->db.elem_atoms = h->elem_atoms.ptr;
     if (h->kind == TA_MODEL_SF_MLP) {
       if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
         throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
@@ -811,11 +840,10 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     } else {
       ta::eam_ensure(h->eam, h->db);
     }
-    HIP_CHECK(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+    HIP_CHECK(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next call
     if (h->pairs_on_device) {
-      int32_t stats[8];
-      HIP_CHECK(hipMemcpy(stats, h->nl_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
-      if (stats[6] != 0)
+      nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
+      if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
         throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
     }
     h->have_batch = true;
@@ -858,18 +886,32 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, 
       throw std::invalid_argument("forces / virial requested but the last ta_compute did not produce them");
     if (descriptors && h->kind != TA_MODEL_SF_MLP)
       throw std::invalid_argument("descriptors are only defined for symmetry-function models");
-    if (energy && F)
-      HIP_CHECK(hipMemcpyAsync(energy, h->db.energy, F * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (forces && N)
-      HIP_CHECK(hipMemcpyAsync(forces, h->db.forces, 3 * N * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (virial && F)
-      HIP_CHECK(hipMemcpyAsync(virial, h->db.virial, 9 * F * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (atomic && N)
-      HIP_CHECK(hipMemcpyAsync(atomic, h->db.eatom, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    // one download of the span of [energy F | virial 9F | atomic N | forces 3N] that was asked for
+    size_t lo = (size_t)-1, hi = 0;
+    auto need = [&](bool on, size_t off, size_t n) {
+      if (!on || n == 0) return;
+      lo = std::min(lo, off);
+      hi = std::max(hi, off + n);
+    };
+    need(energy != nullptr, 0, F);
+    need(virial != nullptr, F, 9 * F);
+    need(atomic != nullptr, 10 * F, N);
+    need(forces != nullptr, 10 * F + N, 3 * N);
+    const double *stage = nullptr;
+    if (hi > lo) {
+      h->stage_out.ensure((hi - lo) * sizeof(double));
+      stage = reinterpret_cast<const double *>(h->stage_out.ptr) - lo;
+      HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->results.ptr + lo, (hi - lo) * sizeof(double),
+                               hipMemcpyDeviceToHost, s));
+    }
     if (descriptors && N)
       HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double),
                                hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (energy && F) std::memcpy(energy, stage, F * sizeof(double));
+    if (virial && F) std::memcpy(virial, stage + F, 9 * F * sizeof(double));
+    if (atomic && N) std::memcpy(atomic, stage + 10 * F, N * sizeof(double));
+    if (forces && N) std::memcpy(forces, stage + 10 * F + N, 3 * N * sizeof(double));
   });
 }
 

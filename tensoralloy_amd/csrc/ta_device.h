@@ -153,6 +153,13 @@ struct NlGrid {  // linked-cell grid of one frame, in fractional coordinates
   int32_t bin_offset;  // first bin of this frame in the batch-wide bin arrays
   int32_t pad_;
 };
+struct NlRec {  // one atom, stored in bin order
+  double x, y, z;
+  int32_t wx, wy, wz;  // integer wrap into the cell
+  int32_t j;           // atom index
+  int32_t sp;          // species
+  int32_t pad_;
+};
 struct NlWork {  // device work buffers, sized by the caller
   int32_t *wrap;        // [3 N] integer wrap of each atom into its cell
   int32_t *binid;       // [N]
@@ -160,6 +167,7 @@ struct NlWork {  // device work buffers, sized by the caller
   int32_t *bin_start;   // [n_bins + 1]
   int32_t *bin_cursor;  // [n_bins + 1]
   int32_t *bin_atoms;   // [N]
+  NlRec *recs;          // [N]
   int32_t *counts;      // [N (nel + 1) + 1]
   int32_t *seg_start;   // [N (nel + 1) + 1]
   // stats[0] = number of triples; as int32: [2] nnl_max, [4] number of pairs, [6] pairs

@@ -13,8 +13,8 @@
 // neighbouring bins are distinct and each carries one image shift; frames
 // that do not qualify (cells thinner than 3 rc) are built on the host.
 //
-// Kernels: bin_atoms (wrap, bin id, histogram) -> scan_bins -> fill_bins (+ per-bin
-// sort by atom index: deterministic order) -> count_pairs (one wavefront per
+// Kernels: bin_atoms (wrap, bin id, histogram) -> scan -> fill_bins -> gather_bins (records
+// in bin order, atoms of a bin by index: deterministic) -> count_pairs (one wavefront per
 // atom, ballot + popcount per neighbour species) -> scan_counts -> fill_pairs
 // (same traversal, slots from the running popcounts) -> reverse_pairs.
 #include <hip/hip_runtime.h>
@@ -95,32 +95,43 @@ __global__ __launch_bounds__(kBlock) void fill_bins_kernel(int n_atoms, const in
   bin_atoms[bin_start[id] + atomicAdd(&bin_cursor[id], 1)] = i;
 }
 
-// insertion sort of every bin's atoms by index: removes the atomics' ordering noise
-__global__ __launch_bounds__(kBlock) void sort_bins_kernel(int n_bins, const int32_t *bin_start,
-                                                           int32_t *bin_atoms) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n_bins) return;
-  const int lo = bin_start[k], hi = bin_start[k + 1];
-  for (int a = lo + 1; a < hi; ++a) {
-    const int v = bin_atoms[a];
-    int c = a - 1;
-    while (c >= lo && bin_atoms[c] > v) {
-      bin_atoms[c + 1] = bin_atoms[c];
-      --c;
-    }
-    bin_atoms[c + 1] = v;
-  }
+// Atoms of every bin in index order (rank = members with a smaller index: removes the
+// atomics' ordering noise), gathered into one record each so that the pair kernels read
+// their candidates contiguously.
+__global__ __launch_bounds__(kBlock) void gather_bins_kernel(int n_atoms, const double *pos,
+                                                             const int32_t *species,
+                                                             const int32_t *wrap, const int32_t *binid,
+                                                             const int32_t *bin_start,
+                                                             const int32_t *bin_atoms, NlRec *recs) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int bin = binid[i];
+  const int lo = bin_start[bin], hi = bin_start[bin + 1];
+  int rank = 0;
+  for (int c = lo; c < hi; ++c) rank += bin_atoms[c] < i;
+  NlRec r;
+  r.x = pos[3 * (size_t)i];
+  r.y = pos[3 * (size_t)i + 1];
+  r.z = pos[3 * (size_t)i + 2];
+  r.wx = wrap[3 * (size_t)i];
+  r.wy = wrap[3 * (size_t)i + 1];
+  r.wz = wrap[3 * (size_t)i + 2];
+  r.j = i;
+  r.sp = species[i];
+  r.pad_ = 0;
+  recs[lo + rank] = r;
 }
 
-// One wavefront per centre atom walks its 27 neighbouring bins. MODE 0 counts
-// the neighbours per species, MODE 1 writes them.
+// One wavefront per centre atom. Lanes 0..26 look up the 27 neighbouring bins (range of
+// records + image shift), the ranges are concatenated by a prefix sum, and the wavefront then
+// sweeps the concatenation 64 candidates at a time. MODE 0 counts the neighbours per
+// species, MODE 1 writes them (same traversal, slots from the running popcounts).
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void pairs_kernel(int n_atoms, int nel, double rmax,
-                                                       const double *pos, const int32_t *species,
-                                                       const int32_t *frame_of_atom,
+                                                       const double *pos, const int32_t *frame_of_atom,
                                                        const NlGrid *grids, const int32_t *wrap,
                                                        const int32_t *binid, const int32_t *bin_start,
-                                                       const int32_t *bin_atoms, int32_t *counts,
+                                                       const NlRec *recs, int32_t *counts,
                                                        const int32_t *seg_start, int32_t *pair_i,
                                                        int32_t *pair_j, int32_t *pair_shift) {
   const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -131,65 +142,79 @@ __global__ __launch_bounds__(kBlock) void pairs_kernel(int n_atoms, int nel, dou
   const int bz = local % g.nb[2], by = (local / g.nb[2]) % g.nb[1], bx = local / (g.nb[2] * g.nb[1]);
   const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
   const int wix = wrap[3 * (size_t)i], wiy = wrap[3 * (size_t)i + 1], wiz = wrap[3 * (size_t)i + 2];
+
+  // lane k < 27: neighbouring bin (k / 9 - 1, k / 3 % 3 - 1, k % 3 - 1)
+  int lo = 0, len = 0, code = 13;
+  if (lane < 27) {
+    int c[3] = {bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1};
+    int sh[3] = {0, 0, 0};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (c[a] < 0 || c[a] >= g.nb[a]) {
+        if (!g.pbc[a]) ok = false;
+        sh[a] = c[a] < 0 ? -1 : 1;
+        c[a] -= sh[a] * g.nb[a];
+      }
+    }
+    if (ok) {
+      const int bin = g.bin_offset + (c[0] * g.nb[1] + c[1]) * g.nb[2] + c[2];
+      lo = bin_start[bin];
+      len = bin_start[bin + 1] - lo;
+      code = (sh[0] + 1) * 9 + (sh[1] + 1) * 3 + (sh[2] + 1);
+    }
+  }
+  // exclusive prefix of len over the lanes
+  int incl = len;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int excl = incl - len;
+  const int total = __builtin_amdgcn_readlane(incl, 26);
+  const int delta = lo - excl;  // record index = delta[k] + flat index
+
   int running[kMaxElements];
 #pragma unroll
   for (int s = 0; s < kMaxElements; ++s) running[s] = 0;
   const int32_t *seg = seg_start ? seg_start + (size_t)i * (nel + 1) : nullptr;
 
-  for (int dx = -1; dx <= 1; ++dx) {
-    int cx = bx + dx, sx = 0;
-    if (cx < 0 || cx >= g.nb[0]) {
-      if (!g.pbc[0]) continue;
-      sx = cx < 0 ? -1 : 1;
-      cx -= sx * g.nb[0];
+  for (int base = 0; base < total; base += 64) {
+    const int f = base + lane;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 27; ++q) k += f >= __builtin_amdgcn_readlane(excl, q);
+    const int dl = __shfl(delta, k);
+    const int cd = __shfl(code, k);
+    bool valid = false;
+    int j = 0, Sx = 0, Sy = 0, Sz = 0, sj = 0;
+    if (f < total) {
+      const NlRec r = recs[dl + f];
+      const int sx = cd / 9 - 1, sy = (cd / 3) % 3 - 1, sz = cd % 3 - 1;
+      j = r.j;
+      sj = r.sp;
+      // shift relative to the positions as given: S = s - w_j + w_i
+      Sx = sx - r.wx + wix;
+      Sy = sy - r.wy + wiy;
+      Sz = sz - r.wz + wiz;
+      const double Dx = r.x - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
+      const double Dy = r.y - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
+      const double Dz = r.z - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
+      const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
+      valid = (sqrt(r2) < rmax) && !(j == i && cd == 13);
     }
-    for (int dy = -1; dy <= 1; ++dy) {
-      int cy = by + dy, sy = 0;
-      if (cy < 0 || cy >= g.nb[1]) {
-        if (!g.pbc[1]) continue;
-        sy = cy < 0 ? -1 : 1;
-        cy -= sy * g.nb[1];
+    for (int s = 0; s < nel; ++s) {
+      const unsigned long long m = __ballot(valid && sj == s);
+      if (MODE == 1 && valid && sj == s) {
+        const int slot = seg[s] + running[s] + __popcll(m & ((1ull << lane) - 1ull));
+        pair_i[slot] = i;
+        pair_j[slot] = j;
+        pair_shift[3 * (size_t)slot] = Sx;
+        pair_shift[3 * (size_t)slot + 1] = Sy;
+        pair_shift[3 * (size_t)slot + 2] = Sz;
       }
-      for (int dz = -1; dz <= 1; ++dz) {
-        int cz = bz + dz, sz = 0;
-        if (cz < 0 || cz >= g.nb[2]) {
-          if (!g.pbc[2]) continue;
-          sz = cz < 0 ? -1 : 1;
-          cz -= sz * g.nb[2];
-        }
-        const int bin = g.bin_offset + (cx * g.nb[1] + cy) * g.nb[2] + cz;
-        const int lo = bin_start[bin], hi = bin_start[bin + 1];
-        for (int c0 = lo; c0 < hi; c0 += 64) {
-          const int c = c0 + lane;
-          bool valid = false;
-          int j = 0, Sx = 0, Sy = 0, Sz = 0, sj = 0;
-          if (c < hi) {
-            j = bin_atoms[c];
-            // shift relative to the positions as given: S = s - w_j + w_i
-            Sx = sx - wrap[3 * (size_t)j] + wix;
-            Sy = sy - wrap[3 * (size_t)j + 1] + wiy;
-            Sz = sz - wrap[3 * (size_t)j + 2] + wiz;
-            const double Dx = pos[3 * (size_t)j] - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
-            const double Dy = pos[3 * (size_t)j + 1] - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
-            const double Dz = pos[3 * (size_t)j + 2] - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
-            const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
-            valid = (sqrt(r2) < rmax) && !(j == i && sx == 0 && sy == 0 && sz == 0);
-            sj = species[j];
-          }
-          for (int s = 0; s < nel; ++s) {
-            const unsigned long long m = __ballot(valid && sj == s);
-            if (MODE == 1 && valid && sj == s) {
-              const int slot = seg[s] + running[s] + __popcll(m & ((1ull << lane) - 1ull));
-              pair_i[slot] = i;
-              pair_j[slot] = j;
-              pair_shift[3 * (size_t)slot] = Sx;
-              pair_shift[3 * (size_t)slot + 1] = Sy;
-              pair_shift[3 * (size_t)slot + 2] = Sz;
-            }
-            running[s] += __popcll(m);
-          }
-        }
-      }
+      running[s] += __popcll(m);
     }
   }
   if (MODE == 0 && lane == 0) {
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void finish_starts_kernel(int n_atoms, int 
   atomicMax(nnl_max, n);
 }
 
-// (i -> j, S) <-> (j -> i, -S): search j's segment of species(i)
+// (i -> j, S) <-> (j -> i, -S): eight lanes search j's segment of species(i)
 __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, int nel,
                                                                const int32_t *species,
                                                                const int32_t *seg_start,
@@ -225,22 +250,39 @@ __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, 
                                                                const int32_t *pair_j,
                                                                const int32_t *pair_shift,
                                                                int32_t *pair_rev, int32_t *n_missing) {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n_pairs) return;
-  const int i = pair_i[p], j = pair_j[p];
-  const int sx = pair_shift[3 * p], sy = pair_shift[3 * p + 1], sz = pair_shift[3 * p + 2];
-  const int32_t *seg = seg_start + (size_t)j * (nel + 1);
-  const int si = species[i];
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t p = tid >> 3;
+  const int sub = (int)(tid & 7);
   int found = -1;
-  for (int q = seg[si]; q < seg[si + 1]; ++q) {
-    if (pair_j[q] == i && pair_shift[3 * (size_t)q] == -sx && pair_shift[3 * (size_t)q + 1] == -sy &&
-        pair_shift[3 * (size_t)q + 2] == -sz) {
-      found = q;
-      break;
+  if (p < n_pairs) {
+    const int i = pair_i[p], j = pair_j[p];
+    const int sx = pair_shift[3 * p], sy = pair_shift[3 * p + 1], sz = pair_shift[3 * p + 2];
+    const int32_t *seg = seg_start + (size_t)j * (nel + 1);
+    const int si = species[i];
+    const int hi = seg[si + 1];
+    // four independent loads in flight per lane: the search is latency-bound
+    for (int q0 = seg[si] + sub; q0 < hi; q0 += 32) {
+      int qq[4], jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        qq[u] = min(q0 + 8 * u, hi - 1);
+        jj[u] = pair_j[qq[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = qq[u];
+        if (jj[u] == i && pair_shift[3 * (size_t)q] == -sx && pair_shift[3 * (size_t)q + 1] == -sy &&
+            pair_shift[3 * (size_t)q + 2] == -sz)
+          found = q;
+      }
     }
   }
-  pair_rev[p] = found;
-  if (found < 0) atomicAdd(n_missing, 1);
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) found = max(found, __shfl_xor(found, off));
+  if (p < n_pairs && sub == 0) {
+    pair_rev[p] = found;
+    if (found < 0) atomicAdd(n_missing, 1);
+  }
 }
 
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -322,11 +364,11 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
                      (int32_t *)nullptr);
   hipLaunchKernelGGL(fill_bins_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms,
                      w.binid, w.bin_start, w.bin_cursor, w.bin_atoms);
-  hipLaunchKernelGGL(sort_bins_kernel, dim3(nblk(n_bins, kBlock)), dim3(kBlock), 0, s, n_bins,
-                     w.bin_start, w.bin_atoms);
+  hipLaunchKernelGGL(gather_bins_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms,
+                     pos, species, w.wrap, w.binid, w.bin_start, w.bin_atoms, w.recs);
   hipLaunchKernelGGL(pairs_kernel<0>, dim3(nblk((int64_t)n_atoms * 64, kBlock)), dim3(kBlock), 0, s,
-                     n_atoms, nel, rmax, pos, species, frame_of_atom, grids, w.wrap, w.binid,
-                     w.bin_start, w.bin_atoms, w.counts, (const int32_t *)nullptr, (int32_t *)nullptr,
+                     n_atoms, nel, rmax, pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start,
+                     w.recs, w.counts, (const int32_t *)nullptr, (int32_t *)nullptr,
                      (int32_t *)nullptr, (int32_t *)nullptr);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), w.counts,
                      w.seg_start, reinterpret_cast<int32_t *>(w.stats) + 4);
@@ -341,11 +383,10 @@ void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *p
              hipStream_t s) {
   if (n_atoms == 0) return;
   hipLaunchKernelGGL(pairs_kernel<1>, dim3(nblk((int64_t)n_atoms * 64, kBlock)), dim3(kBlock), 0, s,
-                     n_atoms, nel, rmax, pos, species, frame_of_atom, grids, w.wrap, w.binid,
-                     w.bin_start, w.bin_atoms, (int32_t *)nullptr, w.seg_start, pair_i, pair_j,
-                     pair_shift);
+                     n_atoms, nel, rmax, pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start,
+                     w.recs, (int32_t *)nullptr, w.seg_start, pair_i, pair_j, pair_shift);
   if (n_pairs > 0)
-    hipLaunchKernelGGL(reverse_pairs_kernel, dim3(nblk(n_pairs, kBlock)), dim3(kBlock), 0, s, n_pairs,
+    hipLaunchKernelGGL(reverse_pairs_kernel, dim3(nblk(n_pairs * 8, kBlock)), dim3(kBlock), 0, s, n_pairs,
                        nel, species, w.seg_start, pair_i, pair_j, pair_shift, pair_rev,
                        reinterpret_cast<int32_t *>(w.stats) + 6);
 }

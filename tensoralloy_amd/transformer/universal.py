@@ -61,6 +61,8 @@ class UniversalTransformer:
         self._symmetric = symmetric
         self._use_computed_dists = use_computed_dists
         self._vap_transformers: Dict[str, VirtualAtomMap] = {}
+        self._vap_by_numbers: Dict[bytes, VirtualAtomMap] = {}
+        self._z_lookup = None
 
     # ---- reference-compatible properties ----------------------------------
     def as_dict(self) -> Dict:
@@ -128,6 +130,12 @@ class UniversalTransformer:
     # ---- VAP --------------------------------------------------------------
     def get_vap_transformer(self, atoms) -> VirtualAtomMap:
         """One `VirtualAtomMap` per reduced formula (base.py:199-226)."""
+        # same atomic numbers in the same order <=> same reduced formula: skip rebuilding
+        # the formula string (1 ms for 4000 atoms) on every MD step
+        numbers = getattr(atoms, "numbers", None)
+        key = numbers.tobytes() if isinstance(numbers, np.ndarray) else None
+        if key is not None and key in self._vap_by_numbers:
+            return self._vap_by_numbers[key]
         formula = atoms.get_chemical_formula(mode="reduce")
         if formula not in self._vap_transformers:
             symbols = atoms.get_chemical_symbols()
@@ -136,11 +144,29 @@ class UniversalTransformer:
             for element in self._elements:
                 max_occurs[element] = max(1, counter[element])
             self._vap_transformers[formula] = VirtualAtomMap(max_occurs, symbols)
+        if key is not None:
+            if len(self._vap_by_numbers) > 64:
+                self._vap_by_numbers.clear()
+            self._vap_by_numbers[key] = self._vap_transformers[formula]
         return self._vap_transformers[formula]
 
     # ---- species / neighbour helpers ----------------------------------------
     def species_indices(self, atoms) -> np.ndarray:
         """Index of every atom's element in the sorted element list."""
+        numbers = getattr(atoms, "numbers", None)
+        if isinstance(numbers, np.ndarray):
+            if self._z_lookup is None:
+                from ..atoms import chemical_symbols
+                table = np.full(len(chemical_symbols), -1, dtype=np.int32)
+                for k, e in enumerate(self._elements):
+                    table[chemical_symbols.index(e)] = k
+                self._z_lookup = table
+            idx = self._z_lookup[numbers]
+            if len(idx) and idx.min() < 0:
+                from ..atoms import chemical_symbols
+                bad = chemical_symbols[int(numbers[np.argmin(idx)])]
+                raise ValueError(f"element {bad} is not supported by this model")
+            return idx
         lookup = {e: k for k, e in enumerate(self._elements)}
         try:
             return np.array([lookup[s] for s in atoms.get_chemical_symbols()], dtype=np.int32)
