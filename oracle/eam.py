@@ -116,6 +116,39 @@ def zjw04_embed(rho, p):
     return F, dF
 
 
+def zjw04xc_embed(rho, p):
+    """Zjw04xc / Zjw04uxc embedding: the three Zjw04 branches blended with
+    c1 = sigmoid(2 (rho_n - rho)), c3 = sigmoid(2 (rho - rho_0)), c2 = 1 - c1 - c3, and
+    x = rho / rho_s + 1e-8 in the third branch (reference zjw04.py:482-543)."""
+    rho = np.asarray(rho, dtype=np.float64)
+    rho_n, rho_0 = 0.85 * p["rho_e"], 1.15 * p["rho_e"]
+    x1 = rho / rho_n - 1.0
+    y1 = p["Fn0"] + p["Fn1"] * x1 + p["Fn2"] * x1 ** 2 + p["Fn3"] * x1 ** 3
+    d1 = (p["Fn1"] + 2 * p["Fn2"] * x1 + 3 * p["Fn3"] * x1 ** 2) / rho_n
+    x2 = rho / p["rho_e"] - 1.0
+    y2 = p["F0"] + p["F1"] * x2 + p["F2"] * x2 ** 2 + p["F3"] * x2 ** 3
+    d2 = (p["F1"] + 2 * p["F2"] * x2 + 3 * p["F3"] * x2 ** 2) / p["rho_e"]
+    x3 = rho / p["rho_s"] + 1e-8
+    lnx = np.log(x3)
+    y3 = p["Fe"] * (1.0 - p["eta"] * lnx) * x3 ** p["eta"]
+    d3 = -p["Fe"] * p["eta"] ** 2 * lnx * x3 ** (p["eta"] - 1.0) / p["rho_s"]
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    c1, c3 = sig(2.0 * (rho_n - rho)), sig(2.0 * (rho - rho_0))
+    c2 = 1.0 - (c1 + c3)
+    dc1, dc3 = -2.0 * c1 * (1.0 - c1), 2.0 * c3 * (1.0 - c3)
+    F = c1 * y1 + c2 * y2 + c3 * y3
+    dF = c1 * d1 + c2 * d2 + c3 * d3 + dc1 * y1 - (dc1 + dc3) * y2 + dc3 * y3
+    return F, dF
+
+
+def zjw04xcp_phi_ab(r, q):
+    """Cross-element phi of Zjw04xcp: the AA form with the pair's own constants
+    (reference zjw04.py:676-693)."""
+    fa, dfa = zhou_exp(r, q["A"], q["alpha"], q["kappa"], q["r_eq"])
+    fb, dfb = zhou_exp(r, q["B"], q["beta"], q["lamda"], q["r_eq"])
+    return fa - fb, dfa - dfb
+
+
 def mishin_polar(r, p1, p2, p3, rc, h):
     """(p1 exp(-p2 r) + p3) psi((r - rc)/h), psi(x) = x^4/(1+x^4) for x < 0 else 0."""
     z = (r - rc) / h
@@ -134,11 +167,13 @@ class EamModel:
     """elements (sorted), rcut, per-element Zjw04 parameters, optional ADP pair parameters
     keyed by the sorted pair 'AB' (dict with d1..q3, h, rc)."""
 
-    def __init__(self, elements, rcut, params=None, adp=None):
+    def __init__(self, elements, rcut, params=None, adp=None, blended_embed=False, phi_pairs=None):
         self.elements = sorted(set(elements))
         self.rcut = float(rcut)
         self.params = params or {e: dict(ZJW04[e]) for e in self.elements}
         self.adp = adp  # {'NiNi': {...}} or None
+        self.blended_embed = bool(blended_embed)  # Zjw04xc / uxc / xcp embedding
+        self.phi_pairs = phi_pairs or {}          # Zjw04xcp: {'MoNi': {r_eq, A, B, ...}}
 
 
 def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
@@ -163,7 +198,11 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
         rho_pair[m], drho_pair[m] = zjw04_rho(r[m], model.params[eb])  # neighbour's element, alloy.py:176
         for a, ea in enumerate(els):
             mm = m & (si == a)
-            phi_pair[mm], dphi_pair[mm] = zjw04_phi(r[mm], model.params[ea], model.params[eb], a == b)
+            key = "".join(sorted([ea, eb]))
+            if a != b and key in model.phi_pairs:
+                phi_pair[mm], dphi_pair[mm] = zjw04xcp_phi_ab(r[mm], model.phi_pairs[key])
+            else:
+                phi_pair[mm], dphi_pair[mm] = zjw04_phi(r[mm], model.params[ea], model.params[eb], a == b)
     rho = np.zeros(N)
     np.add.at(rho, pi, rho_pair)
     phisum = np.zeros(N)
@@ -172,7 +211,8 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
     dF = np.zeros(N)
     for a, ea in enumerate(els):
         m = spec == a
-        F[m], dF[m] = zjw04_embed(rho[m], model.params[ea])
+        embed = zjw04xc_embed if model.blended_embed else zjw04_embed
+        F[m], dF[m] = embed(rho[m], model.params[ea])
     atomic = F + 0.5 * phisum
     # dE/dD of the directed pair (i -> j): centre i's terms only
     s = dF[pi] * drho_pair + 0.5 * dphi_pair

@@ -7,6 +7,8 @@
 //   AdpNN._build_dipole_nn          reference nn/eam/adp.py:315-392
 //   AdpNN._build_quadrupole_nn      reference nn/eam/adp.py:394-498
 //   Zjw04.rho / phi / embed         reference nn/eam/potentials/zjw04.py:187-389
+//   Zjw04xc.embed (sigmoid-blended) reference nn/eam/potentials/zjw04.py:440-550 (also Zjw04uxc)
+//   Zjw04xcp.phi (own AB constants) reference nn/eam/potentials/zjw04.py:642-696
 //   mishin_polar / mishin_cutoff    reference nn/eam/potentials/generic.py:52-84
 // and the tf.gradients that give forces and virial (nn/basic.py:277-331).
 //
@@ -37,8 +39,11 @@ constexpr int kMaxPairTypes = kMaxEamElements * (kMaxEamElements + 1) / 2;
 struct EamParams {
   int nel;
   int adp;
-  double el[kMaxEamElements][20];  // ZJW04_KEYS order (tensoralloy_amd/eam.py)
-  double pair[kMaxPairTypes][8];  // d1 d2 d3 q1 q2 q3 h rc
+  int embed_kind[kMaxEamElements];  // 0: piecewise (Zjw04), 1: sigmoid-blended (Zjw04xc)
+  int phi_kind[kMaxPairTypes];      // 0: Zjw04 (AA, or AB by density mixing), 1: own constants (Zjw04xcp)
+  double el[kMaxEamElements][20];   // ZJW04_KEYS order (tensoralloy_amd/eam.py)
+  double phi[kMaxPairTypes][7];     // r_eq A B alpha beta kappa lamda of a Zjw04xcp cross term
+  double pair[kMaxPairTypes][8];    // d1 d2 d3 q1 q2 q3 h rc
 };
 
 enum { R_EQ, F_EQ, RHO_E, RHO_S, ALPHA, BETA, PA, PB, KAPPA, LAMDA, FN0, FN1, FN2, FN3, F0, F1, F2, F3, ETA, FE };
@@ -77,6 +82,16 @@ __device__ __forceinline__ void zjw_phi(const EamParams &P, int sa, int sb, doub
     zjw_phi_aa(P.el[sa], r, f, df);
     return;
   }
+  const int pt = pair_type(sa, sb, P.nel);
+  if (P.phi_kind[pt] == 1) {  // zjw04.py:689-693
+    const double *q = P.phi[pt];
+    double fa, dfa, fb, dfb;
+    zhou_exp(r, q[1], q[3], q[5], q[0], fa, dfa);
+    zhou_exp(r, q[2], q[4], q[6], q[0], fb, dfb);
+    f = fa - fb;
+    df = dfa - dfb;
+    return;
+  }
   double pha, dpha, phb, dphb, ra, dra, rb, drb;
   zjw_phi_aa(P.el[sa], r, pha, dpha);
   zjw_phi_aa(P.el[sb], r, phb, dphb);
@@ -90,8 +105,30 @@ __device__ __forceinline__ void zjw_phi(const EamParams &P, int sa, int sb, doub
 }
 
 // piecewise embedding energy, thresholds 0.85 rho_e and 1.15 rho_e (zjw04.py:319-386)
-__device__ __forceinline__ void zjw_embed(const double *p, double rho, double &F, double &dF) {
+__device__ __forceinline__ void zjw_embed(const double *p, int kind, double rho, double &F,
+                                          double &dF) {
   const double rho_n = 0.85 * p[RHO_E], rho_0 = 1.15 * p[RHO_E];
+  if (kind == 1) {
+    // Zjw04xc: the three branches blended by sigmoids of width 1/2 (zjw04.py:482-543)
+    const double x1 = rho / rho_n - 1.0;
+    const double y1 = p[FN0] + x1 * (p[FN1] + x1 * (p[FN2] + x1 * p[FN3]));
+    const double d1 = (p[FN1] + x1 * (2.0 * p[FN2] + 3.0 * p[FN3] * x1)) / rho_n;
+    const double x2 = rho / p[RHO_E] - 1.0;
+    const double y2 = p[F0] + x2 * (p[F1] + x2 * (p[F2] + x2 * p[F3]));
+    const double d2 = (p[F1] + x2 * (2.0 * p[F2] + 3.0 * p[F3] * x2)) / p[RHO_E];
+    const double x3 = rho / p[RHO_S] + 1e-8;
+    const double lnx = log(x3);
+    const double xe = pow(x3, p[ETA]);
+    const double y3 = p[FE] * (1.0 - p[ETA] * lnx) * xe;
+    const double d3 = -p[FE] * p[ETA] * p[ETA] * lnx * xe / x3 / p[RHO_S];
+    const double c1 = 1.0 / (1.0 + ta_exp(-2.0 * (rho_n - rho)));
+    const double c3 = 1.0 / (1.0 + ta_exp(-2.0 * (rho - rho_0)));
+    const double c2 = 1.0 - (c1 + c3);
+    const double dc1 = -2.0 * c1 * (1.0 - c1), dc3 = 2.0 * c3 * (1.0 - c3);
+    F = c1 * y1 + c2 * y2 + c3 * y3;
+    dF = c1 * d1 + c2 * d2 + c3 * d3 + dc1 * y1 - (dc1 + dc3) * y2 + dc3 * y3;
+    return;
+  }
   if (rho < rho_n) {
     const double x = rho / rho_n - 1.0;
     F = p[FN0] + x * (p[FN1] + x * (p[FN2] + x * p[FN3]));
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
   phis = wave_sum(phis);
   if (lane == 0) {
     double F, d;
-    zjw_embed(P.el[sA], rho, F, d);
+    zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
     b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
     dF[i] = d;
   }
@@ -248,7 +285,8 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   const int nel = m->n_elements;
   const bool adp = m->kind == TA_MODEL_EAM_ADP;
   const int npair = nel * (nel + 1) / 2;
-  const int need = nel * 20 + (adp ? npair * 8 : 0);
+  // per element 20 Zjw04 constants + embed kind; per pair phi kind + 7 constants; ADP: + 8 per pair
+  const int need = nel * 21 + npair * 8 + (adp ? npair * 8 : 0);
   if (!m->eam_params || m->n_eam_params != need) {
     err = "eam_params must hold " + std::to_string(need) + " doubles for this model";
     return nullptr;
@@ -265,10 +303,24 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   std::memset(&e->p, 0, sizeof(e->p));
   e->p.nel = nel;
   e->p.adp = adp ? 1 : 0;
-  for (int k = 0; k < nel; ++k)
-    for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 20 + c];
+  for (int k = 0; k < nel; ++k) {
+    for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 21 + c];
+    e->p.embed_kind[k] = m->eam_params[k * 21 + 20] != 0.0 ? 1 : 0;
+  }
+  const double *pp = m->eam_params + nel * 21;
   for (int k = 0; k < npair; ++k) {
-    for (int c = 0; c < 8; ++c) e->p.pair[k][c] = adp ? m->eam_params[nel * 20 + k * 8 + c] : 0.0;
+    e->p.phi_kind[k] = pp[k * 8] != 0.0 ? 1 : 0;
+    for (int c = 0; c < 7; ++c) e->p.phi[k][c] = pp[k * 8 + 1 + c];
+    if (e->p.phi_kind[k] == 1 && !(e->p.phi[k][0] > 0.0)) {
+      delete e;
+      err = "r_eq of a zjw04xcp pair term must be positive";
+      return nullptr;
+    }
+    if (e->p.phi_kind[k] == 0) e->p.phi[k][0] = 1.0;
+  }
+  pp += npair * 8;
+  for (int k = 0; k < npair; ++k) {
+    for (int c = 0; c < 8; ++c) e->p.pair[k][c] = adp ? pp[k * 8 + c] : 0.0;
     if (!adp || e->p.pair[k][6] == 0.0) e->p.pair[k][6] = 1.0;  // h: avoid 0/0 for absent terms
   }
   for (int k = 0; k < nel; ++k)

@@ -5,16 +5,19 @@ analytic-potential hot path:
   EamAlloyNN  <- reference tensoralloy/nn/eam/alloy.py:24-127 (+ EamNN, eam.py:78-130)
   AdpNN       <- reference tensoralloy/nn/eam/adp.py (dipole / quadrupole terms)
 
-Supported potentials (the ones BASELINE.json config 4 names): `zjw04` for
-rho / embed / phi (nn/eam/potentials/zjw04.py) and `mishinh` for ADP dipole /
-quadrupole (nn/eam/potentials/mishin.py:269-315). "nn" potentials (MLP-based
-rho / phi / embed) and the other empirical parameterisations are out of scope
-and raise `ValueError`.
+Supported potentials: the Zhou-Johnson-Wadley family for rho / embed / phi --
+`zjw04` (nn/eam/potentials/zjw04.py:155-412), `zjw04xc` / `zjw04uxc` (sigmoid-
+blended embedding, :415-568; the two differ only in which constants are
+trainable) and `zjw04xcp` (own constants for cross-element phi, :571-696) -- and
+`mishinh` for the ADP dipole / quadrupole (nn/eam/potentials/mishin.py:269-315).
+One family per model. "nn" potentials (MLP-based rho / phi / embed) and the other
+empirical parameterisations are out of scope and raise `ValueError`.
 
 Flat parameter block handed to the C ABI (`ta_model_desc.eam_params`):
-  per element (sorted), 20 doubles in `ZJW04_KEYS` order;
-  for ADP, per unordered element pair (a <= b, row-major upper triangle),
-  8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = no angular term).
+  per element (sorted): 20 doubles in `ZJW04_KEYS` order + embed kind (0 / 1);
+  per unordered element pair (a <= b, row-major upper triangle): phi kind
+  (0 = Zjw04, 1 = Zjw04xcp constants) + [r_eq, A, B, alpha, beta, kappa, lamda];
+  for ADP, per pair: 8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = none).
 """
 from __future__ import annotations
 
@@ -46,6 +49,24 @@ ZJW04_DEFAULTS = {
     "W": [2.74084, 3.48734, 37.234847, 37.234847, 8.900114, 4.746728, 0.882435, 1.394592, 0.139209, 0.278417, -4.946281, -0.148818, 0.365057, -4.432406, -4.96, 0.0, 0.661935, 0.348147, -0.582714, -4.961306],
     "Ta": [2.860082, 3.086341, 33.787168, 33.787168, 8.489528, 4.527748, 0.611679, 1.032101, 0.176977, 0.353954, -5.103845, -0.405524, 1.112997, -3.585325, -5.14, 0.0, 1.640098, 0.221375, 0.848843, -5.141526],
     "Zr": [3.199978, 2.230909, 30.879991, 30.879991, 8.55919, 4.564902, 0.424667, 0.640054, 0.5, 1.0, -4.485793, -0.293129, 0.990148, -3.202516, -4.51, 0.0, 0.928602, -0.98187, 0.597133, -4.509025],
+}
+
+ZJW04_FAMILY = ("zjw04", "zjw04xc", "zjw04uxc", "zjw04xcp")
+PHI_KEYS = ["r_eq", "A", "B", "alpha", "beta", "kappa", "lamda"]
+# Zjw04xcp refits (reference nn/eam/potentials/zjw04.py:608-633; the later assignment wins)
+_XCP_KEYS = ["A", "B", "F0", "F1", "F2", "F3", "Fe", "Fn0", "Fn1", "Fn2", "Fn3", "alpha", "beta",
+             "eta", "f_eq", "kappa", "lamda", "r_eq", "rho_e", "rho_s"]
+ZJW04XCP_ELEMENTS = {
+    "Ni": dict(zip(_XCP_KEYS, [0.333956, 0.576165, -3.291077, 0.395187, 0.533360, -2.154562, -3.206066,
+                               -3.353943, 0.041024, -2.098675, -7.605803, 8.401944, 3.288919, 1.182809,
+                               1.543016, 0.419188, 0.857673, 2.488746, 25.423122, 26.498945])),
+    "Mo": dict(zip(_XCP_KEYS, [1.070439, 1.762964, -6.613181, 2.160862, 0.587255, -4.271510, -6.847272,
+                               -6.931113, 1.532229, 0.354207, -2.301498, 7.639637, 5.295918, 0.642979,
+                               3.321370, 0.142495, 0.211357, 2.728100, 32.766506, 21.342554])),
+}
+ZJW04XCP_PAIRS = {  # zjw04.py:646-649
+    "MoNi": dict(A=0.949134, B=1.360144, alpha=9.168006, beta=3.449561, kappa=0.478692,
+                 lamda=0.424937, r_eq=2.235219),
 }
 
 ADP_KEYS = ["d1", "d2", "d3", "q1", "q2", "q3", "h", "rc"]
@@ -113,13 +134,21 @@ class EamAlloyNN:
                 pots[term] = {"phi": sec.get("phi", "nn")}
                 for fn in self._extra_functions():
                     pots[term][fn] = sec.get(fn, "nn")
+        family = set()
         for key, sec in pots.items():
             for fn, name in sec.items():
-                ok = {"rho": ("zjw04",), "embed": ("zjw04",), "phi": ("zjw04",),
+                ok = {"rho": ZJW04_FAMILY, "embed": ZJW04_FAMILY, "phi": ZJW04_FAMILY,
                       "dipole": ("mishinh",), "quadrupole": ("mishinh",)}[fn]
                 if str(name).lower() not in ok:
                     raise ValueError(f"potential '{name}' for {key}/{fn} is not implemented by "
                                      f"tensoralloy_amd (available: {ok})")
+                if fn in ("rho", "embed", "phi"):
+                    family.add(str(name).lower())
+        if len(family) > 1:
+            # every reference potential object carries its own constants per element; mixing
+            # them inside one model needs per-function parameter sets, which the kernels lack
+            raise ValueError(f"one Zjw04 variant per model, got {sorted(family)}")
+        self._family = family.pop() if family else "zjw04"
         return pots
 
     # -- reference-compatible surface ----------------------------------------------
@@ -165,11 +194,36 @@ class EamAlloyNN:
                 "parameters": self._parameters}
 
     # -- parameters ---------------------------------------------------------------------
+    @property
+    def family(self) -> str:
+        """'zjw04', 'zjw04xc', 'zjw04uxc' or 'zjw04xcp'."""
+        return self._family
+
     def element_parameters(self, el: str) -> Dict[str, float]:
-        if el not in ZJW04_DEFAULTS:
-            raise ValueError(f"zjw04 has no parameters for element {el}")
-        p = dict(zip(ZJW04_KEYS, ZJW04_DEFAULTS[el]))
+        # defaults per variant: zjw04.py:19-152; Zjw04xc adds Be := Mo (:436-438);
+        # Zjw04xcp refits Ni and Mo (:608-633)
+        table = dict(ZJW04_DEFAULTS)
+        if self._family != "zjw04":
+            table["Be"] = table["Mo"]
+        if el not in table:
+            raise ValueError(f"{self._family} has no parameters for element {el}")
+        p = dict(zip(ZJW04_KEYS, table[el]))
+        if self._family == "zjw04xcp" and el in ZJW04XCP_ELEMENTS:
+            p.update(ZJW04XCP_ELEMENTS[el])
         p.update(self._parameters.get(el, {}))
+        return p
+
+    def phi_parameters(self, a: str, b: str):
+        """Constants of a cross-element phi of Zjw04xcp, else None (Zjw04 mixing rule)."""
+        if a == b or self._family != "zjw04xcp":
+            return None
+        key = "".join(sorted([a, b]))
+        p = dict(ZJW04XCP_PAIRS.get(key, {}))
+        p.update({k: v for k, v in self._parameters.get(key, {}).items() if k in PHI_KEYS})
+        missing = [k for k in PHI_KEYS if k not in p]
+        if missing:
+            raise ValueError(f"zjw04xcp has no phi constants for {key} (missing {missing}); "
+                             f"pass parameters={{'{key}': {{...}}}}")
         return p
 
     def pair_parameters(self, term: str):
@@ -177,9 +231,20 @@ class EamAlloyNN:
 
     def flat_parameters(self) -> np.ndarray:
         out = []
+        embed_kind = 0.0 if self._family == "zjw04" else 1.0
         for el in self._elements:
             p = self.element_parameters(el)
             out.extend(p[k] for k in ZJW04_KEYS)
+            out.append(embed_kind)
+        n = len(self._elements)
+        for i in range(n):
+            for j in range(i, n):
+                p = self.phi_parameters(self._elements[i], self._elements[j])
+                if p is None:
+                    out.extend([0.0] * 8)
+                else:
+                    out.append(1.0)
+                    out.extend(p[k] for k in PHI_KEYS)
         return np.array(out, dtype=np.float64)
 
     def to_desc(self):

@@ -43,3 +43,16 @@ def test_adp_ni(lib):
 
 def test_adp_binary(lib):
     _compare(make_eam(["Mo", "Ni"], 6.0, adp=True), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
+
+
+def test_zjw04xc_blended_embedding(lib):
+    # densities on both sides of 0.85 rho_e and 1.15 rho_e: compressed, equilibrium, expanded
+    frames = [fcc(rep=(2, 2, 2), a=a, seed=3) for a in (3.3, 3.52, 3.8)]
+    _compare(make_eam(["Ni"], 6.0, potential="zjw04xc"), frames)
+    _compare(make_eam(["Al", "Cu"], 6.5, potential="zjw04uxc"), [_alloy(["Al", "Cu"], rep=(2, 2, 2), a=3.9)])
+
+
+def test_zjw04xcp_cross_term(lib):
+    _compare(make_eam(["Mo", "Ni"], 6.5, potential="zjw04xcp"), [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 3))])
+    with pytest.raises(ValueError, match="no phi constants"):
+        make_eam(["Cu", "Ni"], 6.5, potential="zjw04xcp").to_desc()

@@ -207,7 +207,7 @@ def test_model_file_roundtrip(tmp_path):
     p = e.export(str(tmp_path / "adp"))
     e2, _, _ = load_model(p)
     assert e2.as_dict() == e.as_dict()
-    assert np.array_equal(e2.flat_parameters(), e.flat_parameters()) and len(e.flat_parameters()) == 2 * 20 + 3 * 8
+    assert np.array_equal(e2.flat_parameters(), e.flat_parameters()) and len(e.flat_parameters()) == 2 * 21 + 3 * 8 + 3 * 8
     with pytest.raises(ValueError):
         load_model(str(tmp_path / "missing.pb"))
     (tmp_path / "bad.json").write_text(json.dumps({"format": "other"}))
@@ -226,6 +226,17 @@ def test_model_argument_checks():
         EamAlloyNN(["Ni"], custom_potentials="sutton90")
     with pytest.raises(ValueError):
         EamAlloyNN(["Ni"])                                                # nn-EAM not implemented
+    with pytest.raises(ValueError, match="one Zjw04 variant"):
+        EamAlloyNN(["Ni"], custom_potentials={"Ni": {"rho": "zjw04", "embed": "zjw04xc"},
+                                              "NiNi": {"phi": "zjw04"}})
+    xc = EamAlloyNN(["Be", "Ni"], custom_potentials="zjw04xc")          # Be := Mo (zjw04.py:436-438)
+    assert xc.family == "zjw04xc" and xc.element_parameters("Be") == EamAlloyNN(
+        ["Mo"], custom_potentials="zjw04").element_parameters("Mo")
+    xcp = EamAlloyNN(["Mo", "Ni"], custom_potentials="zjw04xcp")
+    assert xcp.element_parameters("Ni")["rho_e"] == 25.423122           # the refit, zjw04.py:621-626
+    flat = xcp.flat_parameters()
+    assert len(flat) == 2 * 21 + 3 * 8 and flat[20] == 1.0 and flat[41] == 1.0
+    assert list(flat[42:50]) == [0.0] * 8 and flat[50] == 1.0 and flat[51] == 2.235219
     nn = AtomicNN(["Ni"], SymmetryFunction(["Ni"]), hidden_sizes=[4])
     with pytest.raises(ValueError):
         nn.ndim()                                                         # no transformer attached

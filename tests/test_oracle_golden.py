@@ -198,3 +198,47 @@ def test_adp_oracle_finite_differences():
         p = atoms.positions.copy(); p[i, k] -= d
         em = evaluate(m, sym, p, cell, atoms.pbc)["energy"]
         assert abs(o["forces"][i, k] + (ep - em) / (2 * d)) < 1e-6
+
+
+def test_zjw04xc_embed_tracks_zjw04():
+    """The reference's only numeric statement about Zjw04xc
+    (nn/eam/potentials/tests/test_zjw04.py:303-341): at rho = {0, 0.1, 0.85, 1, 1.15, 2} rho_e(Al)
+    the blended embedding and its derivative stay within numpy's `decimal=1e-4` band
+    (|diff| < 1.5 * 10**-1e-4) of the piecewise Zjw04 ones. The oracle must satisfy the same."""
+    from oracle.eam import ZJW04, zjw04_embed, zjw04xc_embed
+    p = ZJW04["Al"]
+    rho = np.array([0.0, 0.1, 0.85, 1.0, 1.15, 2.0]) * p["rho_e"]
+    f_old, d_old = zjw04_embed(rho, p)
+    f_new, d_new = zjw04xc_embed(rho, p)
+    band = 1.5 * 10 ** (-1e-4)
+    assert np.abs(f_old - f_new).max() < band
+    assert np.abs(d_old - d_new).max() < band
+    # far from the two thresholds the blend reduces to the branches themselves
+    far = np.array([0.3, 1.0, 1.9]) * p["rho_e"]
+    assert np.abs(zjw04_embed(far, p)[0] - zjw04xc_embed(far, p)[0]).max() < 1e-3
+    # analytic derivative of the blend
+    h = 1e-6
+    num = (zjw04xc_embed(rho[1:] + h, p)[0] - zjw04xc_embed(rho[1:] - h, p)[0]) / (2 * h)
+    assert np.abs(num - d_new[1:]).max() < 1e-7
+
+
+def test_zjw04xcp_oracle_finite_differences():
+    from oracle.eam import EamModel, evaluate
+    from tests.test_gpu_sf import _alloy
+    nn = make_eam(["Mo", "Ni"], 6.0, potential="zjw04xcp")
+    assert nn.family == "zjw04xcp" and nn.phi_parameters("Mo", "Ni")["r_eq"] == 2.235219
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    o = oracle_eam_eval(nn, atoms)
+    m = EamModel(nn.elements, 6.0, params={e: nn.element_parameters(e) for e in nn.elements},
+                 blended_embed=True, phi_pairs={"MoNi": nn.phi_parameters("Mo", "Ni")})
+    sym, cell = atoms.get_chemical_symbols(), np.asarray(atoms.get_cell())
+    d = 1e-5
+    for (i, k) in [(0, 0), (7, 1), (20, 2)]:
+        p = atoms.positions.copy(); p[i, k] += d
+        ep = evaluate(m, sym, p, cell, atoms.pbc)["energy"]
+        p = atoms.positions.copy(); p[i, k] -= d
+        em = evaluate(m, sym, p, cell, atoms.pbc)["energy"]
+        assert abs(o["forces"][i, k] + (ep - em) / (2 * d)) < 1e-6
+    # the mixing rule must NOT have been used for Mo-Ni
+    plain = oracle_eam_eval(make_eam(["Mo", "Ni"], 6.0, potential="zjw04xc"), atoms)
+    assert abs(plain["energy"] - o["energy"]) > 1e-3
