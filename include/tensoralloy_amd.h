@@ -98,6 +98,11 @@ typedef struct {
    *   ADP only, per pair: [d1 d2 d3 q1 q2 q3 h rc] (all zero = no angular term).           */
   int32_t n_eam_params;
   const double *eam_params;
+
+  /* added under sqrt(D.D + eps) (universal.py:470-472): 1e-14 for 'high' precision models,
+   * 1e-8 for 'medium' ones (precision.py:113-114). 0 selects 1e-14. Arithmetic is fp64
+   * either way.                                                                      */
+  double eps;
 } ta_model_desc;
 
 /* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`

@@ -123,8 +123,14 @@ class SFModel:
                  eta=(0.05, 4.0, 20.0, 80.0), omega=(0.0,), beta=(0.005,),
                  gamma=(1.0, -1.0), zeta=(1.0, 4.0), cutoff_function="cosine",
                  hidden_sizes=None, activation="softplus", weights=None,
-                 use_resnet_dt=False, minmax=None):
+                 use_resnet_dt=False, minmax=None, symmetric=True):
         self.elements = sorted(set(elements))
+        # symmetric=False lists every neighbour pair of a centre in both orders
+        # (universal.py:183-203). The reference's SymmetryFunction holds n(n+1)/2 angular
+        # terms (sf.py:131-132), so this only exists for one element.
+        self.symmetric = bool(symmetric)
+        if not self.symmetric and angular and len(self.elements) > 1:
+            raise IndexError("non-symmetric angular terms need n^2 slots, sf.py:131-132 has n(n+1)/2")
         self.rcut = float(rcut)
         self.angular = bool(angular)
         self.acut = float(acut) if acut is not None else self.rcut
@@ -255,6 +261,8 @@ def evaluate(model: SFModel, symbols, positions, cell, pbc, want_forces=True,
             if n < 2:
                 continue
             a, b = _triples_of(n)
+            if not model.symmetric:  # (j, k) and (k, j), j != k
+                a, b = np.concatenate([a, b]), np.concatenate([b, a])
             ta.append(a + starts[c])
             tb.append(b + starts[c])
         if ta:

@@ -56,6 +56,7 @@ class ModelDesc(C.Structure):
         ("n_layers", _ip), ("layer_sizes", _ip), ("weights", _dp),
         ("xlo", _dp), ("xhi", _dp),
         ("n_eam_params", C.c_int32), ("eam_params", _dp),
+        ("eps", C.c_double),
     ]
 
 

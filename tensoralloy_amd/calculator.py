@@ -77,8 +77,11 @@ class TensorAlloyCalculator(BaseCalculator):
         self._ops = ops
         self._predict_properties = list(ops.keys())
         self._fp_precision = self._meta.get("Metadata/precision", "high")
-        if self._fp_precision != "high":
-            raise ValueError("only 'high' (float64) precision models are implemented")
+        if self._fp_precision not in ("high", "medium"):
+            raise ValueError(f"unknown precision {self._fp_precision!r}")
+        # 'medium' models are float32 graphs in the reference (calculator.py:154-159); here they
+        # are evaluated in float64 with the float32 eps and the results are cast to float32
+        self._fp_dtype = np.float64 if self._fp_precision == "high" else np.float32
         self._is_finite_temperature = bool(int(self._meta.get("Metadata/is_finite_temperature", 0)))
         self._variational_energy = self._meta.get("Metadata/variational_energy", "energy")
         self._api_version = self._meta.get("Metadata/api", "1.1")
@@ -193,6 +196,9 @@ class TensorAlloyCalculator(BaseCalculator):
                 results[target] = res[target]
         if debug_mode:
             results["descriptors"] = res["descriptors"]
+        if self._fp_dtype is not np.float64:
+            results = {k: (np.asarray(v, dtype=self._fp_dtype) if isinstance(v, np.ndarray)
+                           else self._fp_dtype(v)) for k, v in results.items()}
         self.results = results
         self._ncalls += 1
 

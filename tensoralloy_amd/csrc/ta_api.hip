@@ -215,7 +215,7 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
   if (m->angular && !(m->acut > 0.0)) throw std::invalid_argument("acut must be positive");
   sf.inv_rc2 = 1.0 / (sf.rcut * sf.rcut);
   sf.inv_ac2 = 1.0 / (sf.acut * sf.acut);
-  sf.eps = 1e-14;  // Precision.high eps, reference precision.py:113
+  sf.eps = m->eps > 0.0 ? m->eps : 1e-14;  // Precision.high / medium eps, precision.py:113-114
   sf.n_elements = nel;
   sf.n_rad = m->n_eta * m->n_omega;
   sf.angular = m->angular ? 1 : 0;
@@ -638,7 +638,7 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
       h->rmax = model->rcut;
       std::memset(&h->sf, 0, sizeof(h->sf));
       h->sf.n_elements = model->n_elements;
-      h->sf.eps = 1e-14;
+      h->sf.eps = model->eps > 0.0 ? model->eps : 1e-14;
     } else {
       throw std::invalid_argument("unknown model kind");
     }

@@ -279,6 +279,7 @@ struct EamModel {
   EamParams p;
   double *dF = nullptr, *mom = nullptr;
   size_t cap_atoms = 0;
+  double eps = 1e-14;
 };
 
 EamModel *eam_create(const ta_model_desc *m, std::string &err) {
@@ -303,6 +304,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   std::memset(&e->p, 0, sizeof(e->p));
   e->p.nel = nel;
   e->p.adp = adp ? 1 : 0;
+  e->eps = m->eps > 0.0 ? m->eps : 1e-14;
   for (int k = 0; k < nel; ++k) {
     for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 21 + c];
     e->p.embed_kind[k] = m->eam_params[k * 21 + 20] != 0.0 ? 1 : 0;
@@ -357,7 +359,7 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   SFParams sf;
   std::memset(&sf, 0, sizeof(sf));
   sf.n_elements = m->p.nel;
-  sf.eps = 1e-14;
+  sf.eps = m->eps;
   launch_pair_geometry(sf, b, s);
   hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);

@@ -108,6 +108,7 @@ class EamAlloyNN:
         # overrides of the default constants: {"Ni": {"r_eq": ...}, "NiNi": {"d1": ...}}
         self._parameters = {k: dict(v) for k, v in (parameters or {}).items()}
         self._transformer = None
+        self.precision = "high"
 
     # ------------------------------------------------------------------
     def _extra_functions(self):
@@ -262,6 +263,7 @@ class EamAlloyNN:
         desc.angular = 0
         desc.n_eam_params = len(params)
         desc.eam_params = _lib.as_dp(params)
+        desc.eps = 1e-8 if self.precision == "medium" else 1e-14  # precision.py:113-114
         return desc, keep
 
     def export(self, output_graph_path: str, **_ignored):
@@ -284,7 +286,7 @@ class EamAlloyNN:
             "format": "tensoralloy_amd/1",
             "Transformer/params": self._transformer.as_dict(),
             "Metadata/timestamp": str(datetime.today()),
-            "Metadata/precision": "high",
+            "Metadata/precision": self.precision,
             "Metadata/variational_energy": "energy",
             "Metadata/is_finite_temperature": 0,
             "Metadata/api": API_VERSION,

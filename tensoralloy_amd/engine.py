@@ -109,7 +109,8 @@ class Engine:
         if atomic is not None:
             out["atomic"] = atomic
         if desc is not None:
-            out["descriptors"] = desc
+            scale = getattr(self._nn, "descriptor_scale", None)
+            out["descriptors"] = desc * scale() if scale is not None else desc
         return out
 
     def evaluate(self, atoms_list: Sequence, want: int = None, descriptors=False) -> List[dict]:

@@ -143,6 +143,7 @@ class AtomicNN:
             descriptor = SymmetryFunction(**d)
         self._descriptor = descriptor
         self._transformer = None
+        self.precision = "high"  # 'medium' = float32 reference model: eps 1e-8, float32 results
         #: {element: [(W [in, out], b [out] | None), ...]} last entry = output layer
         self.weights: Dict[str, List] = {}
         #: {element: (xlo [D], xhi [D])}
@@ -208,6 +209,9 @@ class AtomicNN:
             raise ValueError("A descriptor transformer must be attached.")
         return self._descriptor.ndim(self._transformer.angular)
 
+    def ndim_angular(self) -> int:
+        return self.ndim() - self._descriptor.ndim(False)
+
     def initialize(self, seed=Defaults.seed, bias_scale=0.0):
         """
         Random-init variables the way the reference initialises them: He-normal
@@ -265,7 +269,7 @@ class AtomicNN:
             "format": "tensoralloy_amd/1",
             "Transformer/params": self._transformer.as_dict(),
             "Metadata/timestamp": str(datetime.today()),
-            "Metadata/precision": "high",
+            "Metadata/precision": self.precision,
             "Metadata/variational_energy": self.variational_energy,
             "Metadata/is_finite_temperature": 0,
             "Metadata/api": API_VERSION,
@@ -294,8 +298,12 @@ class AtomicNN:
         clf = self._transformer
         if clf is None:
             raise ValueError("A descriptor transformer must be attached.")
-        if not clf.symmetric and clf.angular:
-            raise ValueError("symmetric=False angular terms are not implemented by tensoralloy_amd")
+        nonsym = bool(clf.angular and not clf.symmetric)
+        if nonsym and len(self._elements) > 1:
+            # the reference sizes its output list for the symmetric term count (sf.py:131-132),
+            # so its SymmetryFunction also fails (IndexError) for n >= 2 elements
+            raise ValueError("symmetric=False angular symmetry functions exist only for one element "
+                             "(reference nn/atomic/sf.py:131-132 holds n(n+1)/2 angular terms)")
         sf = self._descriptor
         D = self.ndim()
         keep = []
@@ -310,15 +318,23 @@ class AtomicNN:
             keep.append(a)
             return _lib.as_ip(a)
 
+        # symmetric=False with one element: every {j, k} is listed as (j, k) and (k, j)
+        # (universal.py:183-203), so the angular features are exactly twice the symmetric
+        # ones. The library always sums unordered triples; the factor is folded into the
+        # first layer (or into xlo / xhi when min-max scaling comes first).
+        n_rad = D - self.ndim_angular() if nonsym else D
         n_layers, sizes, flat = [], [], []
         for el in self._elements:
             layers = self.weights[el]
             n_layers.append(len(layers))
             s = [D]
-            for w, b in layers:
+            for k, (w, b) in enumerate(layers):
                 w = np.asarray(w, dtype=np.float64)
                 if w.ndim != 2 or w.shape[0] != s[-1]:
                     raise ValueError(f"weight shape {w.shape} does not chain from {s[-1]}")
+                if nonsym and k == 0 and not self._minmax_scale:
+                    w = w.copy()
+                    w[n_rad:] *= 2.0
                 s.append(w.shape[1])
                 flat.append(w.ravel())
                 flat.append(np.zeros(w.shape[1]) if b is None
@@ -342,10 +358,22 @@ class AtomicNN:
         desc.layer_sizes = iptr(sizes)
         desc.weights = dptr(np.concatenate(flat))
         if self._minmax_scale:
-            desc.xlo = dptr(np.concatenate([np.ravel(self.minmax[el][0]) for el in self._elements]))
-            desc.xhi = dptr(np.concatenate([np.ravel(self.minmax[el][1]) for el in self._elements]))
+            scale = np.ones(D)
+            if nonsym:
+                scale[n_rad:] = 0.5
+            desc.xlo = dptr(np.concatenate([np.ravel(self.minmax[el][0]) * scale for el in self._elements]))
+            desc.xhi = dptr(np.concatenate([np.ravel(self.minmax[el][1]) * scale for el in self._elements]))
         desc.n_eam_params = 0
+        desc.eps = 1e-8 if self.precision == "medium" else 1e-14  # precision.py:113-114
         return desc, keep
+
+    def descriptor_scale(self):
+        """Factors that turn the library's (symmetric) descriptors into this model's."""
+        clf = self._transformer
+        scale = np.ones(self.ndim())
+        if clf is not None and clf.angular and not clf.symmetric:
+            scale[self.ndim() - self.ndim_angular():] = 2.0
+        return scale
 
 
 def _model_stem(path: str) -> str:
@@ -409,4 +437,8 @@ def load_model(graph_model_path: str):
         nn.attach_transformer(clf)
     else:
         raise ValueError(f"Unsupported model class: {nn_cls}")
+    precision = meta.get("Metadata/precision", "high")
+    if precision not in ("high", "medium"):
+        raise ValueError(f"{stem}.json: unknown precision {precision!r}")
+    nn.precision = precision
     return nn, clf, meta

@@ -24,14 +24,15 @@ def pd3o2():
 
 def make_nn(elements, rcut, angular, hidden, activation="softplus", acut=None, seed=611,
             minmax=False, resnet=False, bias_scale=0.1, cutoff="cosine", sf_kwargs=None,
-            static_energy=None):
-    clf = UniversalTransformer(elements, rcut=rcut, acut=acut, angular=angular)
+            static_energy=None, symmetric=True, precision="high"):
+    clf = UniversalTransformer(elements, rcut=rcut, acut=acut, angular=angular, symmetric=symmetric)
     sf = SymmetryFunction(elements, cutoff_function=cutoff, **(sf_kwargs or {}))
     nn = AtomicNN(elements, sf, hidden_sizes=hidden, activation=activation,
                   minmax_scale=minmax, use_resnet_dt=resnet,
                   atomic_static_energy=static_energy or {},
                   export_properties=("energy", "forces", "stress"))
     nn.attach_transformer(clf)
+    nn.precision = precision
     nn.initialize(seed=seed, bias_scale=bias_scale)
     if minmax:
         rng = np.random.RandomState(seed + 1)
@@ -50,14 +51,16 @@ def oracle_model(nn):
                 omega=d["omega"], beta=d["beta"], gamma=d["gamma"], zeta=d["zeta"],
                 cutoff_function=d["cutoff_function"], hidden_sizes=nn.hidden_sizes,
                 activation=nn._activation, weights=nn.weights, use_resnet_dt=nn._use_resnet_dt,
-                minmax=nn.minmax if nn._minmax_scale else None)
+                minmax=nn.minmax if nn._minmax_scale else None, symmetric=clf.symmetric)
     return m
 
 
 def oracle_eval(nn, atoms, want_forces=True):
     from oracle.sf import evaluate
+    eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14  # precision.py:113-114
     return evaluate(oracle_model(nn), atoms.get_chemical_symbols(), atoms.positions,
-                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, want_forces=want_forces)
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, want_forces=want_forces,
+                    eps=eps)
 
 
 def make_eam(elements, rcut=6.5, adp=False, potential="zjw04", parameters=None):
@@ -101,5 +104,6 @@ def oracle_eam_eval(nn, atoms):
     m = EamModel(nn.elements, nn.transformer.rcut,
                  params={el: nn.element_parameters(el) for el in nn.elements}, adp=adp,
                  blended_embed=nn.family != "zjw04", phi_pairs=phi_pairs)
+    eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
     return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
-                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc)
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)

@@ -82,3 +82,18 @@ def test_unsupported_model_file(lib, tmp_path):
     p.write_bytes(b"\x0a\x00")
     with pytest.raises(ValueError):
         TensorAlloyCalculator(str(p))
+
+
+def test_calculator_medium_precision_model(lib, tmp_path):
+    """A 'medium' (float32) model: float32 results as from the reference's float32 graph
+    (calculator.py:154-159), values from the fp64 path with the float32 eps."""
+    from tensoralloy_amd import TensorAlloyCalculator
+    nn = make_nn(["Ni"], 6.0, True, [16, 16], precision="medium")
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "ni_medium")))
+    atoms = fcc(rep=(2, 2, 2))
+    calc.calculate(atoms, properties=["energy", "forces", "stress"])
+    assert calc.results["forces"].dtype == np.float32 and calc.results["stress"].dtype == np.float32
+    assert isinstance(calc.results["energy"], np.float32)
+    o = oracle_eval(nn, atoms)
+    assert abs(float(calc.results["energy"]) - o["energy"]) < 1e-5 * max(1.0, abs(o["energy"]))
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < 1e-5

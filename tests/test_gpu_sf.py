@@ -168,3 +168,27 @@ def test_energy_only(lib, monkeypatch):
     assert abs(r["energy"] - o["energy"]) < E_TOL
     assert np.abs(r["atomic"] - o["atomic"]).max() < E_TOL
     assert "forces" not in r
+
+
+def test_medium_precision_eps(lib):
+    """'medium' models: sqrt(D.D + 1e-8) (precision.py:114) everywhere a distance is formed,
+    including r_jk and the law-of-cosines angle."""
+    nn = make_nn(["Mo", "Ni"], 6.0, True, [16, 16], precision="medium")
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    res = _compare(nn, [atoms])
+    nn_hi = make_nn(["Mo", "Ni"], 6.0, True, [16, 16])
+    from tensoralloy_amd import Engine
+    with Engine(nn_hi) as eng:
+        hi = eng.evaluate([atoms], descriptors=True)[0]
+    # eps really changed the numbers (1e-8 under the roots is visible at 1e-10)
+    assert np.abs(hi["descriptors"] - res[0]["descriptors"]).max() > 1e-9
+
+
+@pytest.mark.parametrize("minmax", [False, True])
+def test_non_symmetric_single_element(lib, minmax):
+    """symmetric=False lists (j, k) and (k, j): twice the symmetric angular features."""
+    nn = make_nn(["Ni"], 6.0, True, [16, 16], symmetric=False, minmax=minmax)
+    _compare(nn, [fcc(rep=(2, 2, 2), seed=21)])
+    from tests.helpers import AtomicNN  # noqa: F401
+    with pytest.raises(ValueError, match="only for one element"):
+        make_nn(["Mo", "Ni"], 6.0, True, [8], symmetric=False).to_desc()

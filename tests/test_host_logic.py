@@ -242,8 +242,15 @@ def test_model_argument_checks():
         nn.ndim()                                                         # no transformer attached
     nn.attach_transformer(UniversalTransformer(["Ni"], 6.0, angular=True, symmetric=False))
     nn.initialize()
+    desc, _ = nn.to_desc()                                                # one element: allowed
+    assert desc.eps == 1e-14 and list(nn.descriptor_scale()) == [1.0] * 4 + [2.0] * 4
+    nn.precision = "medium"
+    assert nn.to_desc()[0].eps == 1e-8
+    nn2 = AtomicNN(["Mo", "Ni"], SymmetryFunction(["Mo", "Ni"]), hidden_sizes=[4])
+    nn2.attach_transformer(UniversalTransformer(["Mo", "Ni"], 6.0, angular=True, symmetric=False))
+    nn2.initialize()
     with pytest.raises(ValueError):
-        nn.to_desc()                                                      # symmetric=False unsupported
+        nn2.to_desc()                                                     # as sf.py:131-132
 
 
 def test_atoms_and_calculator_shims():
