@@ -19,6 +19,9 @@ namespace ta {
 size_t mlp_scratch_doubles(const MlpDev &mlp);
 void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                      const DeviceBatch &b, double *scratch, hipStream_t s);
+size_t mlp_all_scratch_doubles(const MlpDev *mlps_host, int nel, const int32_t *elem_start);
+void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, int activation, int ndim,
+                    const DeviceBatch &b, double *scratch, hipStream_t s);
 // EAM / ADP (ta_eam.hip)
 struct EamModel;
 EamModel *eam_create(const ta_model_desc *m, std::string &err);
@@ -516,11 +519,8 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
     end(TA_K_DESCRIPTOR_REDUCE);
     used[TA_K_DESCRIPTOR_REDUCE] = true;
     begin(TA_K_MLP);
-    for (int el = 0; el < h->n_elements; ++el) {
-      const int n_el = db.elem_start[el + 1] - db.elem_start[el];
-      launch_mlp_impl(h->mlp[el], h->activation, h->sf.ndim, db.elem_atoms + db.elem_start[el], n_el,
-                      db, h->mlp_scratch.ptr, s);
-    }
+    launch_mlp_all(h->mlp_dev, h->mlp, h->n_elements, h->activation, h->sf.ndim, db,
+                   h->mlp_scratch.ptr, s);
     end(TA_K_MLP);
     used[TA_K_MLP] = true;
     if (need_forces) {
@@ -830,11 +830,7 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     if (h->kind == TA_MODEL_SF_MLP) {
       if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
         throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
-      size_t need = 0;
-      for (int e = 0; e < h->n_elements; ++e) {
-        const size_t tiles = (size_t)(h->db.elem_start[e + 1] - h->db.elem_start[e] + 15) / 16;
-        need = std::max(need, tiles * ta::mlp_scratch_doubles(h->mlp[e]));
-      }
+      size_t need = ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start);
       if (h->use_fused) need = std::max(need, ta::fused_scratch_doubles(h->fplan, h->db.n_blk));
       h->mlp_scratch.ensure(need);
     } else {
