@@ -49,7 +49,7 @@ enum {
   TA_WANT_DESCRIPTORS = 16 /* Atomic/<El> descriptors  sf.py:184-215 (debug)    */
 };
 
-enum { TA_MODEL_SF_MLP = 1, TA_MODEL_EAM_ALLOY = 2, TA_MODEL_EAM_ADP = 3 };
+enum { TA_MODEL_SF_MLP = 1, TA_MODEL_EAM_ALLOY = 2, TA_MODEL_EAM_ADP = 3, TA_MODEL_GRAP_MLP = 4 };
 enum { TA_CUTOFF_COSINE = 0, TA_CUTOFF_POLYNOMIAL = 1 }; /* nn/cutoff.py:20-85 */
 
 /* activation ids follow `actfn_map` of atomic.py:323 for 0..3 */
@@ -103,6 +103,14 @@ typedef struct {
    * 1e-8 for 'medium' ones (precision.py:113-114). 0 selects 1e-14. Arithmetic is fp64
    * either way.                                                                      */
   double eps;
+
+  /* GRAP descriptor (TA_MODEL_GRAP_MLP; nn/atomic/grap.py:272-704), with the MLP fields above and
+   * `rcut`, `cutoff_function`: [algorithm (0 sf, 1 morse, 2 density, 3 pexp), K filters,
+   * max moment (0..3), legacy_mode, symmetric, moment mask (bit m: moment m listed), then K x 3
+   * filter constants: sf (eta, omega, -), morse (D, gamma, r0), density (A, beta, re),
+   * pexp (rl, pl, -)].                                                                    */
+  int32_t n_grap_params;
+  const double *grap_params;
 } ta_model_desc;
 
 /* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`
@@ -137,7 +145,8 @@ enum {
   TA_K_PAIR_GEOMETRY = 0, TA_K_G4_FORWARD = 1, TA_K_DESCRIPTOR_REDUCE = 2,
   TA_K_MLP = 3, TA_K_BACKWARD = 4, TA_K_FORCE_GATHER = 5, TA_K_FRAME_REDUCE = 6,
   TA_K_EAM = 7,
-  TA_K_FUSED = 8 /* geometry + descriptors + MLP + dE/dD in one launch; slot 9 reserved */
+  TA_K_FUSED = 8, /* geometry + descriptors + MLP + dE/dD in one launch */
+  TA_K_GRAP = 9   /* GRAP moments + features (forward) */
 };
 
 int ta_device_count(void);

@@ -202,6 +202,54 @@ def pair_geometry(positions, cell, i, j, S, eps=EPS64):
     return D, r
 
 
+def apply_mlp(model, symbols, G):
+    """Per-element MLP on the descriptors G [N, D] (`model` needs elements, weights, activation,
+    use_resnet_dt, minmax): atomic energies [N] and dE/dG [N, D].
+    Follows atomic.py:157-195 (min-max), convolutional.py:257-290 (layers, skip), atomic.py:236-259."""
+    elements = model.elements
+    N, Dn = G.shape
+    atomic = np.zeros(N)
+    dEdG = np.zeros((N, Dn))
+    for el in elements:
+        idx = np.array([k for k, s in enumerate(symbols) if s == el], dtype=np.int64)
+        if len(idx) == 0:
+            continue
+        x = G[idx]
+        scale = None
+        if model.minmax is not None and el in model.minmax:
+            xlo, xhi = model.minmax[el]
+            den = xhi - xlo
+            ok = den != 0.0
+            safe = np.where(ok, den, 1.0)
+            x = np.where(ok, (xhi - x) / safe, 0.0)  # div_no_nan, atomic.py:195
+            scale = np.where(ok, -1.0 / safe, 0.0)
+        layers = model.weights[el]
+        hs, dacts = [x], []
+        hcur = x
+        for l, (W, b) in enumerate(layers[:-1]):
+            zl = hcur @ W + (b if b is not None else 0.0)
+            a, da = activation(model.activation, zl)
+            res = (l > 0 and model.use_resnet_dt and W.shape[0] == W.shape[1])
+            hnext = a + hcur if res else a  # convolutional.py:272-273
+            dacts.append((da, res))
+            hcur = hnext
+            hs.append(hcur)
+        Wo, bo = layers[-1]
+        y = hcur @ Wo + (bo if bo is not None else 0.0)
+        atomic[idx] = y[:, 0]
+        # backward to the inputs
+        delta = np.repeat(Wo.T, len(idx), axis=0)  # dy/dh_L
+        for l in range(len(layers) - 2, -1, -1):
+            W, _ = layers[l]
+            da, res = dacts[l]
+            back = (delta * da) @ W.T
+            delta = back + delta if res else back
+        if scale is not None:
+            delta = delta * scale
+        dEdG[idx] = delta
+    return atomic, dEdG
+
+
 def _triples_of(n):
     a, b = np.triu_indices(n, k=1)
     return a, b
@@ -298,45 +346,7 @@ def evaluate(model: SFModel, symbols, positions, cell, pbc, want_forces=True,
         return out
 
     # ---- min-max + MLP forward/backward -----------------------------------
-    atomic = np.zeros(N)
-    dEdG = np.zeros((N, Dn))
-    for el in elements:
-        idx = np.array([k for k, s in enumerate(symbols) if s == el], dtype=np.int64)
-        if len(idx) == 0:
-            continue
-        x = G[idx]
-        scale = None
-        if model.minmax is not None and el in model.minmax:
-            xlo, xhi = model.minmax[el]
-            den = xhi - xlo
-            ok = den != 0.0
-            safe = np.where(ok, den, 1.0)
-            x = np.where(ok, (xhi - x) / safe, 0.0)  # div_no_nan, atomic.py:195
-            scale = np.where(ok, -1.0 / safe, 0.0)
-        layers = model.weights[el]
-        hs, dacts = [x], []
-        hcur = x
-        for l, (W, b) in enumerate(layers[:-1]):
-            zl = hcur @ W + (b if b is not None else 0.0)
-            a, da = activation(model.activation, zl)
-            res = (l > 0 and model.use_resnet_dt and W.shape[0] == W.shape[1])
-            hnext = a + hcur if res else a  # convolutional.py:272-273
-            dacts.append((da, res))
-            hcur = hnext
-            hs.append(hcur)
-        Wo, bo = layers[-1]
-        y = hcur @ Wo + (bo if bo is not None else 0.0)
-        atomic[idx] = y[:, 0]
-        # backward to the inputs
-        delta = np.repeat(Wo.T, len(idx), axis=0)  # dy/dh_L
-        for l in range(len(layers) - 2, -1, -1):
-            W, _ = layers[l]
-            da, res = dacts[l]
-            back = (delta * da) @ W.T
-            delta = back + delta if res else back
-        if scale is not None:
-            delta = delta * scale
-        dEdG[idx] = delta
+    atomic, dEdG = apply_mlp(model, symbols, G)
 
     energy = float(np.sum(atomic))
     out.update(energy=energy, atomic=atomic, dEdG=dEdG)

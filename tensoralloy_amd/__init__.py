@@ -11,9 +11,10 @@ C ABI in include/tensoralloy_amd.h). There is no CPU fallback.
 """
 from .atoms import Atoms, HAVE_ASE
 from .model import AtomicNN, SymmetryFunction, load_model
+from .grap import GenericRadialAtomicPotential
 from .transformer import UniversalTransformer, VirtualAtomMap
 from .calculator import TensorAlloyCalculator
 from .engine import Engine
 
-__all__ = ["Atoms", "AtomicNN", "SymmetryFunction", "UniversalTransformer", "VirtualAtomMap",
+__all__ = ["Atoms", "AtomicNN", "SymmetryFunction", "GenericRadialAtomicPotential", "UniversalTransformer", "VirtualAtomMap",
            "TensorAlloyCalculator", "Engine", "load_model", "HAVE_ASE"]

@@ -19,19 +19,19 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip",
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip", "ta_grap.hip",
            "ta_neighbor.cpp"]
 
 TA_OK = 0
 TA_ERR_INVALID, TA_ERR_UNSUPPORTED, TA_ERR_HIP, TA_ERR_NOMEM = -1, -2, -3, -4
 TA_WANT_ENERGY, TA_WANT_FORCES, TA_WANT_VIRIAL, TA_WANT_ATOMIC, TA_WANT_DESCRIPTORS = 1, 2, 4, 8, 16
-TA_MODEL_SF_MLP, TA_MODEL_EAM_ALLOY, TA_MODEL_EAM_ADP = 1, 2, 3
+TA_MODEL_SF_MLP, TA_MODEL_EAM_ALLOY, TA_MODEL_EAM_ADP, TA_MODEL_GRAP_MLP = 1, 2, 3, 4
 TA_CUTOFF = {"cosine": 0, "polynomial": 1}
 TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
           "sigmoid": 5, "softsign": 6, "elu": 7}
 TA_N_KERNEL_SLOTS = 10
 KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
-                "force_gather", "frame_reduce", "eam", "fused", "reserved"]
+                "force_gather", "frame_reduce", "eam", "fused", "grap_forward"]
 
 # every symbol include/tensoralloy_amd.h declares
 EXPORTED_SYMBOLS = [
@@ -57,6 +57,7 @@ class ModelDesc(C.Structure):
         ("xlo", _dp), ("xhi", _dp),
         ("n_eam_params", C.c_int32), ("eam_params", _dp),
         ("eps", C.c_double),
+        ("n_grap_params", C.c_int32), ("grap_params", _dp),
     ]
 
 

@@ -22,6 +22,14 @@ void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t 
 size_t mlp_all_scratch_doubles(const MlpDev *mlps_host, int nel, const int32_t *elem_start);
 void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, int activation, int ndim,
                     const DeviceBatch &b, double *scratch, hipStream_t s);
+// GRAP (ta_grap.hip)
+struct GrapModel;
+GrapModel *grap_create(const ta_model_desc *m, std::string &err);
+int grap_ndim(const GrapModel *g);
+void grap_destroy(GrapModel *);
+void grap_ensure(GrapModel *, const DeviceBatch &b);
+void launch_grap_forward(GrapModel *, const DeviceBatch &b, hipStream_t s);
+void launch_grap_backward(GrapModel *, const DeviceBatch &b, hipStream_t s);
 // EAM / ADP (ta_eam.hip)
 struct EamModel;
 EamModel *eam_create(const ta_model_desc *m, std::string &err);
@@ -114,6 +122,7 @@ struct ta_context {
   ta::MlpDev mlp[ta::kMaxElements];
   std::vector<void *> model_allocs;
   ta::EamModel *eam = nullptr;
+  ta::GrapModel *grap = nullptr;
 
   ta::HostPairs hp;
   ta::DeviceBatch db;
@@ -203,6 +212,8 @@ void hd_series(int cutoff, double beta, ta::AngChunk &ch) {
   }
 }
 
+void build_mlp(ta_context *h, const ta_model_desc *m, int ndim);
+
 void build_sf_model(ta_context *h, const ta_model_desc *m) {
   using namespace ta;
   SFParams &sf = h->sf;
@@ -277,8 +288,14 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
   (void)0;
   sf.ndim = sf.n_radial_dim + n_aterms * sf.n_ang;
   h->rmax = std::max(sf.rcut, sf.acut);
+  build_mlp(h, m, sf.ndim);
+}
 
-  // MLP weights
+// per-element MLP weights -> padded device copies, both orientations
+void build_mlp(ta_context *h, const ta_model_desc *m, int ndim) {
+  using namespace ta;
+  const int nel = m->n_elements;
+  struct { int ndim; } sf{ndim};
   if (!m->n_layers || !m->layer_sizes || !m->weights)
     throw std::invalid_argument("MLP description missing");
   h->activation = m->activation;
@@ -369,7 +386,8 @@ void upload_batch(ta_context *h) {
     put(h->pair_rev, hp.pair_rev);
   }
 
-  const int D = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 1;
+  const bool has_mlp = h->kind == TA_MODEL_SF_MLP || h->kind == TA_MODEL_GRAP_MLP;
+  const int D = has_mlp ? h->sf.ndim : 1;
   h->rec.ensure(P * kRecDoubles);
   if (h->kind == TA_MODEL_SF_MLP && h->sf.angular) {
     h->part4.ensure((size_t)nel * h->sf.n_ang * P);
@@ -552,6 +570,30 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       end(TA_K_FORCE_GATHER);
       used[TA_K_FORCE_GATHER] = true;
     }
+  } else if (h->kind == TA_MODEL_GRAP_MLP) {
+    begin(TA_K_PAIR_GEOMETRY);
+    launch_pair_geometry(h->sf, db, s);
+    end(TA_K_PAIR_GEOMETRY);
+    used[TA_K_PAIR_GEOMETRY] = true;
+    begin(TA_K_GRAP);
+    launch_grap_forward(h->grap, db, s);
+    end(TA_K_GRAP);
+    used[TA_K_GRAP] = true;
+    begin(TA_K_MLP);
+    launch_mlp_all(h->mlp_dev, h->mlp, h->n_elements, h->activation, h->sf.ndim, db,
+                   h->mlp_scratch.ptr, s);
+    end(TA_K_MLP);
+    used[TA_K_MLP] = true;
+    if (need_forces) {
+      begin(TA_K_BACKWARD);
+      launch_grap_backward(h->grap, db, s);
+      end(TA_K_BACKWARD);
+      used[TA_K_BACKWARD] = true;
+      begin(TA_K_FORCE_GATHER);
+      launch_force_gather(h->sf, db, s);
+      end(TA_K_FORCE_GATHER);
+      used[TA_K_FORCE_GATHER] = true;
+    }
   } else {
     begin(TA_K_EAM);
     eam_compute(h->eam, db, want, s, nullptr);
@@ -631,6 +673,18 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
     for (auto &e : h->ev) HIP_CHECK(hipEventCreate(&e));
     if (model->kind == TA_MODEL_SF_MLP) {
       build_sf_model(h, model);
+    } else if (model->kind == TA_MODEL_GRAP_MLP) {
+      if (model->cutoff_function != TA_CUTOFF_COSINE && model->cutoff_function != TA_CUTOFF_POLYNOMIAL)
+        throw std::invalid_argument("unknown cutoff function");
+      std::string err;
+      h->grap = ta::grap_create(model, err);
+      if (!h->grap) throw std::invalid_argument(err);
+      h->rmax = model->rcut;
+      std::memset(&h->sf, 0, sizeof(h->sf));
+      h->sf.n_elements = model->n_elements;
+      h->sf.eps = model->eps > 0.0 ? model->eps : 1e-14;
+      h->sf.ndim = ta::grap_ndim(h->grap);
+      build_mlp(h, model, h->sf.ndim);
     } else if (model->kind == TA_MODEL_EAM_ALLOY || model->kind == TA_MODEL_EAM_ADP) {
       std::string err;
       h->eam = ta::eam_create(model, err);
@@ -658,6 +712,7 @@ int ta_destroy(ta_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->model_allocs) (void)hipFree(p);
   if (h->eam) ta::eam_destroy(h->eam);
+  if (h->grap) ta::grap_destroy(h->grap);
   h->stage_in.release(); h->stage_out.release(); h->inbuf.release(); h->results.release();
   h->rec.release(); h->part4.release(); h->G.release();
   h->dEdG.release(); h->g.release(); h->wat.release();
@@ -833,6 +888,9 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       size_t need = ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start);
       if (h->use_fused) need = std::max(need, ta::fused_scratch_doubles(h->fplan, h->db.n_blk));
       h->mlp_scratch.ensure(need);
+    } else if (h->kind == TA_MODEL_GRAP_MLP) {
+      h->mlp_scratch.ensure(ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start));
+      ta::grap_ensure(h->grap, h->db);
     } else {
       ta::eam_ensure(h->eam, h->db);
     }
@@ -849,7 +907,7 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       info->n_pairs = h->hp.n_pairs;
       info->n_triples = h->hp.n_triples;
       info->nnl_max = h->hp.nnl_max;
-      info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP) ? h->sf.ndim : 0;
+      info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP || h->kind == TA_MODEL_GRAP_MLP) ? h->sf.ndim : 0;
       info->nl_on_device = h->pairs_on_device ? 1 : 0;
       info->reserved_ = 0;
       info->nl_ms = nl_ms;
@@ -880,8 +938,8 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, 
     const bool have_forces = (h->last_want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
     if ((forces || virial) && !have_forces)
       throw std::invalid_argument("forces / virial requested but the last ta_compute did not produce them");
-    if (descriptors && h->kind != TA_MODEL_SF_MLP)
-      throw std::invalid_argument("descriptors are only defined for symmetry-function models");
+    if (descriptors && h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+      throw std::invalid_argument("descriptors are only defined for symmetry-function and GRAP models");
     // one download of the span of [energy F | virial 9F | atomic N | forces 3N] that was asked for
     size_t lo = (size_t)-1, hi = 0;
     auto need = [&](bool on, size_t off, size_t n) {

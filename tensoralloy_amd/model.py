@@ -135,12 +135,16 @@ class AtomicNN:
         self._export_properties = list(export_properties)
         if isinstance(descriptor, dict):
             d = dict(descriptor)
-            cls = d.pop("class", "SymmetryFunction")
+            cls = d.pop("class", None) or d.get("@class", "SymmetryFunction")
             d.pop("@module", None)
             d.pop("@class", None)
-            if cls != "SymmetryFunction":
+            if cls == "SymmetryFunction":
+                descriptor = SymmetryFunction(**d)
+            elif cls == "GenericRadialAtomicPotential":
+                from .grap import GenericRadialAtomicPotential
+                descriptor = GenericRadialAtomicPotential(**d)
+            else:
                 raise ValueError(f"Unsupported descriptor: {cls}")
-            descriptor = SymmetryFunction(**d)
         self._descriptor = descriptor
         self._transformer = None
         self.precision = "high"  # 'medium' = float32 reference model: eps 1e-8, float32 results
@@ -298,6 +302,9 @@ class AtomicNN:
         clf = self._transformer
         if clf is None:
             raise ValueError("A descriptor transformer must be attached.")
+        is_grap = getattr(self._descriptor, "name", "SF") == "GRAP"
+        if is_grap and clf.angular:
+            raise ValueError("GRAP is a radial descriptor: the transformer must have angular=False")
         nonsym = bool(clf.angular and not clf.symmetric)
         if nonsym and len(self._elements) > 1:
             # the reference sizes its output list for the symmetric term count (sf.py:131-132),
@@ -341,16 +348,23 @@ class AtomicNN:
                             else np.asarray(b, dtype=np.float64).ravel())
             sizes.extend(s)
         desc = _lib.ModelDesc()
-        desc.kind = _lib.TA_MODEL_SF_MLP
         desc.n_elements = len(self._elements)
         desc.rcut = float(clf.rcut)
         desc.acut = float(clf.acut if clf.acut is not None else clf.rcut)
-        desc.angular = int(bool(clf.angular))
         desc.cutoff_function = _lib.TA_CUTOFF[sf.cutoff_function]
-        desc.n_eta, desc.n_omega = len(sf._eta), len(sf._omega)
-        desc.n_beta, desc.n_gamma, desc.n_zeta = len(sf._beta), len(sf._gamma), len(sf._zeta)
-        desc.eta, desc.omega = dptr(sf._eta), dptr(sf._omega)
-        desc.beta, desc.gamma, desc.zeta = dptr(sf._beta), dptr(sf._gamma), dptr(sf._zeta)
+        if is_grap:
+            desc.kind = _lib.TA_MODEL_GRAP_MLP
+            desc.angular = 0
+            gp = sf.flat_parameters()
+            desc.n_grap_params = len(gp)
+            desc.grap_params = dptr(gp)
+        else:
+            desc.kind = _lib.TA_MODEL_SF_MLP
+            desc.angular = int(bool(clf.angular))
+            desc.n_eta, desc.n_omega = len(sf._eta), len(sf._omega)
+            desc.n_beta, desc.n_gamma, desc.n_zeta = len(sf._beta), len(sf._gamma), len(sf._zeta)
+            desc.eta, desc.omega = dptr(sf._eta), dptr(sf._omega)
+            desc.beta, desc.gamma, desc.zeta = dptr(sf._beta), dptr(sf._gamma), dptr(sf._zeta)
         desc.activation = _lib.TA_ACT[self._activation.lower()]
         desc.use_resnet_dt = int(self._use_resnet_dt)
         desc.minmax_scale = int(self._minmax_scale)

@@ -107,3 +107,46 @@ def oracle_eam_eval(nn, atoms):
     eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
     return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
                     np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)
+
+
+PEXP = {"rl": [1.0, 1.15, 1.3, 1.45, 1.6, 1.75, 1.9, 2.05, 2.2, 2.35],
+        "pl": [5.0, 4.75, 4.5, 4.25, 4.0, 3.75, 3.5, 3.25, 3.0, 2.75]}  # test_grap.py:52-53
+
+
+def make_grap_nn(elements, rcut, hidden, algorithm="pexp", parameters=None, moment_tensors=(0, 1, 2),
+                 legacy_mode=False, symmetric=False, cutoff="cosine", param_space_method="pair",
+                 minmax=False, seed=611, precision="high"):
+    from tensoralloy_amd.grap import GenericRadialAtomicPotential
+    clf = UniversalTransformer(elements, rcut=rcut, angular=False)
+    grap = GenericRadialAtomicPotential(elements, algorithm, parameters=parameters or PEXP,
+                                        param_space_method=param_space_method,
+                                        moment_tensors=list(moment_tensors), cutoff_function=cutoff,
+                                        symmetric=symmetric, legacy_mode=legacy_mode)
+    nn = AtomicNN(elements, grap, hidden_sizes=hidden, minmax_scale=minmax,
+                  export_properties=("energy", "forces", "stress"))
+    nn.attach_transformer(clf)
+    nn.precision = precision
+    nn.initialize(seed=seed, bias_scale=0.1)
+    if minmax:
+        rng = np.random.RandomState(seed + 1)
+        D = nn.ndim()
+        for el in nn.elements:
+            nn.minmax[el] = (rng.rand(D) * 0.1 - 0.05, 1.0 + rng.rand(D) * 5.0)
+    return nn
+
+
+def oracle_grap_model(nn):
+    from oracle.grap import GrapModel
+    d = nn.descriptor.as_dict()
+    return GrapModel(nn.elements, nn.transformer.rcut, algorithm=d["algorithm"], parameters=d["parameters"],
+                     param_space_method=d["param_space_method"], moment_tensors=d["moment_tensors"],
+                     cutoff_function=d["cutoff_function"], symmetric=d["symmetric"],
+                     legacy_mode=d["legacy_mode"], weights=nn.weights, activation=nn._activation,
+                     use_resnet_dt=nn._use_resnet_dt, minmax=nn.minmax if nn._minmax_scale else None)
+
+
+def oracle_grap_eval(nn, atoms):
+    from oracle.grap import evaluate
+    eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
+    return evaluate(oracle_grap_model(nn), atoms.get_chemical_symbols(), atoms.positions,
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)

@@ -1,0 +1,81 @@
+"""GPU parity of the GRAP descriptor path (csrc/ta_grap.hip) against oracle/grap.py."""
+import numpy as np
+import pytest
+
+from tests.helpers import fcc, make_grap_nn, oracle_grap_eval
+from tests.test_gpu_sf import _alloy, E_TOL, F_TOL, G_TOL, W_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(nn, atoms_list):
+    from tensoralloy_amd import Engine
+    with Engine(nn) as eng:
+        res = eng.evaluate(atoms_list, descriptors=True)
+    for atoms, r in zip(atoms_list, res):
+        o = oracle_grap_eval(nn, atoms)
+        scale = max(1.0, np.abs(o["descriptors"]).max())
+        assert np.abs(r["descriptors"] - o["descriptors"]).max() < G_TOL * scale
+        assert abs(r["energy"] - o["energy"]) < E_TOL
+        assert np.abs(r["atomic"] - o["atomic"]).max() < E_TOL
+        assert np.abs(r["forces"] - o["forces"]).max() < F_TOL
+        assert np.abs(r["virial"] - o["virial"]).max() < W_TOL
+        assert np.abs(r["stress"] - o["stress_voigt"]).max() < 1e-8
+    return res
+
+
+def test_default_production_descriptor(lib):
+    """defaults.toml:131-155: pexp, 16 filters, moments 0..3, new mode, cosine cutoff, rc 6.0."""
+    rl = [1.0 + 0.2 * k for k in range(16)]
+    pl = [5.0 - 0.25 * k for k in range(16)]
+    nn = make_grap_nn(["Ni"], 6.0, [64, 64], "pexp", {"rl": rl, "pl": pl}, moment_tensors=[0, 1, 2, 3])
+    _compare(nn, [fcc(rep=(3, 3, 3)), fcc(rep=(2, 2, 2), a=3.3, seed=5)])
+
+
+def test_binary_be_w_pexp_polynomial(lib):
+    """The reference's own GRAP test case (test_grap.py:49-105): Be/W, pexp, moments 0 1 2,
+    polynomial cutoff, rc 5; legacy and new mode must agree to 1e-6."""
+    atoms = _alloy(["Be", "W"], rep=(2, 2, 2), a=3.6)
+    new = make_grap_nn(["Be", "W"], 5.0, [16, 16], cutoff="polynomial")
+    old = make_grap_nn(["Be", "W"], 5.0, [16, 16], cutoff="polynomial", legacy_mode=True)
+    g_new = _compare(new, [atoms])[0]["descriptors"]
+    g_old = _compare(old, [atoms])[0]["descriptors"]
+    assert np.abs(g_new - g_old).max() < 1e-6
+
+
+@pytest.mark.parametrize("algorithm,parameters,method", [
+    ("sf", {"eta": [0.1, 0.5, 1.0, 4.0], "omega": [0.0, 1.5]}, "cross"),
+    ("morse", {"D": [1.0, 1.0, 1.0], "gamma": [1.0, 1.0, 1.0], "r0": [3.3, 3.4, 3.5]}, "pair"),
+    ("density", {"A": [1.0], "beta": [1.0, 2.0, 3.0, 4.0], "re": [4.0]}, "cross"),
+    ("pexp", {"rl": [1.5, 2.0, 2.5], "pl": [1.0, 2.0, 3.0]}, "pair"),
+])
+def test_every_filter_family(lib, algorithm, parameters, method):
+    nn = make_grap_nn(["Mo", "Ni"], 6.0, [16], algorithm, parameters, moment_tensors=[0, 1, 2, 3],
+                      symmetric=True, param_space_method=method, minmax=True)
+    _compare(nn, [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
+
+
+def test_legacy_moment_subsets_and_many_filters(lib):
+    rl = [1.0 + 0.1 * k for k in range(20)]
+    pl = [4.0 - 0.1 * k for k in range(20)]
+    nn = make_grap_nn(["Ni"], 6.0, [16], "pexp", {"rl": rl, "pl": pl}, moment_tensors=[2, 0],
+                      legacy_mode=True)
+    assert nn.ndim() == 2 * 20
+    _compare(nn, [fcc(rep=(2, 2, 2), seed=8)])
+    nn = make_grap_nn(["Ni"], 6.0, [16], "pexp", {"rl": rl, "pl": pl}, moment_tensors=[1])
+    assert nn.ndim() == 2 * 20  # new mode emits every moment up to the largest (grap.py:606)
+    _compare(nn, [fcc(rep=(2, 2, 2), seed=8)])
+
+
+def test_molecule_medium_precision_and_calculator(lib, tmp_path):
+    from tensoralloy_amd import Atoms, TensorAlloyCalculator
+    nn = make_grap_nn(["C", "H"], 5.0, [16, 16], moment_tensors=[0, 1, 2, 3], precision="medium")
+    rng = np.random.RandomState(4)
+    pos = rng.rand(9, 3) * 4.0
+    atoms = Atoms(symbols=["C", "H", "H", "H", "C", "H", "H", "H", "H"], positions=pos,
+                  cell=np.eye(3) * 20.0, pbc=False)
+    _compare(nn, [atoms])
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "grap")))
+    o = oracle_grap_eval(nn, atoms)
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < 1e-5
+    assert calc.results["forces"].dtype == np.float32

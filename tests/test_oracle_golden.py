@@ -242,3 +242,74 @@ def test_zjw04xcp_oracle_finite_differences():
     # the mixing rule must NOT have been used for Mo-Ni
     plain = oracle_eam_eval(make_eam(["Mo", "Ni"], 6.0, potential="zjw04xc"), atoms)
     assert abs(plain["energy"] - o["energy"]) > 1e-3
+
+
+def test_grap_modes_agree_like_the_reference_tests():
+    """The reference pins GRAP only by self-consistency (nn/atomic/tests/test_grap.py): legacy ==
+    new mode to 1e-6 for Be/W pexp moments 0,1,2 with the polynomial cutoff (:49-105) and to 1e-8 for
+    bcc Fe morse moments 0,1 over lattice constants 2.87 (1 +- 0.2) (:108-149, the sign of G0)."""
+    from oracle import grap
+    from tests.helpers import PEXP
+    from tests.test_gpu_sf import _alloy
+    from tensoralloy_amd import Atoms
+    atoms = _alloy(["Be", "W"], rep=(2, 2, 2), a=3.6)
+    kw = dict(algorithm="pexp", parameters=PEXP, param_space_method="pair", moment_tensors=[0, 1, 2],
+              cutoff_function="polynomial")
+    sym, cell = atoms.get_chemical_symbols(), np.asarray(atoms.get_cell())
+    g1 = grap.descriptors(grap.GrapModel(["Be", "W"], 5.0, legacy_mode=True, **kw), sym, atoms.positions,
+                          cell, atoms.pbc)
+    g2 = grap.descriptors(grap.GrapModel(["Be", "W"], 5.0, legacy_mode=False, **kw), sym, atoms.positions,
+                          cell, atoms.pbc)
+    assert g1.shape == (32, 2 * 10 * 3) and np.abs(g1 - g2).max() < 1e-6
+    kw = dict(algorithm="morse", parameters={"D": [1.0] * 3, "gamma": [1.0] * 3, "r0": [3.3, 3.4, 3.5]},
+              param_space_method="pair", moment_tensors=[0, 1], cutoff_function="cosine")
+    saw_negative = False
+    for x in range(-20, 21, 4):
+        a = 2.87 * (1.0 + x / 100.0)
+        fe = Atoms(symbols=["Fe", "Fe"], positions=[[0, 0, 0], [a / 2] * 3], cell=np.eye(3) * a, pbc=True)
+        y = grap.descriptors(grap.GrapModel(["Fe"], 6.0, legacy_mode=False, **kw), ["Fe", "Fe"],
+                             fe.positions, np.asarray(fe.get_cell()), fe.pbc)
+        z = grap.descriptors(grap.GrapModel(["Fe"], 6.0, legacy_mode=True, **kw), ["Fe", "Fe"],
+                             fe.positions, np.asarray(fe.get_cell()), fe.pbc)
+        assert np.abs(y - z).max() < 1e-8
+        saw_negative |= bool((y[:, 0::2] < 0).any())
+    assert saw_negative  # the morse sums change sign in this range: sign(P0) matters
+
+
+def test_grap_packed_tensors_match_full_tensors():
+    """test_grap.py:152-200: T_dm . M_d of the packed components (with multiplicities) equals the sum
+    over the full 3^m Cartesian tensors."""
+    from oracle import grap
+    rng = np.random.RandomState(0)
+    D = rng.randn(40, 3)
+    u = D / np.linalg.norm(D, axis=1)[:, None]
+    M = grap.moment_coefficients(u, 3)
+    T = grap.multiplicity_tensor(3, symmetric=False)
+    packed = M @ T                                    # [p, m]
+    full = np.stack([np.ones(len(u)), u.sum(axis=1), np.einsum("pa,pb->p", u, u),
+                     np.einsum("pa,pb,pc->p", u, u, u)], axis=1)
+    assert np.abs(packed - full).max() < 1e-12
+    # and squared sums, the quantity the descriptor uses: sum_d T M_d^2 = |u|^(2m) = 1
+    assert np.abs((M ** 2) @ T - 1.0).max() < 1e-12
+
+
+def test_grap_oracle_finite_differences():
+    from oracle import grap
+    from tests.helpers import make_grap_nn, oracle_grap_model
+    from tests.test_gpu_sf import _alloy
+    atoms = _alloy(["Be", "W"], rep=(2, 2, 2), a=3.6)
+    for kwargs in (dict(moment_tensors=[0, 1, 2, 3], symmetric=True), dict(legacy_mode=True)):
+        m = oracle_grap_model(make_grap_nn(["Be", "W"], 5.0, [16], **kwargs))
+        sym, cell = atoms.get_chemical_symbols(), np.asarray(atoms.get_cell())
+        o = grap.evaluate(m, sym, atoms.positions, cell, atoms.pbc)
+        d = 1e-5
+        for (i, k) in [(0, 0), (5, 1), (17, 2)]:
+            p = atoms.positions.copy(); p[i, k] += d
+            ep = grap.evaluate(m, sym, p, cell, atoms.pbc)["energy"]
+            p = atoms.positions.copy(); p[i, k] -= d
+            em = grap.evaluate(m, sym, p, cell, atoms.pbc)["energy"]
+            assert abs(o["forces"][i, k] + (ep - em) / (2 * d)) < 1e-7
+        e = np.zeros((3, 3)); e[1, 2] = 1e-6
+        Ep = grap.evaluate(m, sym, atoms.positions @ (np.eye(3) + e), cell @ (np.eye(3) + e), atoms.pbc)["energy"]
+        Em = grap.evaluate(m, sym, atoms.positions @ (np.eye(3) - e), cell @ (np.eye(3) - e), atoms.pbc)["energy"]
+        assert abs(o["virial"][1, 2] - (Ep - Em) / 2e-6) < 1e-6
