@@ -137,6 +137,39 @@ def main():
                     "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
                                "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
                                "dW_max": float(np.abs(o["virial"] - r["virial"]).max())}}
+    # ---- N1: the reference's default production descriptor (io/input/defaults.toml:131-155):
+    # GRAP, pexp, 16 filters, moments 0..3, new mode, cosine cutoff, rc = 6.0; MLP 2 x 64
+    from oracle import grap as ograp
+    from tensoralloy_amd.grap import GenericRadialAtomicPotential
+    rl = [1.0 + 0.2 * k for k in range(16)]
+    pl = [5.0 - 0.25 * k for k in range(16)]
+    for tag, els, atoms in (("N1_grap_Ni", ["Ni"], ni_frame(611)), ("N1_grap_NiMo", ["Mo", "Ni"], None)):
+        if atoms is None:
+            base = ni_frame(611)
+            atoms = Atoms(symbols=["Mo" if k % 5 == 0 else "Ni" for k in range(len(base))],
+                          positions=base.positions, cell=np.asarray(base.get_cell()), pbc=True)
+        gd = GenericRadialAtomicPotential(els, "pexp", {"rl": rl, "pl": pl}, moment_tensors=[0, 1, 2, 3],
+                                          legacy_mode=False)
+        nn = AtomicNN(els, gd, hidden_sizes=[64, 64], activation="softplus", minmax_scale=False,
+                      export_properties=("energy", "forces", "stress"))
+        nn.attach_transformer(UniversalTransformer(els, rcut=6.0))
+        nn.initialize(seed=611)
+        with Engine(nn) as eng:
+            r = eng.evaluate([atoms])[0]
+            ms, slots = timeit(eng, WANT, steps=100)
+            d = gd.as_dict()
+            om = ograp.GrapModel(els, 6.0, algorithm="pexp", parameters=d["parameters"],
+                                 moment_tensors=d["moment_tensors"], legacy_mode=False,
+                                 weights=nn.weights, activation="softplus")
+            t0 = time.perf_counter()
+            o = ograp.evaluate(om, atoms.get_chemical_symbols(), atoms.positions,
+                               np.asarray(atoms.get_cell()), atoms.pbc)
+            out[tag] = {"atoms": len(atoms), "pairs": int(eng.info.n_pairs), "D": nn.ndim(),
+                        "ms_per_eval": ms, "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+                        "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
+                                   "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
+                                   "dW_max": float(np.abs(o["virial"] - r["virial"]).max()),
+                                   "cpu_oracle_s": time.perf_counter() - t0}}
     print(json.dumps(out, indent=1))
 
 

@@ -14,12 +14,15 @@
 // j = 4 step + (l >> 4)): no LDS, no cross-lane reduction for the sum over neighbours.
 // Q[k][m] = sum_d T[d][m] P[k][d]^2 is a 16-lane DPP row sum of the accumulator tile.
 //
-// Backward: A[k][d] = dE/dP[k][d] (grap_dp_kernel), then per 16-pair tile
+// Backward: A[k][d] = dE/dP[k][d] (formed while staging it in LDS), then per 16-pair tile
 //     a[j][d] = sum_k H_k(r_j) A[k][d],  b[j][d] = sum_k H'_k(r_j) A[k][d]     (MFMA again)
 //     dE/dD_j = sum_d b_d M_d u + a_d (dM_d/du - deg_d M_d u) / r               (row sum over d)
+// Both kernels run one wavefront (= workgroup) per centre and stage its pairs in LDS (unit
+// vector, r, fc, dfc/dr: the cutoff is evaluated once per pair, not once per filter).
 // Forces / virial / energy then use force_gather and frame_reduce like every other model.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -68,115 +71,149 @@ __device__ __forceinline__ double dpow3(double u, int n) {
   return n == 0 ? 0.0 : (n == 1 ? 1.0 : (n == 2 ? 2.0 * u : 3.0 * u * u));
 }
 
-// v(r) and dv/dr of one radial filter (without the cutoff)
-__device__ __forceinline__ void filter_fn(int algo, double p0, double p1, double p2, double r,
-                                          double inv_rc2, double &v, double &dv) {
+// v(r) and dv/dr of one radial filter (without the cutoff), from constants preprocessed on the
+// host (grap_create) so that no division and no logarithm is left per (pair, filter):
+//   sf      exp(-eta (r - omega)^2 / rc^2)                 c0 = eta / rc^2, c1 = omega
+//   morse   D [exp(-2 g (r - r0)) - 2 exp(-g (r - r0))]    c0 = D, c1 = gamma, c2 = r0
+//   density A exp(-beta (r / re - 1))                      c0 = A exp(beta), c1 = beta / re
+//   pexp    exp(-(r / rl)^pl) = exp(-exp(pl (ln r - ln rl)))   c0 = pl, c1 = ln rl
+// `logr` = ln r and `inv_r` are per-pair values staged in LDS.
+__device__ __forceinline__ void filter_fn(int algo, double c0, double c1, double c2, double r,
+                                          double logr, double inv_r, double &v, double &dv) {
   switch (algo) {
-    case GRAP_SF: {  // exp(-eta (r - omega)^2 / rc^2); p0 = eta, p1 = omega
-      const double t = r - p1;
-      v = ta_exp(-p0 * t * t * inv_rc2);
-      dv = v * (-2.0 * p0 * t * inv_rc2);
+    case GRAP_SF: {
+      const double t = r - c1;
+      v = ta_exp(-c0 * t * t);
+      dv = v * (-2.0 * c0 * t);
       break;
     }
-    case GRAP_MORSE: {  // D [exp(-2 g (r - r0)) - 2 exp(-g (r - r0))]; p0 = D, p1 = gamma, p2 = r0
-      const double e1 = ta_exp(-p1 * (r - p2));
+    case GRAP_MORSE: {
+      const double e1 = ta_exp(-c1 * (r - c2));
       const double e2 = e1 * e1;
-      v = p0 * (e2 - 2.0 * e1);
-      dv = p0 * p1 * (2.0 * e1 - 2.0 * e2);
+      v = c0 * (e2 - 2.0 * e1);
+      dv = c0 * c1 * (2.0 * e1 - 2.0 * e2);
       break;
     }
-    case GRAP_DENSITY: {  // A exp(-beta (r / re - 1)); p0 = A, p1 = beta, p2 = re
-      v = p0 * ta_exp(-p1 * (r / p2 - 1.0));
-      dv = v * (-p1 / p2);
+    case GRAP_DENSITY: {
+      v = c0 * ta_exp(-c1 * r);
+      dv = -c1 * v;
       break;
     }
-    default: {  // exp(-(r / rl)^pl); p0 = rl, p1 = pl
-      const double x = r / p0;
-      double xp;
-      if (p1 == 1.0) xp = x;
-      else if (p1 == 2.0) xp = x * x;
-      else if (p1 == 3.0) xp = x * x * x;
-      else xp = pow(x, p1);
+    default: {
+      const double xp = ta_exp(c0 * (logr - c1));
       v = ta_exp(-xp);
-      dv = v * (-p1 * xp / r);
+      dv = v * (-c0 * xp * inv_r);
       break;
     }
   }
-}
-
-// H = v fc, dH/dr
-__device__ __forceinline__ void filter_cut(const GrapParams &g, double p0, double p1, double p2,
-                                           double r, double r2, double &H, double &dH) {
-  double v, dv, f, dfdu;
-  filter_fn(g.algo, p0, p1, p2, r, g.inv_rc2, v, dv);
-  const double u = r2 * g.inv_rc2;
-  if (u < 1.0) {
-    cutoff_u(g.cutoff, u, f, dfdu);
-  } else {
-    f = 0.0;
-    dfdu = 0.0;
-  }
-  H = v * f;
-  dH = dv * f + v * dfdu * 2.0 * r * g.inv_rc2;
 }
 
 // block index of neighbour species sb for centre species sA: [AA, AB (B != A sorted)]
 __device__ __forceinline__ int term_block(int sA, int sb) { return sb == sA ? 0 : (sb < sA ? sb + 1 : sb); }
 
-// One wavefront per atom: P (kept for the backward pass) and the features.
-__global__ __launch_bounds__(kBlock) void grap_forward_kernel(GrapParams g, DeviceBatch b, double *Pbuf,
-                                                              int ndim) {
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (i >= b.n_atoms) return;
+constexpr int kChunk = 128;  // pairs of one (centre, species) segment staged in LDS at a time
+constexpr int kWave = 64;    // one wavefront per workgroup = per centre atom
+
+// pair fields staged per chunk: unit vector, r, 1/r, fc(r), dfc/dr
+struct PairLds {
+  double ux[kChunk], uy[kChunk], uz[kChunk], r[kChunk], inv_r[kChunk], f[kChunk], df[kChunk],
+      logr[kChunk];
+};
+
+__device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBatch &b, int first, int n,
+                                            PairLds &L, int lane) {
+  for (int t = lane; t < n; t += kWave) {
+    const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
+    const double r2 = rec[3], inv_r = rec[4];
+    const double r = r2 * inv_r;  // sqrt(r2): rec[4] = 1 / sqrt(r2)
+    L.ux[t] = rec[0] * inv_r;
+    L.uy[t] = rec[1] * inv_r;
+    L.uz[t] = rec[2] * inv_r;
+    L.r[t] = r;
+    L.inv_r[t] = inv_r;
+    L.logr[t] = g.algo == GRAP_PEXP ? log(r) : 0.0;
+    const double u = r2 * g.inv_rc2;
+    double f = 0.0, dfdu = 0.0;
+    if (u < 1.0) cutoff_u(g.cutoff, u, f, dfdu);
+    L.f[t] = f;
+    L.df[t] = dfdu * 2.0 * r * g.inv_rc2;
+  }
+}
+
+// One wavefront (= workgroup) per atom: P (kept for the backward pass) and the features.
+__global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, DeviceBatch b, double *Pbuf,
+                                                            int ndim) {
+  __shared__ PairLds L;
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
   const int m16 = lane & 15, q4 = lane >> 4;
   const int nel = g.nel, K = g.K, nd = g.nd;
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
-  const int c0 = comp_code(m16), c1 = comp_code(16 + m16 < kMaxComp ? 16 + m16 : 0);
+  const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
+  const int c0 = comp_code(m16), c1 = comp_code(d1);
   const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
   double T0[4], T1[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     T0[m] = d0_ok ? g.T[m16][m] : 0.0;
-    T1[m] = d1_ok ? g.T[16 + m16 < kMaxComp ? 16 + m16 : 0][m] : 0.0;
+    T1[m] = d1_ok ? g.T[d1][m] : 0.0;
+  }
+  const int n_kt = (K + 15) / 16;  // 1 or 2
+  double fp0[2], fp1[2], fp2[2];
+  bool k_ok[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int k = kt * 16 + m16;
+    k_ok[kt] = k < K;
+    fp0[kt] = k_ok[kt] ? g.fp[4 * k] : 1.0;
+    fp1[kt] = k_ok[kt] ? g.fp[4 * k + 1] : 1.0;
+    fp2[kt] = k_ok[kt] ? g.fp[4 * k + 2] : 1.0;
   }
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     const int tb = term_block(sA, sb);
-    for (int kt = 0; kt * 16 < K; ++kt) {
-      const int k = kt * 16 + m16;
-      const bool k_ok = k < K;
-      const double p0 = k_ok ? g.fp[4 * k] : 1.0, p1 = k_ok ? g.fp[4 * k + 1] : 1.0,
-                   p2 = k_ok ? g.fp[4 * k + 2] : 1.0;
-      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-      for (int base = lo; base < hi; base += 4) {
-        const int p = base + q4;
-        double h = 0.0, ma = 0.0, mb = 0.0;
-        if (p < hi) {
-          const double *rec = b.rec + kRecDoubles * (size_t)p;
-          const double r2 = rec[3], inv_r = rec[4];
-          const double ux = rec[0] * inv_r, uy = rec[1] * inv_r, uz = rec[2] * inv_r;
-          if (k_ok) {
-            double dH;
-            filter_cut(g, p0, p1, p2, sqrt(r2), r2, h, dH);
-          }
-          if (d0_ok) ma = pow3(ux, c0 & 3) * pow3(uy, (c0 >> 2) & 3) * pow3(uz, (c0 >> 4) & 3);
-          if (d1_ok) mb = pow3(ux, c1 & 3) * pow3(uy, (c1 >> 2) & 3) * pow3(uz, (c1 >> 4) & 3);
+    f64x4 acc0[2], acc1[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) acc0[kt] = acc1[kt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int first = lo; first < hi; first += kChunk) {
+      const int n = min(kChunk, hi - first);
+      __syncthreads();
+      stage_pairs(g, b, first, n, L, lane);
+      __syncthreads();
+      for (int base = 0; base < n; base += 4) {
+        const int t = base + q4;
+        const bool ok = t < n;
+        const int tt = ok ? t : 0;
+        const double ux = L.ux[tt], uy = L.uy[tt], uz = L.uz[tt], r = L.r[tt], f = ok ? L.f[tt] : 0.0;
+        const double logr = L.logr[tt], inv_r = L.inv_r[tt];
+        const double ma = (ok && d0_ok) ? pow3(ux, c0 & 3) * pow3(uy, (c0 >> 2) & 3) * pow3(uz, (c0 >> 4) & 3) : 0.0;
+        const double mb = (ok && d1_ok) ? pow3(ux, c1 & 3) * pow3(uy, (c1 >> 2) & 3) * pow3(uz, (c1 >> 4) & 3) : 0.0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          if (kt >= n_kt) break;
+          double v = 0.0, dv;
+          if (k_ok[kt]) filter_fn(g.algo, fp0[kt], fp1[kt], fp2[kt], r, logr, inv_r, v, dv);
+          const double h = v * f;
+          acc0[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, ma, acc0[kt], 0, 0, 0);
+          if (nd > 16) acc1[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, mb, acc1[kt], 0, 0, 0);
         }
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, ma, acc0, 0, 0, 0);
-        if (nd > 16) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, mb, acc1, 0, 0, 0);
       }
-      // accumulator register r holds P[k' = 16 kt + q4 + 4 r][d = m16 (+ 16)]
+    }
+    // accumulator register r of tile kt holds P[k' = 16 kt + q4 + 4 r][d = m16 (+ 16)]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt >= n_kt) break;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = kt * 16 + q4 + 4 * r;
         const bool kk_ok = kk < K;
         double *Prow = Pbuf + (((size_t)i * nel + tb) * K + (kk_ok ? kk : 0)) * nd;
-        if (kk_ok && d0_ok) Prow[m16] = acc0[r];
-        if (kk_ok && d1_ok) Prow[16 + m16] = acc1[r];
-        const double s0 = acc0[r] * acc0[r], s1 = acc1[r] * acc1[r];
-        const double p_lin = row16_sum(m16 == 0 ? acc0[r] : 0.0);  // P[k'][0] in every lane of the row
+        const double pa = acc0[kt][r], pb = acc1[kt][r];
+        if (kk_ok && d0_ok) Prow[m16] = pa;
+        if (kk_ok && d1_ok) Prow[16 + m16] = pb;
+        const double s0 = pa * pa, s1 = pb * pb;
+        const double p_lin = row16_sum(m16 == 0 ? pa : 0.0);  // P[k'][0] in every lane of the row
         double feat = 0.0;
         int col = -1;
 #pragma unroll
@@ -199,48 +236,16 @@ __global__ __launch_bounds__(kBlock) void grap_forward_kernel(GrapParams g, Devi
   }
 }
 
-// A[k][d] = dE/dP[k][d] = 2 P[k][d] sum_m c[k][m] T[d][m]   (+ dE/dG0 for d = 0 in legacy mode)
-__global__ __launch_bounds__(kBlock) void grap_dp_kernel(GrapParams g, DeviceBatch b, const double *Pbuf,
-                                                         double *Abuf, int ndim) {
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (i >= b.n_atoms) return;
-  const int nel = g.nel, K = g.K, nd = g.nd;
-  const int total = nel * K * nd;
-  for (int idx = lane; idx < total; idx += 64) {
-    const int d = idx % nd, k = (idx / nd) % K, tb = idx / (nd * K);
-    const size_t row = (((size_t)i * nel + tb) * K + k) * nd;
-    const double P = Pbuf[row + d];
-    const double *w = b.dEdG + (size_t)i * ndim + ((size_t)tb * K + k) * g.nf;
-    double s = 0.0, lin = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (m > g.max_moment) break;
-      const int col = g.col_of_m[m];
-      if (col < 0) continue;
-      double c = w[col];
-      if (m == 0) {
-        if (g.legacy) {
-          lin = (d == 0) ? c : 0.0;
-          c = 0.0;
-        } else {
-          const double P0 = Pbuf[row];
-          const double sgn = P0 > 0.0 ? 1.0 : (P0 < 0.0 ? -1.0 : 0.0);
-          c = c * sgn / (2.0 * sqrt(P0 * P0 + 1e-16));
-        }
-      }
-      s = fma(c, g.T[d][m], s);
-    }
-    Abuf[row + d] = 2.0 * P * s + lin;
-  }
-}
-
-// One wavefront per atom: dE/dD of its directed pairs.
-__global__ __launch_bounds__(kBlock) void grap_backward_kernel(GrapParams g, DeviceBatch b,
-                                                               const double *Abuf) {
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (i >= b.n_atoms) return;
+// One wavefront (= workgroup) per atom: dE/dD of its directed pairs.
+//   A[k][d] = dE/dP[k][d] = 2 P[k][d] sum_m c[k][m] T[d][m]  (+ dE/dG0 for d = 0 in legacy mode)
+// is formed while staging it in LDS.
+__global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, DeviceBatch b,
+                                                             const double *Pbuf, int ndim) {
+  __shared__ PairLds L;
+  __shared__ double A[kMaxFilters * kMaxComp];
+  __shared__ double FP[kMaxFilters * 4];
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
   const int m16 = lane & 15, q4 = lane >> 4;
   const int nel = g.nel, K = g.K, nd = g.nd;
   const int sA = b.species[i];
@@ -251,71 +256,111 @@ __global__ __launch_bounds__(kBlock) void grap_backward_kernel(GrapParams g, Dev
   const int nx0 = c0 & 3, ny0 = (c0 >> 2) & 3, nz0 = (c0 >> 4) & 3;
   const int nx1 = c1 & 3, ny1 = (c1 >> 2) & 3, nz1 = (c1 >> 4) & 3;
   const double deg0 = nx0 + ny0 + nz0, deg1 = nx1 + ny1 + nz1;
+  for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
+  const int Kp = (K + 3) & ~3;
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
+    if (lo == hi) continue;
     const int tb = term_block(sA, sb);
-    const double *A = Abuf + ((size_t)i * nel + tb) * K * nd;
-    for (int j0 = lo; j0 < hi; j0 += 16) {
-      // A operand rows: this lane's pair
-      const int pa = j0 + m16;
-      double r = 1.0, r2 = 1.0;
-      const bool pa_ok = pa < hi;
-      if (pa_ok) {
-        r2 = b.rec[kRecDoubles * (size_t)pa + 3];
-        r = sqrt(r2);
-      }
-      f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + q4;
-        double H = 0.0, dH = 0.0, B0 = 0.0, B1 = 0.0;
-        if (k < K) {
-          if (pa_ok) filter_cut(g, g.fp[4 * k], g.fp[4 * k + 1], g.fp[4 * k + 2], r, r2, H, dH);
-          if (d0_ok) B0 = A[(size_t)k * nd + m16];
-          if (d1_ok) B1 = A[(size_t)k * nd + 16 + m16];
-        }
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B0, a0, 0, 0, 0);
-        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B0, b0, 0, 0, 0);
-        if (nd > 16) {
-          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B1, a1, 0, 0, 0);
-          b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B1, b1, 0, 0, 0);
-        }
-      }
-      // register rr: pair j0 + q4 + 4 rr, component d = m16 (+ 16)
+    __syncthreads();
+    for (int idx = lane; idx < Kp * nd; idx += kWave) {
+      const int d = idx % nd, k = idx / nd;
+      double val = 0.0;
+      if (k < K) {
+        const size_t row = (((size_t)i * nel + tb) * K + k) * nd;
+        const double P = Pbuf[row + d];
+        const double *w = b.dEdG + (size_t)i * ndim + ((size_t)tb * K + k) * g.nf;
+        double s = 0.0, lin = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int p = j0 + q4 + 4 * rr;
-        const bool p_ok = p < hi;
-        double gx = 0.0, gy = 0.0, gz = 0.0;
-        if (p_ok) {
-          const double *rec = b.rec + kRecDoubles * (size_t)p;
-          const double inv_r = rec[4];
-          const double ux = rec[0] * inv_r, uy = rec[1] * inv_r, uz = rec[2] * inv_r;
-          if (d0_ok) {
-            const double px = pow3(ux, nx0), py = pow3(uy, ny0), pz = pow3(uz, nz0);
-            const double M = px * py * pz;
-            const double rad = (b0[rr] - deg0 * a0[rr] * inv_r) * M;  // multiplies u
-            const double t = a0[rr] * inv_r;
-            gx = fma(rad, ux, t * dpow3(ux, nx0) * py * pz);
-            gy = fma(rad, uy, t * px * dpow3(uy, ny0) * pz);
-            gz = fma(rad, uz, t * px * py * dpow3(uz, nz0));
+        for (int m = 0; m < 4; ++m) {
+          if (m > g.max_moment) break;
+          const int col = g.col_of_m[m];
+          if (col < 0) continue;
+          double c = w[col];
+          if (m == 0) {
+            if (g.legacy) {
+              lin = (d == 0) ? c : 0.0;
+              c = 0.0;
+            } else {
+              const double P0 = Pbuf[row];
+              const double sgn = P0 > 0.0 ? 1.0 : (P0 < 0.0 ? -1.0 : 0.0);
+              c = c * sgn / (2.0 * sqrt(P0 * P0 + 1e-16));
+            }
           }
-          if (d1_ok) {
-            const double px = pow3(ux, nx1), py = pow3(uy, ny1), pz = pow3(uz, nz1);
-            const double M = px * py * pz;
-            const double rad = (b1[rr] - deg1 * a1[rr] * inv_r) * M;
-            const double t = a1[rr] * inv_r;
-            gx += fma(rad, ux, t * dpow3(ux, nx1) * py * pz);
-            gy += fma(rad, uy, t * px * dpow3(uy, ny1) * pz);
-            gz += fma(rad, uz, t * px * py * dpow3(uz, nz1));
+          s = fma(c, g.T[d][m], s);
+        }
+        val = 2.0 * P * s + lin;
+      }
+      A[k * nd + d] = val;
+    }
+    for (int first = lo; first < hi; first += kChunk) {
+      const int n = min(kChunk, hi - first);
+      __syncthreads();
+      stage_pairs(g, b, first, n, L, lane);
+      __syncthreads();
+      for (int j0 = 0; j0 < n; j0 += 16) {
+        // A-operand rows: this lane's pair
+        const int ta = j0 + m16;
+        const bool ta_ok = ta < n;
+        const int tz = ta_ok ? ta : 0;
+        const double r = L.r[tz], f = ta_ok ? L.f[ta] : 0.0, df = ta_ok ? L.df[ta] : 0.0;
+        const double logr = L.logr[tz], inv_ra = L.inv_r[tz];
+        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+        for (int k0 = 0; k0 < Kp; k0 += 4) {
+          const int k = k0 + q4;
+          double H = 0.0, dH = 0.0;
+          if (k < K && ta_ok) {
+            double v, dv;
+            filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_ra, v, dv);
+            H = v * f;
+            dH = dv * f + v * df;
+          }
+          const double B0 = d0_ok ? A[k * nd + m16] : 0.0;
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B0, a0, 0, 0, 0);
+          b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B0, b0, 0, 0, 0);
+          if (nd > 16) {
+            const double B1 = d1_ok ? A[k * nd + 16 + m16] : 0.0;
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B1, a1, 0, 0, 0);
+            b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B1, b1, 0, 0, 0);
           }
         }
-        gx = row16_sum(gx);
-        gy = row16_sum(gy);
-        gz = row16_sum(gz);
-        if (p_ok && m16 == 0) {
-          b.g[4 * (size_t)p] = gx;
-          b.g[4 * (size_t)p + 1] = gy;
-          b.g[4 * (size_t)p + 2] = gz;
+        // register rr: pair j0 + q4 + 4 rr, component d = m16 (+ 16)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int t = j0 + q4 + 4 * rr;
+          const bool t_ok = t < n;
+          double gx = 0.0, gy = 0.0, gz = 0.0;
+          if (t_ok) {
+            const double inv_r = L.inv_r[t];
+            const double ux = L.ux[t], uy = L.uy[t], uz = L.uz[t];
+            if (d0_ok) {
+              const double px = pow3(ux, nx0), py = pow3(uy, ny0), pz = pow3(uz, nz0);
+              const double M = px * py * pz;
+              const double rad = (b0[rr] - deg0 * a0[rr] * inv_r) * M;  // multiplies u
+              const double tt = a0[rr] * inv_r;
+              gx = fma(rad, ux, tt * dpow3(ux, nx0) * py * pz);
+              gy = fma(rad, uy, tt * px * dpow3(uy, ny0) * pz);
+              gz = fma(rad, uz, tt * px * py * dpow3(uz, nz0));
+            }
+            if (d1_ok) {
+              const double px = pow3(ux, nx1), py = pow3(uy, ny1), pz = pow3(uz, nz1);
+              const double M = px * py * pz;
+              const double rad = (b1[rr] - deg1 * a1[rr] * inv_r) * M;
+              const double tt = a1[rr] * inv_r;
+              gx += fma(rad, ux, tt * dpow3(ux, nx1) * py * pz);
+              gy += fma(rad, uy, tt * px * dpow3(uy, ny1) * pz);
+              gz += fma(rad, uz, tt * px * py * dpow3(uz, nz1));
+            }
+          }
+          gx = row16_sum(gx);
+          gy = row16_sum(gy);
+          gz = row16_sum(gz);
+          if (t_ok && m16 == 0) {
+            double *dst = b.g + 4 * (size_t)(first + t);
+            dst[0] = gx;
+            dst[1] = gy;
+            dst[2] = gz;
+          }
         }
       }
     }
@@ -327,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void grap_backward_kernel(GrapParams g, Dev
 struct GrapModel {
   GrapParams p;
   double *fp = nullptr;                  // device filter constants
-  double *Pbuf = nullptr, *Abuf = nullptr;
+  double *Pbuf = nullptr;
   size_t cap_atoms = 0;
   int ndim = 0;
 };
@@ -417,6 +462,23 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
       return nullptr;
     }
   }
+  // constants in the form filter_fn wants
+  for (int k = 0; k < K; ++k) {
+    double *f = &host[4 * k];
+    if (algo == GRAP_SF) {
+      f[0] = f[0] * p.inv_rc2;
+    } else if (algo == GRAP_DENSITY) {
+      const double A = f[0], beta = f[1], re = f[2];
+      f[0] = A * std::exp(beta);
+      f[1] = beta / re;
+      f[2] = 0.0;
+    } else if (algo == GRAP_PEXP) {
+      const double rl = f[0], pl = f[1];
+      f[0] = pl;
+      f[1] = std::log(rl);
+      f[2] = 0.0;
+    }
+  }
   if (hipMalloc((void **)&g->fp, sizeof(host)) != hipSuccess ||
       hipMemcpy(g->fp, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) {
     delete g;
@@ -434,7 +496,6 @@ void grap_destroy(GrapModel *g) {
   if (!g) return;
   if (g->fp) (void)hipFree(g->fp);
   if (g->Pbuf) (void)hipFree(g->Pbuf);
-  if (g->Abuf) (void)hipFree(g->Abuf);
   delete g;
 }
 
@@ -442,27 +503,23 @@ void grap_ensure(GrapModel *g, const DeviceBatch &b) {
   const size_t n = (size_t)b.n_atoms;
   if (n <= g->cap_atoms) return;
   if (g->Pbuf) (void)hipFree(g->Pbuf);
-  if (g->Abuf) (void)hipFree(g->Abuf);
-  g->Pbuf = g->Abuf = nullptr;
+  g->Pbuf = nullptr;
   const size_t cap = n + n / 8 + 64;
   const size_t per = (size_t)g->p.nel * g->p.K * g->p.nd * sizeof(double);
-  if (hipMalloc((void **)&g->Pbuf, cap * per) != hipSuccess ||
-      hipMalloc((void **)&g->Abuf, cap * per) != hipSuccess)
-    throw std::bad_alloc();
+  if (hipMalloc((void **)&g->Pbuf, cap * per) != hipSuccess) throw std::bad_alloc();
   g->cap_atoms = cap;
 }
 
 void launch_grap_forward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, g->p, b, g->Pbuf, g->ndim);
+  hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
+                     g->ndim);
 }
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  const dim3 grid((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(grap_dp_kernel, grid, dim3(kBlock), 0, s, g->p, b, g->Pbuf, g->Abuf, g->ndim);
-  hipLaunchKernelGGL(grap_backward_kernel, grid, dim3(kBlock), 0, s, g->p, b, g->Abuf);
+  hipLaunchKernelGGL(grap_backward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
+                     g->ndim);
 }
 
 }  // namespace ta
