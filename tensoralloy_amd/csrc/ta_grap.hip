@@ -62,13 +62,14 @@ __device__ __forceinline__ int comp_code(int d) {
   return c;
 }
 
-__device__ __forceinline__ double pow3(double u, int n) {
-  const double u2 = u * u;
-  return n == 0 ? 1.0 : (n == 1 ? u : (n == 2 ? u2 : u2 * u));
-}
-// d/du u^n
-__device__ __forceinline__ double dpow3(double u, int n) {
-  return n == 0 ? 0.0 : (n == 1 ? 1.0 : (n == 2 ? 2.0 * u : 3.0 * u * u));
+// packed index of the component with exponents (nx, ny, nz); 0 when any exponent is negative
+__device__ __forceinline__ int comp_index(int nx, int ny, int nz) {
+  if (nx < 0 || ny < 0 || nz < 0) return 0;
+  const int code = nx | (ny << 2) | (nz << 4);
+  int idx = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxComp; ++k) idx = (comp_code(k) == code) ? k : idx;
+  return idx;
 }
 
 // v(r) and dv/dr of one radial filter (without the cutoff), from constants preprocessed on the
@@ -111,39 +112,83 @@ __device__ __forceinline__ void filter_fn(int algo, double c0, double c1, double
 // block index of neighbour species sb for centre species sA: [AA, AB (B != A sorted)]
 __device__ __forceinline__ int term_block(int sA, int sb) { return sb == sA ? 0 : (sb < sA ? sb + 1 : sb); }
 
-constexpr int kChunk = 128;  // pairs of one (centre, species) segment staged in LDS at a time
-constexpr int kWave = 64;    // one wavefront per workgroup = per centre atom
+constexpr int kWave = 64;  // one wavefront per workgroup = per centre atom
+constexpr int kFwdChunk = 64;  // pairs of one (centre, species) segment staged in LDS at a time
+constexpr int kBwdChunk = 32;
 
-// pair fields staged per chunk: unit vector, r, 1/r, fc(r), dfc/dr
+// Per-pair fields staged in LDS: r, ln r, 1/r, fc(r), dfc/dr, the unit vector and the table of
+// all packed monomials M[t][d] (every lane of a 16-lane row needs a different component of the
+// same pair: one ds_read instead of a per-lane select chain). Entries n .. round_up(n, 16) are
+// zero-filled so that the MFMA loops need no tail predicates.
+template <int CH>
 struct PairLds {
-  double ux[kChunk], uy[kChunk], uz[kChunk], r[kChunk], inv_r[kChunk], f[kChunk], df[kChunk],
-      logr[kChunk];
+  double r[CH], logr[CH], inv_r[CH], f[CH], df[CH], ux[CH], uy[CH], uz[CH];
+  double M[CH][kMaxComp];
 };
 
+template <int CH>
 __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBatch &b, int first, int n,
-                                            PairLds &L, int lane) {
-  for (int t = lane; t < n; t += kWave) {
-    const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
-    const double r2 = rec[3], inv_r = rec[4];
-    const double r = r2 * inv_r;  // sqrt(r2): rec[4] = 1 / sqrt(r2)
-    L.ux[t] = rec[0] * inv_r;
-    L.uy[t] = rec[1] * inv_r;
-    L.uz[t] = rec[2] * inv_r;
+                                            PairLds<CH> &L, int lane) {
+  const int npad = min(CH, (n + 15) & ~15);
+  for (int t = lane; t < npad; t += kWave) {
+    double ux = 0.0, uy = 0.0, uz = 0.0, r = 1.0, inv_r = 1.0, f = 0.0, df = 0.0, one = 0.0;
+    if (t < n) {
+      const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
+      const double r2 = rec[3];
+      inv_r = rec[4];
+      r = r2 * inv_r;  // sqrt(r2): rec[4] = 1 / sqrt(r2)
+      ux = rec[0] * inv_r;
+      uy = rec[1] * inv_r;
+      uz = rec[2] * inv_r;
+      const double u = r2 * g.inv_rc2;
+      double dfdu = 0.0;
+      if (u < 1.0) cutoff_u(g.cutoff, u, f, dfdu);
+      df = dfdu * 2.0 * r * g.inv_rc2;
+      one = 1.0;
+    }
     L.r[t] = r;
-    L.inv_r[t] = inv_r;
     L.logr[t] = g.algo == GRAP_PEXP ? log(r) : 0.0;
-    const double u = r2 * g.inv_rc2;
-    double f = 0.0, dfdu = 0.0;
-    if (u < 1.0) cutoff_u(g.cutoff, u, f, dfdu);
+    L.inv_r[t] = inv_r;
     L.f[t] = f;
-    L.df[t] = dfdu * 2.0 * r * g.inv_rc2;
+    L.df[t] = df;
+    L.ux[t] = ux;
+    L.uy[t] = uy;
+    L.uz[t] = uz;
+    double *M = L.M[t];
+    M[0] = one;
+    if (g.nd > 1) {
+      M[1] = ux;
+      M[2] = uy;
+      M[3] = uz;
+    }
+    if (g.nd > 4) {
+      const double xx = ux * ux, xy = ux * uy, xz = ux * uz, yy = uy * uy, yz = uy * uz, zz = uz * uz;
+      M[4] = xx;
+      M[5] = xy;
+      M[6] = xz;
+      M[7] = yy;
+      M[8] = yz;
+      M[9] = zz;
+      if (g.nd > 10) {
+        M[10] = xx * ux;
+        M[11] = xx * uy;
+        M[12] = xx * uz;
+        M[13] = xy * uy;
+        M[14] = xy * uz;
+        M[15] = xz * uz;
+        M[16] = yy * uy;
+        M[17] = yy * uz;
+        M[18] = yz * uz;
+        M[19] = zz * uz;
+      }
+    }
   }
 }
 
 // One wavefront (= workgroup) per atom: P (kept for the backward pass) and the features.
 __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, DeviceBatch b, double *Pbuf,
                                                             int ndim) {
-  __shared__ PairLds L;
+  __shared__ PairLds<kFwdChunk> L;
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const int m16 = lane & 15, q4 = lane >> 4;
@@ -151,65 +196,44 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
   const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
-  const int c0 = comp_code(m16), c1 = comp_code(d1);
   const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
-  double T0[4], T1[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    T0[m] = d0_ok ? g.T[m16][m] : 0.0;
-    T1[m] = d1_ok ? g.T[d1][m] : 0.0;
-  }
-  const int n_kt = (K + 15) / 16;  // 1 or 2
-  double fp0[2], fp1[2], fp2[2];
-  bool k_ok[2];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    const int k = kt * 16 + m16;
-    k_ok[kt] = k < K;
-    fp0[kt] = k_ok[kt] ? g.fp[4 * k] : 1.0;
-    fp1[kt] = k_ok[kt] ? g.fp[4 * k + 1] : 1.0;
-    fp2[kt] = k_ok[kt] ? g.fp[4 * k + 2] : 1.0;
-  }
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     const int tb = term_block(sA, sb);
-    f64x4 acc0[2], acc1[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) acc0[kt] = acc1[kt] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int first = lo; first < hi; first += kChunk) {
-      const int n = min(kChunk, hi - first);
-      __syncthreads();
-      stage_pairs(g, b, first, n, L, lane);
-      __syncthreads();
-      for (int base = 0; base < n; base += 4) {
-        const int t = base + q4;
-        const bool ok = t < n;
-        const int tt = ok ? t : 0;
-        const double ux = L.ux[tt], uy = L.uy[tt], uz = L.uz[tt], r = L.r[tt], f = ok ? L.f[tt] : 0.0;
-        const double logr = L.logr[tt], inv_r = L.inv_r[tt];
-        const double ma = (ok && d0_ok) ? pow3(ux, c0 & 3) * pow3(uy, (c0 >> 2) & 3) * pow3(uz, (c0 >> 4) & 3) : 0.0;
-        const double mb = (ok && d1_ok) ? pow3(ux, c1 & 3) * pow3(uy, (c1 >> 2) & 3) * pow3(uz, (c1 >> 4) & 3) : 0.0;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          if (kt >= n_kt) break;
-          double v = 0.0, dv;
-          if (k_ok[kt]) filter_fn(g.algo, fp0[kt], fp1[kt], fp2[kt], r, logr, inv_r, v, dv);
-          const double h = v * f;
-          acc0[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, ma, acc0[kt], 0, 0, 0);
-          if (nd > 16) acc1[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, mb, acc1[kt], 0, 0, 0);
+    for (int kt = 0; kt * 16 < K; ++kt) {
+      const int k = kt * 16 + m16;
+      const bool k_ok = k < K;
+      const double fp0 = k_ok ? g.fp[4 * k] : 0.0, fp1 = k_ok ? g.fp[4 * k + 1] : 0.0,
+                   fp2 = k_ok ? g.fp[4 * k + 2] : 0.0;
+      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      for (int first = lo; first < hi; first += kFwdChunk) {
+        const int n = min(kFwdChunk, hi - first);
+        __syncthreads();
+        stage_pairs(g, b, first, n, L, lane);
+        __syncthreads();
+        for (int base = 0; base < n; base += 4) {
+          const int t = base + q4;  // < round_up(n, 16): staged (zero beyond n)
+          double v, dv;
+          filter_fn(g.algo, fp0, fp1, fp2, L.r[t], L.logr[t], L.inv_r[t], v, dv);
+          const double h = k_ok ? v * L.f[t] : 0.0;
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d0_ok ? L.M[t][m16] : 0.0, acc0, 0, 0, 0);
+          if (nd > 16)
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d1_ok ? L.M[t][d1] : 0.0, acc1, 0, 0, 0);
         }
       }
-    }
-    // accumulator register r of tile kt holds P[k' = 16 kt + q4 + 4 r][d = m16 (+ 16)]
+      // accumulator register r holds P[k' = 16 kt + q4 + 4 r][d = m16 (+ 16)]
+      double T0[4], T1[4];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt >= n_kt) break;
+      for (int m = 0; m < 4; ++m) {
+        T0[m] = d0_ok ? g.T[m16][m] : 0.0;
+        T1[m] = d1_ok ? g.T[d1][m] : 0.0;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = kt * 16 + q4 + 4 * r;
         const bool kk_ok = kk < K;
         double *Prow = Pbuf + (((size_t)i * nel + tb) * K + (kk_ok ? kk : 0)) * nd;
-        const double pa = acc0[kt][r], pb = acc1[kt][r];
+        const double pa = acc0[r], pb = acc1[r];
         if (kk_ok && d0_ok) Prow[m16] = pa;
         if (kk_ok && d1_ok) Prow[16 + m16] = pb;
         const double s0 = pa * pa, s1 = pb * pb;
@@ -238,26 +262,48 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
 
 // One wavefront (= workgroup) per atom: dE/dD of its directed pairs.
 //   A[k][d] = dE/dP[k][d] = 2 P[k][d] sum_m c[k][m] T[d][m]  (+ dE/dG0 for d = 0 in legacy mode)
-// is formed while staging it in LDS.
+// is formed while staging it in LDS. dM_d/du_c = n_c M_{d - e_c}: a second read of the monomial
+// table at the index of the component with one power of u_c less.
 __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, DeviceBatch b,
                                                              const double *Pbuf, int ndim) {
-  __shared__ PairLds L;
-  __shared__ double A[kMaxFilters * kMaxComp];
-  __shared__ double FP[kMaxFilters * 4];
+  __shared__ PairLds<kBwdChunk> L;
+  extern __shared__ double dyn[];  // A[Kp][nd], then FP[4 K]
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const int m16 = lane & 15, q4 = lane >> 4;
   const int nel = g.nel, K = g.K, nd = g.nd;
+  const int Kp = (K + 3) & ~3;
+  double *A = dyn, *FP = dyn + Kp * nd;
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
   const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
-  const int c0 = comp_code(m16), c1 = comp_code(d1);
   const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
-  const int nx0 = c0 & 3, ny0 = (c0 >> 2) & 3, nz0 = (c0 >> 4) & 3;
-  const int nx1 = c1 & 3, ny1 = (c1 >> 2) & 3, nz1 = (c1 >> 4) & 3;
-  const double deg0 = nx0 + ny0 + nz0, deg1 = nx1 + ny1 + nz1;
+  // per-lane constants of the two components this lane owns in the output tiles
+  int ix0, iy0, iz0, ix1, iy1, iz1;
+  double nx0, ny0, nz0, nx1, ny1, nz1, deg0, deg1;
+  {
+    const int c = comp_code(m16);
+    const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
+    ix0 = comp_index(ex - 1, ey, ez);
+    iy0 = comp_index(ex, ey - 1, ez);
+    iz0 = comp_index(ex, ey, ez - 1);
+    nx0 = d0_ok ? ex : 0;
+    ny0 = d0_ok ? ey : 0;
+    nz0 = d0_ok ? ez : 0;
+    deg0 = ex + ey + ez;
+  }
+  {
+    const int c = comp_code(d1);
+    const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
+    ix1 = comp_index(ex - 1, ey, ez);
+    iy1 = comp_index(ex, ey - 1, ez);
+    iz1 = comp_index(ex, ey, ez - 1);
+    nx1 = d1_ok ? ex : 0;
+    ny1 = d1_ok ? ey : 0;
+    nz1 = d1_ok ? ez : 0;
+    deg1 = ex + ey + ez;
+  }
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
-  const int Kp = (K + 3) & ~3;
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     if (lo == hi) continue;
@@ -293,23 +339,20 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
       }
       A[k * nd + d] = val;
     }
-    for (int first = lo; first < hi; first += kChunk) {
-      const int n = min(kChunk, hi - first);
+    for (int first = lo; first < hi; first += kBwdChunk) {
+      const int n = min(kBwdChunk, hi - first);
       __syncthreads();
       stage_pairs(g, b, first, n, L, lane);
       __syncthreads();
       for (int j0 = 0; j0 < n; j0 += 16) {
-        // A-operand rows: this lane's pair
+        // A-operand rows: this lane's pair (zero-filled beyond n: f = df = 0)
         const int ta = j0 + m16;
-        const bool ta_ok = ta < n;
-        const int tz = ta_ok ? ta : 0;
-        const double r = L.r[tz], f = ta_ok ? L.f[ta] : 0.0, df = ta_ok ? L.df[ta] : 0.0;
-        const double logr = L.logr[tz], inv_ra = L.inv_r[tz];
+        const double r = L.r[ta], logr = L.logr[ta], inv_ra = L.inv_r[ta], f = L.f[ta], df = L.df[ta];
         f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
         for (int k0 = 0; k0 < Kp; k0 += 4) {
           const int k = k0 + q4;
           double H = 0.0, dH = 0.0;
-          if (k < K && ta_ok) {
+          if (k < K) {
             double v, dv;
             filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_ra, v, dv);
             H = v * f;
@@ -319,7 +362,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
           a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B0, a0, 0, 0, 0);
           b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B0, b0, 0, 0, 0);
           if (nd > 16) {
-            const double B1 = d1_ok ? A[k * nd + 16 + m16] : 0.0;
+            const double B1 = d1_ok ? A[k * nd + d1] : 0.0;
             a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B1, a1, 0, 0, 0);
             b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B1, b1, 0, 0, 0);
           }
@@ -328,34 +371,28 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int t = j0 + q4 + 4 * rr;
-          const bool t_ok = t < n;
-          double gx = 0.0, gy = 0.0, gz = 0.0;
-          if (t_ok) {
-            const double inv_r = L.inv_r[t];
-            const double ux = L.ux[t], uy = L.uy[t], uz = L.uz[t];
-            if (d0_ok) {
-              const double px = pow3(ux, nx0), py = pow3(uy, ny0), pz = pow3(uz, nz0);
-              const double M = px * py * pz;
-              const double rad = (b0[rr] - deg0 * a0[rr] * inv_r) * M;  // multiplies u
-              const double tt = a0[rr] * inv_r;
-              gx = fma(rad, ux, tt * dpow3(ux, nx0) * py * pz);
-              gy = fma(rad, uy, tt * px * dpow3(uy, ny0) * pz);
-              gz = fma(rad, uz, tt * px * py * dpow3(uz, nz0));
-            }
-            if (d1_ok) {
-              const double px = pow3(ux, nx1), py = pow3(uy, ny1), pz = pow3(uz, nz1);
-              const double M = px * py * pz;
-              const double rad = (b1[rr] - deg1 * a1[rr] * inv_r) * M;
-              const double tt = a1[rr] * inv_r;
-              gx += fma(rad, ux, tt * dpow3(ux, nx1) * py * pz);
-              gy += fma(rad, uy, tt * px * dpow3(uy, ny1) * pz);
-              gz += fma(rad, uz, tt * px * py * dpow3(uz, nz1));
-            }
+          const double inv_r = L.inv_r[t];
+          const double ux = L.ux[t], uy = L.uy[t], uz = L.uz[t];
+          const double *M = L.M[t];
+          double gx, gy, gz;
+          {
+            const double at = a0[rr] * inv_r;
+            const double rad = (b0[rr] - deg0 * at) * (d0_ok ? M[m16] : 0.0);  // multiplies u
+            gx = fma(rad, ux, at * nx0 * M[ix0]);
+            gy = fma(rad, uy, at * ny0 * M[iy0]);
+            gz = fma(rad, uz, at * nz0 * M[iz0]);
+          }
+          if (nd > 16) {
+            const double at = a1[rr] * inv_r;
+            const double rad = (b1[rr] - deg1 * at) * (d1_ok ? M[d1] : 0.0);
+            gx += fma(rad, ux, at * nx1 * M[ix1]);
+            gy += fma(rad, uy, at * ny1 * M[iy1]);
+            gz += fma(rad, uz, at * nz1 * M[iz1]);
           }
           gx = row16_sum(gx);
           gy = row16_sum(gy);
           gz = row16_sum(gz);
-          if (t_ok && m16 == 0) {
+          if (t < n && m16 == 0) {
             double *dst = b.g + 4 * (size_t)(first + t);
             dst[0] = gx;
             dst[1] = gy;
@@ -518,8 +555,10 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  hipLaunchKernelGGL(grap_backward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
-                     g->ndim);
+  const int Kp = (g->p.K + 3) & ~3;
+  const size_t lds = ((size_t)Kp * g->p.nd + 4 * (size_t)g->p.K) * sizeof(double);
+  hipLaunchKernelGGL(grap_backward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), lds, s, g->p, b,
+                     g->Pbuf, g->ndim);
 }
 
 }  // namespace ta
