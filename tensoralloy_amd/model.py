@@ -296,6 +296,63 @@ class AtomicNN:
             json.dump(meta, fp, indent=1)
         return stem + ".json"
 
+    def export_to_lammps_native(self, model_path: str, dtype=np.float64):
+        """
+        Write the `.npz` the reference exports for its LAMMPS pair style
+        (`AtomicNN.export_to_lammps_native`, atomic.py:304-480; the only TF-free weight interchange
+        format the reference defines): same keys, dtypes and conventions. GRAP descriptors only.
+        `load_model` / `TensorAlloyCalculator` read such a file directly.
+        """
+        if getattr(self._descriptor, "name", "") != "GRAP":
+            raise ValueError("The descriptor GenericRadialAtomicPotential is required")
+        if self._transformer is None:
+            raise ValueError("A transformer must be attached before exporting to a pb file.")
+        if self._minmax_scale:
+            raise ValueError("the native format has no slot for min-max scaling (atomic.py:360-478)")
+        from .atoms import atomic_masses, atomic_numbers
+        sizes = list(self._hidden_sizes[self._elements[0]])
+        for el in self._elements[1:]:
+            if list(self._hidden_sizes[el]) != sizes:
+                raise ValueError("Layer sizes of all elements must be the same")
+        layer_sizes = np.array(sizes + [1], dtype=np.int32)
+        actfn_map = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3}
+        if self._activation.lower() not in actfn_map:
+            raise ValueError(f"activation '{self._activation}' has no code in the native format")
+        chars = []
+        for el in self._elements:
+            chars.extend([ord(el[0]), 0] if len(el) == 1 else [ord(c) for c in el])
+        clf, gd = self._transformer, self._descriptor
+        data = {"rmax": dtype(clf.rcut), "nelt": np.int32(len(self._elements)),
+                "masses": np.array([atomic_masses[atomic_numbers[el]] for el in self._elements], dtype=dtype),
+                "numbers": np.array(chars, dtype=np.int32), "tdnp": np.int32(0),
+                "precision": np.int32(64 if dtype == np.float64 else 32), "use_fnn": np.int32(0)}
+        algo = gd.algorithm.as_dict(convert_to_pairs=True)
+        method = {"pexp": 0, "morse": 1, "density": 2, "sf": 3}[gd.algorithm.name]
+        data["descriptor::method"] = np.int32(method)
+        for key, values in algo["parameters"].items():
+            data[f"descriptor::{key}"] = np.array(values, dtype=dtype)
+        data["nlayers"] = np.int32(len(layer_sizes))
+        data["max_moment"] = np.int32(gd.max_moment)
+        data["actfn"] = np.int32(actfn_map[self._activation.lower()])
+        data["fctype"] = np.int32({"cosine": 0, "polynomial": 1}[gd.cutoff_function])
+        data["layer_sizes"] = layer_sizes
+        data["use_resnet_dt"] = np.int32(self._use_resnet_dt)
+        data["apply_output_bias"] = np.int32(self._use_atomic_static_energy)
+        data["is_T_symmetric"] = np.int32(gd.is_T_symmetric)
+        for i, el in enumerate(self._elements):
+            layers = self.weights[el]
+            for j, (w, b) in enumerate(layers[:-1]):
+                data[f"weights_{i}_{j}"] = np.asarray(w, dtype=dtype)
+                data[f"biases_{i}_{j}"] = (np.zeros(np.shape(w)[1], dtype=dtype) if b is None
+                                           else np.asarray(b, dtype=dtype))
+            wo, bo = layers[-1]
+            data[f"weights_{i}_{len(layers) - 1}"] = np.asarray(wo, dtype=dtype).ravel()
+            if self._use_atomic_static_energy:
+                data[f"biases_{i}_{len(layers) - 1}"] = (np.zeros(1, dtype=dtype) if bo is None
+                                                         else np.asarray(bo, dtype=dtype).ravel())
+        np.savez(model_path, **data)
+        return model_path if str(model_path).endswith(".npz") else str(model_path) + ".npz"
+
     # -- C ABI -----------------------------------------------------------------
     def to_desc(self):
         """Flatten into a `ta_model_desc`; returns (desc, keepalive list)."""
@@ -398,14 +455,75 @@ def _model_stem(path: str) -> str:
     return path
 
 
+def load_lammps_native(path: str):
+    """
+    Read a model in the reference's native `.npz` format (`export_to_lammps_native`,
+    atomic.py:304-480). Returns (nn, transformer, metadata dict) like `load_model`.
+    The format carries the moments 0..max_moment of the non-legacy GRAP (atomic.py:441, grap.py:606).
+    """
+    from .grap import GenericRadialAtomicPotential
+    from .transformer import UniversalTransformer
+    npz = np.load(path)
+    if int(npz["use_fnn"]) != 0:
+        raise ValueError(f"{path}: the 'nn' filter network of GRAP is not implemented by tensoralloy_amd")
+    if int(npz["tdnp"]) != 0:
+        raise ValueError(f"{path}: temperature-dependent models are not implemented by tensoralloy_amd")
+    chars = np.asarray(npz["numbers"], dtype=int).reshape(-1, 2)
+    elements = ["".join(chr(c) for c in row if c) for row in chars]
+    method = {0: "pexp", 1: "morse", 2: "density", 3: "sf"}[int(npz["descriptor::method"])]
+    keys = {"pexp": ["rl", "pl"], "morse": ["D", "gamma", "r0"], "density": ["A", "beta", "re"],
+            "sf": ["eta", "omega"]}[method]
+    parameters = {k: np.atleast_1d(npz[f"descriptor::{k}"]).astype(float).tolist() for k in keys}
+    max_moment = int(npz["max_moment"])
+    gd = GenericRadialAtomicPotential(
+        elements, method, parameters, param_space_method="pair",
+        moment_tensors=list(range(max_moment + 1)),
+        cutoff_function={0: "cosine", 1: "polynomial"}[int(npz["fctype"])],
+        symmetric=bool(int(npz["is_T_symmetric"])), legacy_mode=False)
+    layer_sizes = [int(x) for x in np.atleast_1d(npz["layer_sizes"])]
+    activation = {0: "relu", 1: "softplus", 2: "tanh", 3: "squareplus"}[int(npz["actfn"])]
+    bias_out = bool(int(npz["apply_output_bias"]))
+    nn = AtomicNN(elements, gd, hidden_sizes=layer_sizes[:-1], activation=activation, minmax_scale=False,
+                  use_resnet_dt=bool(int(npz["use_resnet_dt"])), use_atomic_static_energy=bias_out,
+                  export_properties=("energy", "forces", "stress"))
+    clf = UniversalTransformer(elements, rcut=float(npz["rmax"]), angular=False)
+    nn.attach_transformer(clf)
+    order = sorted(range(len(elements)), key=lambda i: elements[i])  # the file's own element order
+    L = len(layer_sizes)
+    for i in order:
+        layers = []
+        for j in range(L - 1):
+            layers.append((np.array(npz[f"weights_{i}_{j}"], dtype=np.float64),
+                           np.array(npz[f"biases_{i}_{j}"], dtype=np.float64).ravel()))
+        wo = np.array(npz[f"weights_{i}_{L - 1}"], dtype=np.float64).reshape(-1, 1)
+        bo = np.array(npz[f"biases_{i}_{L - 1}"], dtype=np.float64).ravel() if bias_out else None
+        layers.append((wo, bo))
+        nn.weights[elements[i]] = layers
+    nn.precision = "high" if int(npz["precision"]) == 64 else "medium"
+    meta = {"format": "tensoralloy/native-npz", "Transformer/params": clf.as_dict(),
+            "Metadata/precision": nn.precision, "Metadata/api": API_VERSION,
+            "Metadata/variational_energy": "energy", "Metadata/is_finite_temperature": 0,
+            "Metadata/ops": {"energy": "Output/Energy/energy:0", "energy/atom": "Output/Energy/atomic:0",
+                             "forces": "Output/Forces/forces:0", "stress": "Output/Stress/Voigt/stress:0",
+                             "virial": "Output/Stress/Full/virial:0",
+                             "total_pressure": "Output/Stress/pressure/GPa:0"},
+            "nn": nn.as_dict()}
+    return nn, clf, meta
+
+
 def load_model(graph_model_path: str):
     """
-    Read a model written by `AtomicNN.export` (or `EamAlloyNN.export`). Returns
-    (nn, transformer, metadata dict).
+    Read a model written by `AtomicNN.export` (or `EamAlloyNN.export`), or a native `.npz` written by
+    the reference's `export_to_lammps_native`. Returns (nn, transformer, metadata dict).
     """
     from .transformer import UniversalTransformer
 
     path = str(graph_model_path)
+    if path.endswith(".npz") and os.path.exists(path):
+        with np.load(path) as probe:
+            native = "descriptor::method" in probe.files or "use_fnn" in probe.files
+        if native:
+            return load_lammps_native(path)
     if path.endswith(".pb"):
         stem = _model_stem(path)
         if not os.path.exists(stem + ".json"):

@@ -79,3 +79,16 @@ def test_molecule_medium_precision_and_calculator(lib, tmp_path):
     o = oracle_grap_eval(nn, atoms)
     assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < 1e-5
     assert calc.results["forces"].dtype == np.float32
+
+
+def test_native_npz_model_runs_in_the_calculator(lib, tmp_path):
+    """A model in the reference's `export_to_lammps_native` format is loaded as is."""
+    from tensoralloy_amd import TensorAlloyCalculator
+    nn = make_grap_nn(["Mo", "Ni"], 6.0, [32, 32], moment_tensors=[0, 1, 2, 3])
+    path = nn.export_to_lammps_native(str(tmp_path / "MoNi.npz"))
+    calc = TensorAlloyCalculator(path)
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    o = oracle_grap_eval(nn, atoms)
+    assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
+    assert np.abs(calc.get_stress(atoms) - o["stress_voigt"]).max() < 1e-8

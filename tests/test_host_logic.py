@@ -291,3 +291,33 @@ def test_extxyz_config1_structure():
     assert abs(a.info["energy"] + 33.38981773) < 1e-9
     assert a.info["forces"].shape == (6, 3)
     assert abs(np.asarray(a.get_cell())[2, 2] - 24.294656) < 1e-9
+
+
+def test_lammps_native_npz_roundtrip(tmp_path):
+    """The reference's TF-free interchange format (atomic.py:304-480): keys, dtypes, conventions."""
+    from tests.helpers import make_grap_nn
+    from tensoralloy_amd import load_model
+    nn = make_grap_nn(["W", "Be"], 5.0, [16, 16], moment_tensors=[0, 1, 2, 3], symmetric=True,
+                      cutoff="polynomial")
+    path = nn.export_to_lammps_native(str(tmp_path / "BeW.npz"))
+    z = np.load(path)
+    assert z["rmax"] == 5.0 and z["nelt"] == 2 and z["precision"] == 64 and z["use_fnn"] == 0
+    assert list(z["numbers"]) == [ord("B"), ord("e"), ord("W"), 0]           # atomic.py:362-369
+    assert z["descriptor::method"] == 0 and len(z["descriptor::rl"]) == 10   # pexp
+    assert z["nlayers"] == 3 and list(z["layer_sizes"]) == [16, 16, 1]
+    assert z["max_moment"] == 3 and z["fctype"] == 1 and z["is_T_symmetric"] == 1 and z["actfn"] == 1
+    assert z["weights_0_0"].shape == (nn.ndim(), 16) and z["weights_1_2"].shape == (16,)
+    assert z["biases_0_2"].shape == (1,) and abs(z["masses"][0] - 9.0121831) < 1e-6
+    nn2, clf2, meta = load_model(path)
+    assert nn2.elements == ["Be", "W"] and clf2.rcut == 5.0 and not clf2.angular
+    assert nn2.descriptor.as_dict()["moment_tensors"] == [0, 1, 2, 3] and nn2.descriptor.is_T_symmetric
+    assert nn2.descriptor.algorithm.as_dict(True)["parameters"] == nn.descriptor.algorithm.as_dict(True)["parameters"]
+    for el in nn.elements:
+        for (w, b), (w2, b2) in zip(nn.weights[el], nn2.weights[el]):
+            assert np.array_equal(np.asarray(w), w2) and np.array_equal(np.ravel(b), b2)
+    assert set(meta["Metadata/ops"]) >= {"energy", "forces", "stress"}
+    d1, _ = nn.to_desc()
+    d2, _ = nn2.to_desc()
+    assert d1.kind == d2.kind == 4 and d1.n_grap_params == d2.n_grap_params
+    with pytest.raises(ValueError):
+        make_nn(["Ni"], 6.0, False, [8]).export_to_lammps_native(str(tmp_path / "sf.npz"))
