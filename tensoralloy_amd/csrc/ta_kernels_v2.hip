@@ -200,6 +200,46 @@ __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, c
   return mask;
 }
 
+// Lane balance. The expensive triple body runs once per set bit of a lane's candidate mask, and
+// a wavefront runs as long as its busiest lane: with lanes in pair order the mean lane has 20 set
+// bits but the mean wavefront maximum is 37. When a workgroup holds one pair per lane and a single
+// scan pass (n / 2 <= 64), the (pair, mask) jobs are therefore re-dealt to the lanes in
+// descending popcount order (counting sort through LDS), so the lanes of a wavefront finish
+// together. Which lane runs a pair does not change what is computed for it.
+// Scratch aliases the single-precision rings, which are dead once the masks exist.
+__device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M, int &item,
+                                                 unsigned long long &mask) {
+  int *hist = reinterpret_cast<int *>(f.xf);                      // [65] (+ pad)
+  int *start = hist + 66;                                        // [65]
+  unsigned long long *pmask = reinterpret_cast<unsigned long long *>(hist + 132);  // [cap]
+  int *pitem = reinterpret_cast<int *>(pmask + cap);             // [cap]
+  const int tid = threadIdx.x;
+  const bool active = tid < M;
+  __syncthreads();  // every lane is done with the rings
+  if (tid < 66) hist[tid] = 0;
+  __syncthreads();
+  const int bucket = 64 - (active ? __popcll(mask) : 0);
+  int rank = 0;
+  if (active) rank = atomicAdd(&hist[bucket], 1);
+  __syncthreads();
+  if (tid < 65) {
+    int s = 0;
+    for (int k = 0; k < tid; ++k) s += hist[k];
+    start[tid] = s;
+  }
+  __syncthreads();
+  if (active) {
+    const int slot = start[bucket] + rank;
+    pitem[slot] = item;
+    pmask[slot] = mask;
+  }
+  __syncthreads();
+  if (active) {
+    item = pitem[tid];
+    mask = pmask[tid];
+  }
+}
+
 // DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
@@ -214,7 +254,8 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   const double beta = ch.beta[0];
   stage(sf, beta, b, f, s0, M, geom);
 
-  for (int item = threadIdx.x; item < M; item += blockDim.x) {
+  // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -233,9 +274,14 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = partner_mask(sf, f, base, n, a, sc, smax);
-      // the candidate mask is geometry only: keep it for the backward kernel
-      if (b.masks) b.masks[(size_t)(sc >> 6) * b.n_pairs + p] = mask;
+      unsigned long long mask;
+      if (have_mask) {
+        mask = mask0;
+      } else {
+        mask = partner_mask(sf, f, base, n, a, sc, smax);
+        // the candidate mask is geometry only: keep it for the backward kernel
+        if (b.masks) b.masks[(size_t)(sc >> 6) * b.n_pairs + p] = mask;
+      }
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -281,6 +327,31 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
           const int c = ch.chan[ig * NZ + iz];
           b.part4[(size_t)(sp * sf.n_ang + c) * b.n_pairs + p] = acc[sp][ig][iz] * ch.kz[iz];
         }
+  };
+
+  // balanced path: one pair per lane, one scan pass for every centre of the workgroup
+  int item = threadIdx.x;
+  const bool active = item < M;
+  int n_own = 0;
+  if (active) {
+    const int i = b.pair_i[s0 + item];
+    n_own = b.pair_start[i + 1] - b.pair_start[i];
+  }
+  const bool one_pass = M <= (int)blockDim.x && !__syncthreads_or(active && (n_own >> 1) > 64);
+  if (one_pass) {
+    unsigned long long mask = 0ull;
+    if (active) {
+      const int64_t p = (int64_t)s0 + item;
+      const int i = b.pair_i[p];
+      const int base = b.pair_start[i] - s0;
+      const int smax = (f.H[item] != 0.0) ? n_own / 2 : 0;
+      if (smax > 0) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
+      if (b.masks) b.masks[p] = mask;
+    }
+    deal_by_popcount(f, b.cap, M, item, mask);
+    if (active) run_item(item, true, mask);
+  } else {
+    for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull);
   }
 }
 
@@ -301,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
   stage(sf, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
-  for (int item = threadIdx.x; item < M; item += blockDim.x) {
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -331,8 +402,9 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     double gx = 0.0, gy = 0.0, gz = 0.0;
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
-                                        : partner_mask(sf, f, base, n, a, sc, smax);
+      unsigned long long mask = have_mask ? mask0
+                                : (b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
+                                           : partner_mask(sf, f, base, n, a, sc, smax));
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -400,6 +472,32 @@ __global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChu
     atomicAdd(&gacc[item], gx);
     atomicAdd(&gacc[kCap + item], gy);
     atomicAdd(&gacc[2 * kCap + item], gz);
+  };
+
+  {
+    int item = threadIdx.x;
+    const bool active = item < M;
+    int n_own = 0;
+    if (active) {
+      const int i = b.pair_i[s0 + item];
+      n_own = b.pair_start[i + 1] - b.pair_start[i];
+    }
+    const bool one_pass = M <= (int)blockDim.x && !__syncthreads_or(active && (n_own >> 1) > 64);
+    if (one_pass) {  // see deal_by_popcount
+      unsigned long long mask = 0ull;
+      if (active) {
+        const int64_t p = (int64_t)s0 + item;
+        const int i = b.pair_i[p];
+        const int base = b.pair_start[i] - s0;
+        const int smax = (f.H[item] != 0.0) ? n_own / 2 : 0;
+        if (smax > 0)
+          mask = b.masks ? b.masks[p] : partner_mask(sf, f, base, n_own, item - base, 1, smax);
+      }
+      deal_by_popcount(f, kCap, M, item, mask);
+      if (active) run_item(item, true, mask);
+    } else {
+      for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull);
+    }
   }
   __syncthreads();
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
