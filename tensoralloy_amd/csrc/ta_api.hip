@@ -515,15 +515,20 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       end(TA_K_PAIR_GEOMETRY);
       used[TA_K_PAIR_GEOMETRY] = true;
     }
+    h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
+    // the second-generation forward kernel assembles the descriptors itself in its last launch
+    const bool reduce_in_forward = h->sf.angular && h->use_v2 && !h->use_v3;
     if (h->sf.angular) {
       begin(TA_K_G4_FORWARD);
       if (h->use_v2) {
         bool geometry = true;
+        size_t left = h->chunks_v2.size();
         for (const ChunkPlan &cp : h->chunks_v2) {
+          --left;
           if (h->use_v3)
             launch_g4_forward_v3(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
           else
-            launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
+            launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, left == 0, db, s);
           geometry = false;
         }
       } else
@@ -531,11 +536,12 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       end(TA_K_G4_FORWARD);
       used[TA_K_G4_FORWARD] = true;
     }
-    h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
-    begin(TA_K_DESCRIPTOR_REDUCE);
-    launch_descriptor_reduce(h->sf, db, s);
-    end(TA_K_DESCRIPTOR_REDUCE);
-    used[TA_K_DESCRIPTOR_REDUCE] = true;
+    if (!reduce_in_forward) {
+      begin(TA_K_DESCRIPTOR_REDUCE);
+      launch_descriptor_reduce(h->sf, db, s);
+      end(TA_K_DESCRIPTOR_REDUCE);
+      used[TA_K_DESCRIPTOR_REDUCE] = true;
+    }
     begin(TA_K_MLP);
     launch_mlp_all(h->mlp_dev, h->mlp, h->n_elements, h->activation, h->sf.ndim, db,
                    h->mlp_scratch.ptr, s);

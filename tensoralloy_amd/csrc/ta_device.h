@@ -113,8 +113,9 @@ size_t g4_lds_bytes(int nnl_max);
 
 // second-generation angular kernels (ta_kernels_v2.hip); `ch` holds one beta
 size_t v2_lds_bytes(bool backward, int cap);
+// `reduce`: last forward launch of an evaluation, also assembles the descriptor vectors
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
-                          const DeviceBatch &b, hipStream_t s);
+                          bool reduce, const DeviceBatch &b, hipStream_t s);
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
 

@@ -32,6 +32,7 @@
 
 #include "ta_device.h"
 #include "ta_math.h"
+#include "ta_reduce.h"
 
 namespace ta {
 namespace {
@@ -58,11 +59,13 @@ struct Fields {
 
 __device__ __forceinline__ Fields carve(double *lds, int cap) {
   Fields f;
-  f.x = lds;
+  // r2 first: x .. G and the rings behind them are one contiguous region that is dead once the
+  // triple body is done (the descriptor assembly reuses it, see reduce_from_lds)
+  f.r2 = lds;
+  f.x = f.r2 + cap;
   f.y = f.x + cap;
   f.z = f.y + cap;
-  f.r2 = f.z + cap;
-  f.inv = f.r2 + cap;
+  f.inv = f.z + cap;
   f.H = f.inv + cap;
   f.G = f.H + cap;
   f.xf = reinterpret_cast<float *>(f.G + cap);
@@ -240,12 +243,74 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
   }
 }
 
+// Descriptor vectors of the workgroup's centres from data that is still in LDS: G2 from r^2
+// (sf.py:79-119), G4 from the per-pair partial sums `red[local channel][item]` the lanes left
+// there (local channel = (partner species * NG + ig) * NZ + iz), concatenated as sf.py:184-215.
+// One wavefront per centre, round robin.
+template <int NSPEC, int NG, int NZ>
+__device__ __forceinline__ void reduce_from_lds(const SFParams &sf, const AngChunk &ch,
+                                                const DeviceBatch &b, const Fields &f,
+                                                const double *red, int cap, int c0, int c1, int s0) {
+  const int nel = sf.n_elements;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  for (int64_t i = c0 + w; i < c1; i += nwaves) {
+    const int sA = b.species[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    double *Gi = b.G + (size_t)i * sf.ndim;
+    for (int sb = 0; sb < nel; ++sb) {
+      const int tr = radial_term2(sA, sb);
+      const int q0 = seg[sb] - s0, q1 = seg[sb + 1] - s0;
+      for (int cc = 0; cc < sf.n_rad; cc += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = q0 + l; q < q1; q += 64) {
+          const double r2 = f.r2[q];
+          const double u = r2 * sf.inv_rc2;
+          const double r = sqrt(r2);
+          const double fc = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = (cc + k < sf.n_rad) ? cc + k : cc;
+            const double dr = r - sf.omega[c];
+            acc[k] += ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2) * fc;  // sf.py:101-108
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double v = wave_sum(acc[k]);
+          if (l == 0 && cc + k < sf.n_rad) Gi[tr * sf.n_rad + cc + k] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int s1 = 0; s1 < NSPEC; ++s1)
+#pragma unroll
+      for (int s2 = s1; s2 < NSPEC; ++s2) {
+        const int t = angular_term2(s1, s2, nel);
+        const int a0 = seg[s1] - s0, a1 = seg[s1 + 1] - s0;
+        const int b0 = seg[s2] - s0, b1 = seg[s2 + 1] - s0;
+#pragma unroll
+        for (int gz = 0; gz < NG * NZ; ++gz) {
+          double v = 0.0;
+          const double *colA = red + (size_t)(s2 * NG * NZ + gz) * cap;
+          for (int q = a0 + l; q < a1; q += 64) v += colA[q];
+          if (s1 != s2) {
+            const double *colB = red + (size_t)(s1 * NG * NZ + gz) * cap;
+            for (int q = b0 + l; q < b1; q += 64) v += colB[q];
+          }
+          v = wave_sum(v);
+          if (l == 0) Gi[sf.n_radial_dim + t * sf.n_ang + ch.chan[gz]] = sf.ang_scale * v;
+        }
+      }
+  }
+}
+
 // DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
 __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
-                                                               DeviceBatch b, int geom) {
+                                                               DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
+  const int geom = flags & 1;
   extern __shared__ double lds[];
   const Fields f = carve(lds, b.cap);
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
@@ -255,7 +320,8 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   stage(sf, beta, b, f, s0, M, geom);
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
-  auto run_item = [&](int item, bool have_mask, unsigned long long mask0) {
+  // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -325,7 +391,11 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 #pragma unroll
         for (int iz = 0; iz < NZ; ++iz) {
           const int c = ch.chan[ig * NZ + iz];
-          b.part4[(size_t)(sp * sf.n_ang + c) * b.n_pairs + p] = acc[sp][ig][iz] * ch.kz[iz];
+          const double v = acc[sp][ig][iz] * ch.kz[iz];
+          if (out)
+            out[(sp * NG + ig) * NZ + iz] = v;
+          else
+            b.part4[(size_t)(sp * sf.n_ang + c) * b.n_pairs + p] = v;
         }
   };
 
@@ -349,9 +419,49 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       if (b.masks) b.masks[p] = mask;
     }
     deal_by_popcount(f, b.cap, M, item, mask);
-    if (active) run_item(item, true, mask);
+    // flags & 4: this launch holds every angular channel of the model, and the partial sums fit
+    // behind r2 in LDS: the descriptors are assembled without a round trip through part4
+    constexpr int kLocal = NSPEC * NG * NZ;
+    if ((flags & 4) && kLocal <= 6) {
+      double mine[kLocal];
+#pragma unroll
+      for (int k = 0; k < kLocal; ++k) mine[k] = 0.0;
+      if (active) run_item(item, true, mask, mine);
+      __syncthreads();  // nobody reads x .. G or the sort scratch any more
+      double *red = f.x;
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < kLocal; ++k) red[(size_t)k * b.cap + item] = mine[k];
+      }
+      __syncthreads();
+      reduce_from_lds<NSPEC, NG, NZ>(sf, ch, b, f, red, b.cap, c0, c1, s0);
+      return;
+    }
+    if (active) run_item(item, true, mask, nullptr);
   } else {
-    for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull);
+    for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, nullptr);
+  }
+
+  // Last forward launch of the evaluation (flags & 2): the workgroup owns whole centres, so it
+  // also assembles their descriptor vectors (G2 from the pair records, G4 from the per-pair
+  // partial sums of all launches) instead of leaving that to a separate kernel.
+  if (flags & 2) {
+    __syncthreads();  // this workgroup's rec / part4 stores are visible to all of its lanes
+    const int ncent = c1 - c0;
+    const int nwaves = blockDim.x >> 6;
+    if (ncent <= nwaves) {  // one wavefront per centre
+      const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+      const bool act = w < ncent;
+      const int64_t i = c0 + (act ? w : 0);
+      atom_descriptors<64>(sf, b, i, l, act, [&](int c, double v) { b.G[(size_t)i * sf.ndim + c] = v; });
+    } else {                // one 16-lane row per centre, several rounds
+      const int row = threadIdx.x >> 4, l = threadIdx.x & 15, nrows = blockDim.x >> 4;
+      for (int k0 = 0; k0 < ncent; k0 += nrows) {
+        const bool act = k0 + row < ncent;
+        const int64_t i = c0 + (act ? k0 + row : 0);
+        atom_descriptors<16>(sf, b, i, l, act, [&](int c, double v) { b.G[(size_t)i * sf.ndim + c] = v; });
+      }
+    }
   }
 }
 
@@ -600,10 +710,12 @@ size_t v2_lds_bytes(bool backward, int cap) {
 
 // `ch` must describe ONE beta (nb == 1).
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
-                          const DeviceBatch &b, hipStream_t s) {
+                          bool reduce, const DeviceBatch &b, hipStream_t s) {
   if (b.n_blk == 0) return;
   const int nspec = sf.n_elements;
-  const int geom = geometry ? 1 : 0;
+  // bit 0: compute the pair geometry; bit 1: assemble the descriptors at the end; bit 2: this is
+  // the only forward launch (all angular channels are here)
+  const int geom = (geometry ? 1 : 0) | (reduce ? 2 : 0) | ((geometry && reduce) ? 4 : 0);
   TA_DISPATCH_V2(fwd_t, sf, ch, b, geom, s);
 }
 
