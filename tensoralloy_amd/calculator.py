@@ -13,7 +13,9 @@ Differences (documented in INTEGRATION.md):
     cannot be parsed without TensorFlow and raise `ValueError`.
   * `session`, `graph`, `get_op` are TensorFlow objects in the reference; here
     they raise `AttributeError`.
-  * `hessian`, `elastic`, `eentropy`, `free_energy` are not implemented.
+  * `hessian` and `elastic` are central differences of the analytic forces / virial (the
+    reference differentiates its graph twice, basic.py:411-421, constraint/elastic.py:24-92);
+    `eentropy`, `free_energy` are not implemented.
 """
 from __future__ import annotations
 
@@ -134,7 +136,11 @@ class TensorAlloyCalculator(BaseCalculator):
         return clf.map_array(values.reshape((-1, 1)), reverse=True).flatten()
 
     def get_hessian(self, atoms=None):
-        return self.get_property("hessian", atoms)
+        """d2E/dR2 as [3N, 3N] in the caller's atom order (calculator.py:228-241)."""
+        atoms = atoms if atoms is not None else self.atoms
+        hessian = self.get_property("hessian", atoms)
+        clf = self.transformer.get_vap_transformer(atoms)
+        return clf.reverse_map_hessian(hessian)
 
     def get_forces(self, atoms=None):
         atoms = atoms if atoms is not None else self.atoms
@@ -158,7 +164,78 @@ class TensorAlloyCalculator(BaseCalculator):
         return np.mean(stress[:3]) * (-1.0) / GPa
 
     def get_elastic_constant_tensor(self, atoms=None):
-        return self.get_property("elastic", atoms, allow_calculation=True)
+        """6 x 6 elastic constants in GPa, upper triangle mirrored (calculator.py:297-322)."""
+        atoms = atoms if atoms is not None else self.atoms
+        assert np.all(atoms.pbc)
+        elastic = np.array(self.get_property("elastic", atoms, allow_calculation=True))
+        for i in range(6):
+            for j in range(i + 1, 6):
+                elastic[j, i] = elastic[i, j]
+        return elastic
+
+    # -- second derivatives ------------------------------------------------------------
+    _FD_STEP = 1e-4  # Angstrom; central differences of analytic first derivatives
+
+    def _displaced(self, atoms, positions=None, cell=None):
+        from .atoms import Atoms
+        return Atoms(numbers=np.asarray(atoms.numbers).copy(),
+                     positions=atoms.positions if positions is None else positions,
+                     cell=np.asarray(atoms.get_cell(complete=True)) if cell is None else cell,
+                     pbc=np.asarray(atoms.pbc).copy())
+
+    def _hessian(self, atoms, vap):
+        """[n_vap, 3, n_vap, 3], GSL order, virtual atom = zero row/column: the layout of
+        `tf.hessians(energy, positions)` (basic.py:411-421). H = -dF/dR."""
+        n = len(atoms)
+        d = self._FD_STEP
+        want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
+        H = np.zeros((n, 3, n, 3))
+        jobs = [(i, a, sgn) for i in range(n) for a in range(3) for sgn in (1.0, -1.0)]
+        chunk = max(2, min(len(jobs), (1 << 18) // max(n, 1) // 2 * 2))
+        for k0 in range(0, len(jobs), chunk):
+            part = jobs[k0:k0 + chunk]
+            frames = []
+            for i, a, sgn in part:
+                pos = atoms.positions.copy()
+                pos[i, a] += sgn * d
+                frames.append(self._displaced(atoms, positions=pos))
+            res = self._engine.evaluate(frames, want=want)
+            for (i, a, sgn), r in zip(part, res):
+                H[i, a] -= sgn * r["forces"] / (2.0 * d)
+        H = 0.5 * (H + H.transpose(2, 3, 0, 1))
+        nv = vap.max_vap_natoms
+        out = np.zeros((nv, 3, nv, 3))
+        idx = np.asarray(vap.local_to_gsl)
+        out[np.ix_(idx, range(3), idx, range(3))] = H
+        return out
+
+    def _elastic(self, atoms):
+        """C[vi, vj] = ((dW_ij/dh)^T h)_kl / V / GPa with the positions held fixed, as the reference's
+        op differentiates the virial with respect to the cell placeholder
+        (nn/constraint/elastic.py:24-44); Voigt rows/columns xx yy zz yz xz xy."""
+        d = self._FD_STEP
+        want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
+        h = np.asarray(atoms.get_cell(complete=True), dtype=np.float64)
+        frames, keys = [], []
+        for a in range(3):
+            for b in range(3):
+                for sgn in (1.0, -1.0):
+                    cell = h.copy()
+                    cell[a, b] += sgn * d
+                    frames.append(self._displaced(atoms, cell=cell))
+                    keys.append((a, b, sgn))
+        res = self._engine.evaluate(frames, want=want)
+        dW = np.zeros((3, 3, 3, 3))  # [i, j, a, b] = dW_ij / dh_ab
+        for (a, b, sgn), r in zip(keys, res):
+            dW[:, :, a, b] += sgn * r["virial"] / (2.0 * d)
+        volume = abs(np.linalg.det(h))
+        pairs = [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
+        C = np.zeros((6, 6))
+        for vi, (i, j) in enumerate(pairs):
+            cij = dW[i, j].T @ h / volume / GPa
+            for vj, (k, l) in enumerate(pairs):
+                C[vi, vj] = cij[k, l]
+        return C
 
     def set_prerequisite_properties(self, properties: List[str]):
         for prop in properties:
@@ -181,9 +258,14 @@ class TensorAlloyCalculator(BaseCalculator):
         want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC
         if properties & {"forces", "stress", "virial", "total_pressure"}:
             want |= _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
-        res = self._engine.evaluate([atoms], want=want, descriptors=debug_mode)[0]
         vap = self.transformer.get_vap_transformer(atoms)
-        results = {}
+        second = {}
+        if "hessian" in properties:
+            second["hessian"] = self._hessian(atoms, vap)
+        if "elastic" in properties:
+            second["elastic"] = self._elastic(atoms)
+        res = self._engine.evaluate([atoms], want=want, descriptors=debug_mode)[0]
+        results = dict(second)
         for target in properties:
             if target == "energy":
                 results[target] = res["energy"]

@@ -266,9 +266,11 @@ class AtomicNN:
             props["stress"] = "Output/Stress/Voigt/stress:0"
             props["virial"] = "Output/Stress/Full/virial:0"
             props["total_pressure"] = "Output/Stress/pressure/GPa:0"
-        for unsupported in ("hessian", "elastic"):
-            if unsupported in want:
-                raise ValueError(f"'{unsupported}' is not implemented by tensoralloy_amd")
+        # second derivatives: central differences of the analytic forces / virial (calculator.py)
+        if "hessian" in want:
+            props["hessian"] = "Output/Hessian/hessian:0"
+        if "elastic" in want:
+            props["elastic"] = "Output/Elastic/Cijkl/elastic:0"
         meta = {
             "format": "tensoralloy_amd/1",
             "Transformer/params": self._transformer.as_dict(),

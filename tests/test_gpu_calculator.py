@@ -97,3 +97,51 @@ def test_calculator_medium_precision_model(lib, tmp_path):
     o = oracle_eval(nn, atoms)
     assert abs(float(calc.results["energy"]) - o["energy"]) < 1e-5 * max(1.0, abs(o["energy"]))
     assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < 1e-5
+
+
+def test_elastic_constants_of_zjw04_ni_match_the_reference_values(lib, tmp_path):
+    """Known answers from the reference's own tests: EamAlloyNN(['Ni'], 'zjw04'), rc = 6.0,
+    `bulk('Ni', cubic=True)` (a = 3.52): C11 = 246.61, C12 = 147.15, C44 = 124.72 GPa +- 0.01
+    (tests/test_calculator.py:94-111), 247 / 147 / 125 +- 1 (nn/constraint/tests/test_elastic.py:23-57).
+    Second derivatives of the GPU path's energy: pins its virial."""
+    from tensoralloy_amd import Atoms, TensorAlloyCalculator, UniversalTransformer
+    from tensoralloy_amd.eam import EamAlloyNN
+    nn = EamAlloyNN(["Ni"], "zjw04", export_properties=["energy", "forces", "stress", "elastic"])
+    nn.attach_transformer(UniversalTransformer(["Ni"], rcut=6.0))
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "Ni.zhou04.elastic.pb")))
+    assert "elastic" in calc.implemented_properties
+    a = 3.52
+    frac = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]])
+    cubic = Atoms(symbols=["Ni"] * 4, positions=frac * a, cell=np.eye(3) * a, pbc=True)
+    C = calc.get_elastic_constant_tensor(cubic)
+    assert C.shape == (6, 6) and np.abs(C - C.T).max() < 1e-12
+    for k in range(3):
+        assert abs(C[k, k] - 246.61) < 0.01
+        assert abs(C[3 + k, 3 + k] - 124.72) < 0.01
+    assert abs(C[0, 1] - 147.15) < 0.01 and abs(C[0, 2] - 147.15) < 0.01 and abs(C[1, 2] - 147.15) < 0.01
+    assert np.abs(C[:3, 3:]).max() < 1e-3 and abs(C[3, 4]) < 1e-3
+    # bulk modulus of a cubic crystal, K = (C11 + 2 C12) / 3 = K_VRH = 180.31 (test_calculator.py:108)
+    assert abs((C[0, 0] + 2 * C[0, 1]) / 3 - 180.31) < 0.01
+
+
+def test_hessian_matches_the_reference_fixture(lib, tmp_path):
+    """test_files/crystals/Ni_fc2.npy: Hessian of EamAlloyNN(['Ni'], 'zjw04') at rc = 6.5 written by
+    the reference in 'medium' precision (nn/constraint/tests/test_fc2.py:29-54). Here: central
+    differences of the GPU forces, through `get_hessian` (calculator.py:228-241)."""
+    import os
+    from tensoralloy_amd import Atoms, TensorAlloyCalculator, UniversalTransformer
+    from tensoralloy_amd.eam import EamAlloyNN
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "Ni_fc2.npz"))
+    fc2 = z["fc2"].astype(np.float64)  # [32, 32, 3, 3]
+    cell = z["cell"]
+    atoms = Atoms(symbols=["Ni"] * 32, positions=z["frac"] @ cell, cell=cell, pbc=True)
+    nn = EamAlloyNN(["Ni"], "zjw04", export_properties=["energy", "forces", "hessian"])
+    nn.attach_transformer(UniversalTransformer(["Ni"], rcut=6.5))
+    nn.precision = "medium"
+    calc = TensorAlloyCalculator(nn.export(str(tmp_path / "Ni_fc2")))
+    H = calc.get_hessian(atoms)                      # [96, 96]
+    assert H.shape == (96, 96)
+    H4 = H.reshape(32, 3, 32, 3).transpose(0, 2, 1, 3)
+    assert np.abs(H4 - fc2).max() < 5e-5            # fp32 noise of the fixture
+    assert np.abs(H - H.T).max() < 1e-9
+    assert abs(calc.get_potential_energy(atoms) / 32 + 4.44999667) < 1e-6
