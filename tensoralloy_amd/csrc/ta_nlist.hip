@@ -8,10 +8,11 @@
 // the positions as given, per-axis periodicity; output sorted by centre and
 // neighbour species with the reverse-pair index.
 //
-// Linked cells in fractional coordinates (bin width >= rc along every axis).
-// This path needs at least 3 bins along every periodic axis, so that the 27
-// neighbouring bins are distinct and each carries one image shift; frames
-// that do not qualify (cells thinner than 3 rc) are built on the host.
+// Linked cells in fractional coordinates (bin width >= rc along every axis). The 27 neighbouring
+// (bin, image shift) combinations of a centre are distinct even when an axis has only one or
+// two bins (the same bin then appears with different shifts, which is how self-images and
+// multiple images of one neighbour arise), so the only requirement is a cell at least rc
+// thick along every periodic axis; thinner cells are built on the host.
 //
 // Kernels: bin_atoms (wrap, bin id, histogram) -> scan -> fill_bins -> gather_bins (records
 // in bin order, atoms of a bin by index: deterministic) -> count_pairs (one wavefront per
@@ -290,7 +291,7 @@ inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per
 }  // namespace
 
 // Host: grid parameters of one frame. Returns false when the frame cannot use the device
-// builder (a periodic axis with fewer than 3 bins) or the cell is singular.
+// builder (a periodic axis thinner than rmax) or the cell is singular.
 bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g) {
   for (int k = 0; k < 9; ++k) g.h[k] = fr.cell[k];
   auto norm = [](const double *a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
@@ -320,7 +321,7 @@ bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g) {
     const double wfrac = rmax / height;  // bin width in fractional units (perpendicular width = rmax)
     if (g.pbc[a]) {
       const int nb = (int)std::floor(1.0 / wfrac);
-      if (nb < 3) return false;
+      if (nb < 1) return false;  // cell thinner than rc: several images per bin, host builder
       g.nb[a] = std::min(nb, 64);
       g.lo[a] = 0.0;
       g.inv_w[a] = (double)g.nb[a];

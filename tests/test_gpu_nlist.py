@@ -91,11 +91,22 @@ def test_slab_and_cluster_and_alloy_batch(lib):
     assert np.array_equal(dev, _oracle_pairs(frames, 6.0))
 
 
-def test_thin_cells_fall_back_to_host(lib):
+def test_small_cells_self_images_and_fallback(lib):
     nn = make_nn(["Ni"], 6.5, True, [16])
+    # 7.05 A cell, rc 6.5: one bin per axis, every neighbour appears in several images
     atoms = [fcc(rep=(2, 2, 2))]
-    info, dev = _device_pairs(nn, atoms, expect_device=False)
+    info, dev = _device_pairs(nn, atoms, expect_device=True)
     assert np.array_equal(dev, _oracle_pairs(atoms, 6.5))
+    # two bins along x, one along y and z, sheared
+    cell = np.array([[14.5, 0.0, 0.0], [2.0, 7.2, 0.0], [0.5, -1.0, 6.9]])
+    rng = np.random.RandomState(3)
+    tri = [Atoms(symbols=["Ni"] * 40, positions=rng.rand(40, 3) @ cell * 1.7 - 3.0, cell=cell, pbc=True)]
+    info, dev = _device_pairs(nn, tri, expect_device=True)
+    assert np.array_equal(dev, _oracle_pairs(tri, 6.5))
+    # a cell thinner than rc goes to the host builder
+    thin = [fcc(rep=(1, 2, 2))]
+    info, dev = _device_pairs(nn, thin, expect_device=False)
+    assert np.array_equal(dev, _oracle_pairs(thin, 6.5))
 
 
 def test_results_do_not_depend_on_the_builder(lib, monkeypatch):
@@ -129,3 +140,30 @@ def test_eam_on_device_list(lib):
     o = oracle_eam_eval(nn, atoms)
     assert abs(r["energy"] - o["energy"]) < 1e-6
     assert np.abs(r["forces"] - o["forces"]).max() < 1e-5
+
+
+def test_reference_statistics_through_set_frames(lib):
+    """nij / nnl / nijk maxima the reference cached in snap-Ni.db (io/sqlite.py:234-298), for the
+    structures that attain them: what `ta_set_frames` reports (device or host builder, whichever
+    the cell allows) must be exactly those numbers."""
+    import json
+    import os
+    from tensoralloy_amd import Engine
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    with open(os.path.join(golden, "snap_Ni_neighbors.json")) as fp:
+        meta = json.load(fp)
+    z = np.load(os.path.join(golden, "snap_Ni_neighbors.npz"))
+    on_device = 0
+    for key, rc in (("450", 4.5), ("460", 4.6), ("600", 6.0), ("650", 6.5)):
+        nn = make_nn(["Ni"], rc, True, [8])
+        with Engine(nn) as eng:
+            for stat, d in meta["stats"][key].items():
+                rid = d["structure_id"]
+                atoms = Atoms(symbols=["Ni"] * len(z[f"pos_{rid}"]), positions=z[f"pos_{rid}"],
+                              cell=z[f"cell_{rid}"], pbc=z[f"pbc_{rid}"])
+                info = eng.set_frames([atoms])
+                on_device += int(info.nl_on_device)
+                got = dict(nij=int(info.n_pairs), nnl=int(info.nnl_max), nijk=int(info.n_triples),
+                           ij2k=int(info.nnl_max) - 1)[stat]
+                assert got == d["value"], (key, stat, got, d)
+    assert on_device > 0  # at least the large cells went through the GPU builder
