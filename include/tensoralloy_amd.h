@@ -222,6 +222,16 @@ int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64
                      int32_t **i, int32_t **j, int32_t **shift /*[n][3]*/, int32_t **rev);
 void ta_free(void *p);
 
+/* Tables of an EAM / ADP model's analytic functions on caller-supplied abscissae: what
+ * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it
+ * writes a LAMMPS setfl file. Rows: elements (sorted) for rho(r) [n_elements][n_r] and F(rho)
+ * [n_elements][n_rho]; element pairs a <= b (upper triangle, row-major) for phi(r), and for an
+ * ADP model u(r), w(r) (may be NULL), each [n_pairs][n_r]. Evaluated by the same device functions
+ * the energy kernels use. */
+int ta_eam_tabulate(ta_handle h, int32_t n_r, const double *r, int32_t n_rho, const double *rho,
+                    double *rho_of_r, double *phi_of_r, double *embed_of_rho, double *u_of_r,
+                    double *w_of_r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "ta_device_count", "ta_create", "ta_destroy", "ta_last_error", "ta_set_frames",
     "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
+    "ta_eam_tabulate",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -130,6 +131,7 @@ def load():
                                      C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),
                                      C.POINTER(_ip), C.POINTER(_ip)]
     lib.ta_free.argtypes = [C.c_void_p]
+    lib.ta_eam_tabulate.argtypes = [H, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.ta_free.restype = None
     _lib = lib
     return lib

@@ -35,6 +35,9 @@ struct EamModel;
 EamModel *eam_create(const ta_model_desc *m, std::string &err);
 void eam_destroy(EamModel *);
 void eam_ensure(EamModel *, const DeviceBatch &b);
+void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double *rho, double *rho_of_r,
+                  double *phi_of_r, double *embed_of_rho, double *u_of_r, double *w_of_r,
+                  hipStream_t s);
 void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
                  hipEvent_t *ev /* 2 events or null */);
 }  // namespace ta
@@ -1062,6 +1065,45 @@ int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64
 }
 
 void ta_free(void *p) { std::free(p); }
+
+int ta_eam_tabulate(ta_handle h, int32_t n_r, const double *r, int32_t n_rho, const double *rho,
+                    double *rho_of_r, double *phi_of_r, double *embed_of_rho, double *u_of_r,
+                    double *w_of_r) {
+  if (!h) return TA_ERR_INVALID;
+  if (h->kind != TA_MODEL_EAM_ALLOY && h->kind != TA_MODEL_EAM_ADP)
+    return fail(h, TA_ERR_INVALID, "ta_eam_tabulate needs an EAM / ADP model");
+  if (n_r < 0 || n_rho < 0 || (n_r > 0 && (!r || !rho_of_r || !phi_of_r)) ||
+      (n_rho > 0 && (!rho || !embed_of_rho)))
+    return fail(h, TA_ERR_INVALID, "bad table arguments");
+  return guarded(h, [&]() {
+    const size_t nel = (size_t)h->n_elements, npair = nel * (nel + 1) / 2;
+    const bool adp = h->kind == TA_MODEL_EAM_ADP && u_of_r && w_of_r;
+    DevBuf<double> buf;
+    const size_t n_in = (size_t)n_r + (size_t)n_rho;
+    const size_t n_out = (nel + npair * (adp ? 3 : 1)) * (size_t)n_r + nel * (size_t)n_rho;
+    buf.ensure(n_in + n_out + 8);
+    double *d_r = buf.ptr, *d_rho = d_r + n_r;
+    double *d_rho_r = d_rho + n_rho, *d_phi = d_rho_r + nel * n_r, *d_embed = d_phi + npair * n_r;
+    double *d_u = adp ? d_embed + nel * n_rho : nullptr, *d_w = adp ? d_u + npair * n_r : nullptr;
+    hipStream_t s = h->stream;
+    if (n_r) HIP_CHECK(hipMemcpyAsync(d_r, r, (size_t)n_r * sizeof(double), hipMemcpyHostToDevice, s));
+    if (n_rho) HIP_CHECK(hipMemcpyAsync(d_rho, rho, (size_t)n_rho * sizeof(double), hipMemcpyHostToDevice, s));
+    ta::eam_tabulate(h->eam, n_r, d_r, n_rho, d_rho, d_rho_r, d_phi, d_embed, d_u, d_w, s);
+    HIP_CHECK(hipGetLastError());
+    auto back = [&](double *dst, const double *src, size_t n) {
+      if (dst && n) HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    };
+    back(rho_of_r, d_rho_r, nel * n_r);
+    back(phi_of_r, d_phi, npair * n_r);
+    back(embed_of_rho, d_embed, nel * n_rho);
+    if (adp) {
+      back(u_of_r, d_u, npair * n_r);
+      back(w_of_r, d_w, npair * n_r);
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    buf.release();
+  });
+}
 
 int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift) {
   if (!h) return TA_ERR_INVALID;

@@ -273,6 +273,55 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   b.g[4 * (size_t)p + 2] = gz;
 }
 
+// Tables of the analytic functions on caller-supplied abscissae (setfl / ADP export,
+// reference nn/eam/alloy.py:198-381): rows = elements (rho(r), F(rho)) or element pairs a <= b
+// (phi, u, w), evaluated by the same device functions the energy kernels use.
+__global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n_r, const double *r,
+                                                              int n_rho, const double *rho,
+                                                              double *rho_of_r, double *phi_of_r,
+                                                              double *embed_of_rho, double *u_of_r,
+                                                              double *w_of_r) {
+  const int nel = P.nel, npair = nel * (nel + 1) / 2;
+  const int64_t n_rows_r = nel + npair;  // rho rows, then pair rows
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total_r = n_rows_r * n_r;
+  if (idx < total_r) {
+    const int row = (int)(idx / n_r), k = (int)(idx % n_r);
+    const double x = r[k];
+    double f, df;
+    if (row < nel) {
+      zjw_rho(P.el[row], x, f, df);
+      rho_of_r[(size_t)row * n_r + k] = f;
+    } else {
+      const int pt = row - nel;
+      int a = 0, rem = pt;
+      while (rem >= nel - a) {
+        rem -= nel - a;
+        ++a;
+      }
+      const int b2 = a + rem;
+      zjw_phi(P, a, b2, x, f, df);
+      phi_of_r[(size_t)pt * n_r + k] = f;
+      if (P.adp && u_of_r && w_of_r) {
+        const double *pp = P.pair[pt];
+        double u, du, w, dw;
+        mishin_polar(x, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        mishin_polar(x, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        u_of_r[(size_t)pt * n_r + k] = u;
+        w_of_r[(size_t)pt * n_r + k] = w;
+      }
+    }
+    return;
+  }
+  const int64_t j = idx - total_r;
+  if (j < (int64_t)nel * n_rho) {
+    const int row = (int)(j / n_rho), k = (int)(j % n_rho);
+    double F, dF;
+    zjw_embed(P.el[row], P.embed_kind[row], rho[k], F, dF);
+    embed_of_rho[(size_t)row * n_rho + k] = F;
+  }
+}
+
 }  // namespace
 
 struct EamModel {
@@ -352,6 +401,16 @@ void eam_ensure(EamModel *m, const DeviceBatch &b) {
       hipMalloc((void **)&m->mom, cap * (size_t)m->p.nel * 9 * sizeof(double)) != hipSuccess)
     throw std::bad_alloc();
   m->cap_atoms = cap;
+}
+
+void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double *rho, double *rho_of_r,
+                  double *phi_of_r, double *embed_of_rho, double *u_of_r, double *w_of_r,
+                  hipStream_t s) {
+  const int nel = m->p.nel, npair = nel * (nel + 1) / 2;
+  const int64_t total = (int64_t)(nel + npair) * n_r + (int64_t)nel * n_rho;
+  if (total == 0) return;
+  hipLaunchKernelGGL(eam_tabulate_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, s, m->p, n_r, r, n_rho, rho, rho_of_r, phi_of_r, embed_of_rho, u_of_r, w_of_r);
 }
 
 void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {

@@ -301,6 +301,56 @@ class EamAlloyNN:
         return stem + ".json"
 
 
+    # -- LAMMPS tables ------------------------------------------------------------------
+    def export_to_setfl(self, setfl: str, nr: int, dr: float, nrho: int, drho: float,
+                        lattice_constants=None, lattice_types=None, device: int = 0, **_ignored):
+        """
+        Write a LAMMPS `eam/alloy` (setfl) -- or, for `AdpNN`, `adp` -- potential file, as the
+        reference's `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) / `AdpNN.export_to_setfl`
+        do: rho(r) and r*phi(r) on r = k dr (k < nr), F(rho) on rho = k drho (k < nrho), then
+        u(r) and w(r) for ADP. The tables are evaluated on the GPU by the functions the energy
+        kernels use (`ta_eam_tabulate`); plotting arguments of the reference are ignored.
+        """
+        from .atoms import atomic_masses, atomic_numbers
+        from .engine import Engine
+        if self._transformer is None:
+            raise ValueError("A transformer must be attached before exporting")
+        r = np.arange(nr, dtype=np.float64) * float(dr)
+        rho = np.arange(nrho, dtype=np.float64) * float(drho)
+        with Engine(self, device=device) as eng:
+            t = eng.eam_tabulate(r, rho)
+        lattice_constants = lattice_constants or {}
+        lattice_types = lattice_types or {}
+        els = self._elements
+        n = len(els)
+
+        def block(values):
+            vals = ["%24.16e" % v for v in values]
+            return "\n".join(" ".join(vals[k:k + 5]) for k in range(0, len(vals), 5)) + "\n"
+
+        with open(setfl, "w") as fp:
+            fp.write(f"Date: {datetime.today()} tensoralloy_amd\n")
+            fp.write("LAMMPS setfl format\n")
+            fp.write(f"Conversion by tensoralloy_amd {self.__class__.__name__} ({self._family})\n")
+            fp.write(f"{n} " + " ".join(els) + "\n")
+            fp.write(f"{nrho} {float(drho)!r} {nr} {float(dr)!r} {float(self._transformer.rcut)!r}\n")
+            for k, el in enumerate(els):
+                z = atomic_numbers[el]
+                fp.write(f"{z} {atomic_masses[z]!r} {float(lattice_constants.get(el, 0.0))!r} "
+                         f"{lattice_types.get(el, 'fcc')}\n")
+                fp.write(block(t["embed"][k]))
+                fp.write(block(t["rho"][k]))
+            index = {name: k for k, name in enumerate(t["pairs"])}
+            order = [(i, j) for i in range(n) for j in range(i + 1)]  # setfl: (1,1) (2,1) (2,2) ...
+            for i, j in order:
+                fp.write(block(t["phi"][index[els[j] + els[i]]] * r))
+            if "u" in t:
+                for key in ("u", "w"):
+                    for i, j in order:
+                        fp.write(block(t[key][index[els[j] + els[i]]]))
+        return setfl
+
+
 class AdpNN(EamAlloyNN):
     """`eam/adp`: EAM plus Mishin's dipole and quadrupole terms (nn/eam/adp.py)."""
 

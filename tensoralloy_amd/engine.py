@@ -158,6 +158,28 @@ class Engine:
         """Enqueue a D2D copy of the batch energy (one double) on the engine's stream."""
         self._check(self._lib.ta_copy_batch_energy(self._handle, C.c_void_p(int(dst_device_ptr))))
 
+    def eam_tabulate(self, r, rho) -> dict:
+        """rho(r), phi(r), F(rho) (and u, w for ADP) of an EAM model on the given abscissae,
+        evaluated by the device functions of the energy kernels. Rows: sorted elements; pairs
+        a <= b in upper-triangle order."""
+        r = np.ascontiguousarray(r, dtype=np.float64).ravel()
+        rho = np.ascontiguousarray(rho, dtype=np.float64).ravel()
+        nel = len(self._nn.elements)
+        npair = nel * (nel + 1) // 2
+        adp = getattr(self._nn, "tag", "") == "adp"
+        out = {"rho": np.zeros((nel, len(r))), "phi": np.zeros((npair, len(r))),
+               "embed": np.zeros((nel, len(rho)))}
+        null = C.POINTER(C.c_double)()
+        if adp:
+            out["u"], out["w"] = np.zeros((npair, len(r))), np.zeros((npair, len(r)))
+        self._check(self._lib.ta_eam_tabulate(
+            self._handle, len(r), _lib.as_dp(r), len(rho), _lib.as_dp(rho), _lib.as_dp(out["rho"]),
+            _lib.as_dp(out["phi"]), _lib.as_dp(out["embed"]),
+            _lib.as_dp(out["u"]) if adp else null, _lib.as_dp(out["w"]) if adp else null))
+        out["pairs"] = [self._nn.elements[a] + self._nn.elements[b]
+                        for a in range(nel) for b in range(a, nel)]
+        return out
+
     def pairs(self):
         P = int(self.info.n_pairs)
         i = np.zeros(max(P, 1), dtype=np.int32)

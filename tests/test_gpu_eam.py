@@ -56,3 +56,52 @@ def test_zjw04xcp_cross_term(lib):
     _compare(make_eam(["Mo", "Ni"], 6.5, potential="zjw04xcp"), [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 3))])
     with pytest.raises(ValueError, match="no phi constants"):
         make_eam(["Cu", "Ni"], 6.5, potential="zjw04xcp").to_desc()
+
+
+def test_device_functions_reproduce_the_reference_setfl_tables(lib, tmp_path):
+    """`Zhou_AlCu.alloy.eam` / `zjw04_Ni.alloy.eam`: the tables the reference asserts its Zjw04 graph
+    against to 1e-12 (nn/eam/tests/test_eam_alloy_nn.py:139-164), plus the literals of
+    io/tests/test_lammps.py:25-71. Here the DEVICE functions of the energy kernels are tabulated
+    (`ta_eam_tabulate`, what `export_to_setfl` writes) and held to the same tolerance."""
+    import json
+    import os
+    from tensoralloy_amd import Engine
+    with open(os.path.join(os.path.dirname(__file__), "golden", "eam_tables.json")) as fp:
+        t = json.load(fp)
+    for tag in ("AlCu", "Ni"):
+        d = t[tag]
+        nn = make_eam(d["elements"], d["rcut"])
+        r = np.array(d["r_index"]) * d["dr"]
+        rho = np.array(d["rho_index"]) * d["drho"]
+        with Engine(nn) as eng:
+            tab = eng.eam_tabulate(r, rho)
+        for k, el in enumerate(nn.elements):
+            ref = np.array(d["rho"][el])
+            assert np.abs(tab["rho"][k] - ref).max() < 1e-12 * max(1, np.abs(ref).max())
+            assert np.abs(tab["embed"][k] - np.array(d["embed"][el])).max() < 1e-12
+        for key, ref in d["rphi"].items():
+            a, b = sorted([key[:2], key[2:]])
+            row = tab["pairs"].index(a + b)
+            got = tab["phi"][row][1:] * r[1:]
+            ref = np.array(ref)[1:]
+            assert np.abs(got - ref).max() < 1e-12 * max(1, np.abs(ref).max())
+    lit = t["literal"]
+    nn = make_eam(["Al", "Cu"], t["AlCu"]["rcut"])
+    with Engine(nn) as eng:
+        tab = eng.eam_tabulate([t["AlCu"]["dr"]], [10 * t["AlCu"]["drho"]])
+    assert abs(tab["embed"][0][0] - lit["F_Al_10"]) < 1e-14
+    assert abs(tab["phi"][tab["pairs"].index("CuCu")][0] * t["AlCu"]["dr"] - lit["rphi_CuCu_1"]) < 1e-12
+    # the file writer: same grids as the reference's fixture, read back with the oracle's reader
+    from oracle.eam import read_setfl
+    path = nn.export_to_setfl(str(tmp_path / "AlCu.alloy.eam"), nr=2000, dr=0.003, nrho=2000, drho=0.05,
+                              lattice_constants={"Al": 4.05, "Cu": 3.61})
+    back = read_setfl(path)
+    assert back["elements"] == ["Al", "Cu"] and back["nr"] == 2000 and back["nrho"] == 2000
+    assert abs(back["dr"] - 0.003) < 1e-15 and abs(back["rcut"] - t["AlCu"]["rcut"]) < 1e-12
+    d = t["AlCu"]
+    for el in ("Al", "Cu"):
+        assert np.abs(back["rho"][el][d["r_index"]] - np.array(d["rho"][el])).max() < 1e-12 * 30
+        assert np.abs(back["embed"][el][d["rho_index"]] - np.array(d["embed"][el])).max() < 1e-12
+    for key, ref in d["rphi"].items():
+        got = back["rphi"][key][d["r_index"]][1:]
+        assert np.abs(got - np.array(ref)[1:]).max() < 1e-12 * max(1, np.abs(ref).max())

@@ -192,3 +192,32 @@ def test_non_symmetric_single_element(lib, minmax):
     from tests.helpers import AtomicNN  # noqa: F401
     with pytest.raises(ValueError, match="only for one element"):
         make_nn(["Mo", "Ni"], 6.0, True, [8], symmetric=False).to_desc()
+
+
+def test_gpu_descriptors_against_the_reference_fixtures(lib):
+    """The two descriptor fixtures the reference's own tests hold, applied to the GPU path directly:
+    `amp_Pd3O2.npz` (AMP-generated G2+G4 of the periodic Pd3O2 slab, test_sf.py:666-691) and the
+    vectors of the reference's NumPy helpers on B28.xyz (test_sf.py:159-311)."""
+    import os
+    from tensoralloy_amd import Atoms, Engine
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(golden, "amp_Pd3O2.npz"))["g"]
+    nn = make_nn(["Pd", "O"], 6.5, True, [8])
+    with Engine(nn) as eng:
+        G = eng.evaluate([pd3o2()], descriptors=True)[0]["descriptors"]
+    assert np.abs(G[3:5] - g[3:5, 0:20]).max() < 1e-12   # O rows
+    assert np.abs(G[0:3] - g[0:3, 20:40]).max() < 1e-12  # Pd rows
+    z = np.load(os.path.join(golden, "B28_sf.npz"))
+    coords, rc = z["coords"], float(z["rc"])
+    b28 = Atoms(symbols=["B"] * len(coords), positions=coords, cell=np.eye(3) * 60.0, pbc=False)
+    kw = dict(eta=z["etas"].tolist(), omega=[0.0], beta=z["betas"].tolist(), gamma=z["gammas"].tolist(),
+              zeta=z["zetas"].tolist())
+    nn = make_nn(["B"], rc, True, [8], sf_kwargs=kw)
+    with Engine(nn) as eng:
+        G = eng.evaluate([b28], descriptors=True)[0]["descriptors"]
+    assert np.abs(G[:, :4] - z["g2_v1"]).max() < 1e-11
+    assert np.abs(G[:, 4:] - z["g4"]).max() < 1e-11
+    nn = make_nn(["B"], rc, False, [8], sf_kwargs=dict(eta=z["etas"].tolist(), omega=z["omegas"].tolist()))
+    with Engine(nn) as eng:
+        G2 = eng.evaluate([b28], descriptors=True)[0]["descriptors"]
+    assert np.abs(G2 - z["g2_v2"]).max() < 1e-11
