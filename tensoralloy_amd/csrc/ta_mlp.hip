@@ -30,7 +30,7 @@ __global__ __launch_bounds__(THREADS) void mlp_kernel(MlpDev mlp, int act, int n
     buf0[row * stride + k] = row < nrows ? G[(size_t)atoms[a0 + row] * ndim + k] : 0.0;
   }
   __syncthreads();
-  mlp_tile(
+  mlp_tile<16>(
       mlp, act, ndim, nrows, buf0, buf1, stride, da,
       [&](int row, double y) { eatom[atoms[a0 + row]] = y; },
       [&](int row, int k, double d) { dEdG[(size_t)atoms[a0 + row] * ndim + k] = d; });
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(THREADS) void mlp_all_kernel(const MlpDev *__restri
     buf0[row * stride + k] = row < nrows ? G[(size_t)el_atoms[a0 + row] * ndim + k] : 0.0;
   }
   __syncthreads();
-  mlp_tile(
+  mlp_tile<16>(
       mlp, act, ndim, nrows, buf0, buf1, stride, da,
       [&](int row, double y) { eatom[el_atoms[a0 + row]] = y; },
       [&](int row, int k, double d) { dEdG[(size_t)el_atoms[a0 + row] * ndim + k] = d; });

@@ -25,7 +25,9 @@ typedef double mlp_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMlpRows = 16;
 
 // Z[16][np] = X[16][kp] . W[kp][np] (+ bias), result handed to `emit(row, col, z)`.
-template <typename Emit>
+// PF = k-steps whose B operands are fetched from L2 before the first of them is used (4 or 16:
+// one dependent load round per PF k-steps).
+template <int PF, typename Emit>
 __device__ __forceinline__ void mlp_tile_gemm(const double *X, int xstride, const double *W,
                                               int wstride, int kp, int np, const double *bias,
                                               int lane, int wave, int nwaves, Emit emit) {
@@ -35,7 +37,18 @@ __device__ __forceinline__ void mlp_tile_gemm(const double *X, int xstride, cons
     const double b0 = bias ? bias[col] : 0.0;
     mlp_f64x4 acc = {b0, b0, b0, b0};
     const int nk = kp / 4;  // kp is a multiple of 16 -> nk is a multiple of 4
-    for (int kk0 = 0; kk0 < nk; kk0 += 4) {
+    int kk0 = 0;
+    if constexpr (PF > 4) {
+      for (; kk0 + PF <= nk; kk0 += PF) {
+        double w[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) w[j] = W[(size_t)(4 * (kk0 + j) + kq) * wstride + col];
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[m * xstride + 4 * (kk0 + j) + kq], w[j], acc, 0, 0, 0);
+      }
+    }
+    for (; kk0 < nk; kk0 += 4) {
       double a[4], w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -54,7 +67,7 @@ __device__ __forceinline__ void mlp_tile_gemm(const double *X, int xstride, cons
 // descriptors of the rows (k < ndim); rows >= nrows are ignored. All threads of
 // the workgroup must call it. `emit_energy(row, y)` and `emit_grad(row, k, dE/dG)`
 // are called for row < nrows.
-template <typename EmitE, typename EmitG>
+template <int PF = 4, typename EmitE, typename EmitG>
 __device__ __forceinline__ void mlp_tile(const MlpDev &mlp, int act, int ndim, int nrows,
                                          double *buf0, double *buf1, int stride, double *da,
                                          EmitE emit_energy, EmitG emit_grad) {
@@ -82,7 +95,7 @@ __device__ __forceinline__ void mlp_tile(const MlpDev &mlp, int act, int ndim, i
   for (int l = 0; l < L; ++l) {
     const MlpLayerDev ly = mlp.layer[l];
     double *dal = da + (size_t)l * kMlpRows * stride;
-    mlp_tile_gemm(cur, stride, ly.w, ly.np, ly.kp, ly.np, ly.b, lane, wave, nwaves,
+    mlp_tile_gemm<PF>(cur, stride, ly.w, ly.np, ly.kp, ly.np, ly.b, lane, wave, nwaves,
                   [&](int row, int col, double z) {
                     // rows beyond nrows are padding: no transcendental work for them
                     double h = 0.0, dh = 0.0;
@@ -129,7 +142,7 @@ __device__ __forceinline__ void mlp_tile(const MlpDev &mlp, int act, int ndim, i
     // delta_prev[16][kp] = dz[16][np] . W^T[np][kp]  (+ delta when skip)
     const bool res = ly.res != 0;
     double *dst = nxt;
-    mlp_tile_gemm(cur, stride, ly.wt, ly.kp, ly.np, ly.kp, nullptr, lane, wave, nwaves,
+    mlp_tile_gemm<PF>(cur, stride, ly.wt, ly.kp, ly.np, ly.kp, nullptr, lane, wave, nwaves,
                   [&](int row, int col, double z) {
                     const double skip = res ? dst[row * stride + col] : 0.0;
                     dst[row * stride + col] = z + skip;
