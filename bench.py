@@ -134,17 +134,21 @@ def main():
         # kernels go onto torch's current stream so the collective is ordered
         # behind them by stream semantics: no host synchronisation per step
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        slots_ = [ebuf[0:1], ebuf[1:2]]
+        slot_ptrs = [s_.data_ptr() for s_ in slots_]
 
     def step(k):
         if use_dist and inflight[k % 2] is not None:
             inflight[k % 2].wait()  # stream-level wait before the slot is overwritten
-        eng.compute(want)
         if use_dist:
-            # batch energy -> torch buffer, then ONE RCCL all-reduce of 8 bytes
-            slot = ebuf[k % 2:k % 2 + 1]
-            eng.copy_batch_energy(slot.data_ptr())
+            # the frame-reduce kernel writes the batch energy straight into this step's slot of
+            # the torch buffer, then ONE RCCL all-reduce of 8 bytes reduces it in place
+            slot = slots_[k % 2]
+            eng.set_batch_energy_target(slot_ptrs[k % 2])
+            eng.compute(want)
             inflight[k % 2] = dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
             return inflight[k % 2]
+        eng.compute(want)
         return None
 
     def sync_all():

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "ta_device_count", "ta_create", "ta_destroy", "ta_last_error", "ta_set_frames",
     "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
-    "ta_eam_tabulate",
+    "ta_eam_tabulate", "ta_set_batch_energy_target",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -126,6 +126,7 @@ def load():
     lib.ta_time_compute.argtypes = [H, C.c_uint32, C.c_int32, C.c_int32, _dp, _dp]
     lib.ta_batch_energy_device_ptr.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.ta_copy_batch_energy.argtypes = [H, C.c_void_p]
+    lib.ta_set_batch_energy_target.argtypes = [H, C.c_void_p]
     lib.ta_get_pairs.argtypes = [H, _ip, _ip, _ip]
     lib.ta_neighbor_list.argtypes = [C.POINTER(Frame), C.c_int32, C.c_double,
                                      C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),

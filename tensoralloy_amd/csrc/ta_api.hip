@@ -1036,6 +1036,14 @@ int ta_copy_batch_energy(ta_handle h, void *dst_device) {
   });
 }
 
+int ta_set_batch_energy_target(ta_handle h, void *dst_device) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  // no synchronisation: only launches made after this call see the new target
+  h->db.batch_energy = dst_device ? static_cast<double *>(dst_device) : h->benergy.ptr;
+  return TA_OK;
+}
+
 int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64_t *n_pairs,
                      int32_t **i, int32_t **j, int32_t **shift, int32_t **rev) {
   if (!frame || !n_pairs || n_elements < 1 || !(rc > 0.0))

@@ -158,6 +158,11 @@ class Engine:
         """Enqueue a D2D copy of the batch energy (one double) on the engine's stream."""
         self._check(self._lib.ta_copy_batch_energy(self._handle, C.c_void_p(int(dst_device_ptr))))
 
+    def set_batch_energy_target(self, dst_device_ptr):
+        """Later `compute` calls write the batch energy straight to this device address
+        (None = the library's own buffer): no copy before a collective."""
+        self._check(self._lib.ta_set_batch_energy_target(self._handle, C.c_void_p(int(dst_device_ptr or 0))))
+
     def eam_tabulate(self, r, rho) -> dict:
         """rho(r), phi(r), F(rho) (and u, w for ADP) of an EAM model on the given abscissae,
         evaluated by the device functions of the energy kernels. Rows: sorted elements; pairs
