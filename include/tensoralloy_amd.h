@@ -46,7 +46,9 @@ enum {
   TA_WANT_FORCES = 2,      /* Output/Forces/forces     basic.py:277-290         */
   TA_WANT_VIRIAL = 4,      /* Output/Stress (virial)   basic.py:293-331         */
   TA_WANT_ATOMIC = 8,      /* Output/Energy/atomic     atomic.py:289-299        */
-  TA_WANT_DESCRIPTORS = 16 /* Atomic/<El> descriptors  sf.py:184-215 (debug)    */
+  TA_WANT_DESCRIPTORS = 16, /* Atomic/<El> descriptors  sf.py:184-215 (debug)   */
+  TA_WANT_REUSE_DESCRIPTORS = 32 /* energy-only call on the descriptors of the last ta_compute of
+                                    this batch (only the MLP weights changed: training steps) */
 };
 
 enum { TA_MODEL_SF_MLP = 1, TA_MODEL_EAM_ALLOY = 2, TA_MODEL_EAM_ADP = 3, TA_MODEL_GRAP_MLP = 4 };
@@ -225,6 +227,21 @@ int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift /*[n][3]*/)
 int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64_t *n_pairs,
                      int32_t **i, int32_t **j, int32_t **shift /*[n][3]*/, int32_t **rev);
 void ta_free(void *p);
+
+/* --- training support: gradients with respect to the MLP weights ---------------
+ * Parameter vector layout = `ta_model_desc.weights`: per element (sorted), per layer W[in][out]
+ * row-major then b[out]. */
+
+/* length of that vector */
+int ta_param_count(ta_handle h, int64_t *n_params);
+
+/* replace the MLP weights of a live handle (an optimiser step), same layout */
+int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights);
+
+/* grad = sum_f frame_coeff[f] * dE_f/dtheta for the resident batch: with frame_coeff[f] = dL/dE_f
+ * this is the gradient of a loss L(E_1 .. E_F), what `tf.gradients(loss, variables)` gives for the
+ * energy term of nn/losses.py:204-285. The batch's descriptors are computed once and reused. */
+int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int64_t n_grad);
 
 /* Tables of an EAM / ADP model's analytic functions on caller-supplied abscissae: what
  * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it

@@ -19,12 +19,13 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip", "ta_grap.hip",
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip", "ta_grap.hip", "ta_train.hip",
            "ta_neighbor.cpp"]
 
 TA_OK = 0
 TA_ERR_INVALID, TA_ERR_UNSUPPORTED, TA_ERR_HIP, TA_ERR_NOMEM = -1, -2, -3, -4
 TA_WANT_ENERGY, TA_WANT_FORCES, TA_WANT_VIRIAL, TA_WANT_ATOMIC, TA_WANT_DESCRIPTORS = 1, 2, 4, 8, 16
+TA_WANT_REUSE_DESCRIPTORS = 32
 TA_MODEL_SF_MLP, TA_MODEL_EAM_ALLOY, TA_MODEL_EAM_ADP, TA_MODEL_GRAP_MLP = 1, 2, 3, 4
 TA_CUTOFF = {"cosine": 0, "polynomial": 1}
 TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
@@ -38,7 +39,8 @@ EXPORTED_SYMBOLS = [
     "ta_device_count", "ta_create", "ta_destroy", "ta_last_error", "ta_set_frames",
     "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
-    "ta_eam_tabulate", "ta_set_batch_energy_target",
+    "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
+    "ta_energy_gradient",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -127,6 +129,9 @@ def load():
     lib.ta_batch_energy_device_ptr.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.ta_copy_batch_energy.argtypes = [H, C.c_void_p]
     lib.ta_set_batch_energy_target.argtypes = [H, C.c_void_p]
+    lib.ta_param_count.argtypes = [H, C.POINTER(C.c_int64)]
+    lib.ta_update_weights.argtypes = [H, _dp, C.c_int64]
+    lib.ta_energy_gradient.argtypes = [H, _dp, _dp, C.c_int64]
     lib.ta_get_pairs.argtypes = [H, _ip, _ip, _ip]
     lib.ta_neighbor_list.argtypes = [C.POINTER(Frame), C.c_int32, C.c_double,
                                      C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),

@@ -22,6 +22,13 @@ void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t 
 size_t mlp_all_scratch_doubles(const MlpDev *mlps_host, int nel, const int32_t *elem_start);
 void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, int activation, int ndim,
                     const DeviceBatch &b, double *scratch, hipStream_t s);
+// weight gradients (ta_train.hip)
+int mlp_param_count(const MlpDev &mlp);
+size_t mlp_grad_scratch_doubles(const MlpDev &mlp, int n_atoms);
+size_t mlp_grad_partial_doubles(const MlpDev &mlp, int n_atoms);
+void launch_mlp_grad(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
+                     const DeviceBatch &b, const double *frame_coeff, double *scratch, double *partial,
+                     double *grad, hipStream_t s);
 // GRAP (ta_grap.hip)
 struct GrapModel;
 GrapModel *grap_create(const ta_model_desc *m, std::string &err);
@@ -148,6 +155,8 @@ struct ta_context {
   DevBuf<unsigned long long> nl_stats;
   DevBuf<ta::NlRec> nl_recs;
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
+  bool descriptors_valid = false;  // db.G holds the resident batch's descriptors
+  DevBuf<double> train_scratch, train_partial, train_grad, train_coeff;
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
   std::string err;
@@ -498,7 +507,15 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   };
   bool used[TA_N_KERNEL_SLOTS] = {false};
 
-  if (h->kind == TA_MODEL_SF_MLP && h->use_fused) {
+  // energies again on the descriptors already resident (training steps: only the MLP changed)
+  const bool has_mlp = h->kind == TA_MODEL_SF_MLP || h->kind == TA_MODEL_GRAP_MLP;
+  if ((want & TA_WANT_REUSE_DESCRIPTORS) && has_mlp && h->descriptors_valid && !need_forces) {
+    begin(TA_K_MLP);
+    launch_mlp_all(h->mlp_dev, h->mlp, h->n_elements, h->activation, h->sf.ndim, db,
+                   h->mlp_scratch.ptr, s);
+    end(TA_K_MLP);
+    used[TA_K_MLP] = true;
+  } else if (h->kind == TA_MODEL_SF_MLP && h->use_fused) {
     begin(TA_K_FUSED);
     launch_sf_fused(h->sf, h->chunks_v2[0].ch, h->chunks_v2[0].ng, h->chunks_v2[0].nz, db, h->fplan,
                     h->mlp_dev, h->activation, need_forces, h->mlp_scratch.ptr, s);
@@ -615,6 +632,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   used[TA_K_FRAME_REDUCE] = true;
   HIP_CHECK(hipGetLastError());
   h->last_want = want;
+  h->descriptors_valid = true;
 
   if (timed) {
     HIP_CHECK(hipStreamSynchronize(s));
@@ -726,6 +744,7 @@ int ta_destroy(ta_handle h) {
   h->rec.release(); h->part4.release(); h->G.release();
   h->dEdG.release(); h->g.release(); h->wat.release();
   h->benergy.release(); h->mlp_scratch.release();
+  h->train_scratch.release(); h->train_partial.release(); h->train_grad.release(); h->train_coeff.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release();
   h->masks.release();
@@ -751,6 +770,7 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
         throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
     }
     const auto t_begin = std::chrono::steady_clock::now();
+    h->descriptors_valid = false;
     size_t N = 0;
     for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
     if (N >= (1u << 30)) throw std::runtime_error("batch too large for 32-bit atom indices");
@@ -1033,6 +1053,88 @@ int ta_copy_batch_energy(ta_handle h, void *dst_device) {
   return guarded(h, [&]() {
     HIP_CHECK(hipMemcpyAsync(dst_device, h->db.batch_energy, sizeof(double),
                              hipMemcpyDeviceToDevice, h->stream));
+  });
+}
+
+int ta_param_count(ta_handle h, int64_t *n_params) {
+  if (!h || !n_params) return TA_ERR_INVALID;
+  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    return fail(h, TA_ERR_INVALID, "the model has no MLP");
+  int64_t n = 0;
+  for (int e = 0; e < h->n_elements; ++e) n += ta::mlp_param_count(h->mlp[e]);
+  *n_params = n;
+  return TA_OK;
+}
+
+int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights) {
+  if (!h || !weights) return TA_ERR_INVALID;
+  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    return fail(h, TA_ERR_INVALID, "the model has no MLP");
+  return guarded(h, [&]() {
+    int64_t want = 0;
+    for (int e = 0; e < h->n_elements; ++e) want += ta::mlp_param_count(h->mlp[e]);
+    if (n_weights != want)
+      throw std::invalid_argument("ta_update_weights: expected " + std::to_string(want) + " values");
+    HIP_CHECK(hipStreamSynchronize(h->stream));  // nothing may still read the old weights
+    const double *src = weights;
+    for (int e = 0; e < h->n_elements; ++e) {
+      ta::MlpDev &md = h->mlp[e];
+      for (int l = 0; l < md.n_layers; ++l) {
+        ta::MlpLayerDev &ly = md.layer[l];
+        std::vector<double> w((size_t)ly.kp * ly.np, 0.0), wt((size_t)ly.np * ly.kp, 0.0), bb(ly.np, 0.0);
+        for (int k = 0; k < ly.k; ++k)
+          for (int n = 0; n < ly.n; ++n) {
+            const double v = src[(size_t)k * ly.n + n];
+            w[(size_t)k * ly.np + n] = v;
+            wt[(size_t)n * ly.kp + k] = v;
+          }
+        src += (size_t)ly.k * ly.n;
+        for (int n = 0; n < ly.n; ++n) bb[n] = src[n];
+        src += ly.n;
+        HIP_CHECK(hipMemcpy(ly.w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(ly.wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(ly.b, bb.data(), bb.size() * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
+  });
+}
+
+int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int64_t n_grad) {
+  if (!h || !frame_coeff || !grad) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    return fail(h, TA_ERR_INVALID, "the model has no MLP");
+  return guarded(h, [&]() {
+    int64_t total = 0;
+    for (int e = 0; e < h->n_elements; ++e) total += ta::mlp_param_count(h->mlp[e]);
+    if (n_grad != total)
+      throw std::invalid_argument("ta_energy_gradient: expected room for " + std::to_string(total) + " values");
+    // descriptors do not depend on the weights: computed once per resident batch
+    if (!h->descriptors_valid) compute_impl(h, TA_WANT_ENERGY, false, nullptr);
+    hipStream_t s = h->stream;
+    const size_t F = (size_t)h->db.n_frames;
+    size_t scratch = 0, partial = 0;
+    for (int e = 0; e < h->n_elements; ++e) {
+      const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+      scratch = std::max(scratch, ta::mlp_grad_scratch_doubles(h->mlp[e], n_el));
+      partial = std::max(partial, ta::mlp_grad_partial_doubles(h->mlp[e], n_el));
+    }
+    h->train_scratch.ensure(scratch + 8);
+    h->train_partial.ensure(partial + 8);
+    h->train_grad.ensure((size_t)total + 8);
+    h->train_coeff.ensure(F + 8);
+    if (F) HIP_CHECK(hipMemcpyAsync(h->train_coeff.ptr, frame_coeff, F * sizeof(double), hipMemcpyHostToDevice, s));
+    size_t off = 0;
+    for (int e = 0; e < h->n_elements; ++e) {
+      const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+      ta::launch_mlp_grad(h->mlp[e], h->activation, h->sf.ndim, h->db.elem_atoms + h->db.elem_start[e], n_el,
+                          h->db, h->train_coeff.ptr, h->train_scratch.ptr, h->train_partial.ptr,
+                          h->train_grad.ptr + off, s);
+      off += (size_t)ta::mlp_param_count(h->mlp[e]);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
   });
 }
 

@@ -158,6 +158,32 @@ class Engine:
         """Enqueue a D2D copy of the batch energy (one double) on the engine's stream."""
         self._check(self._lib.ta_copy_batch_energy(self._handle, C.c_void_p(int(dst_device_ptr))))
 
+    # -- training support (SURVEY 8(f) N3) ---------------------------------------------------
+    def param_count(self) -> int:
+        n = C.c_int64(0)
+        self._check(self._lib.ta_param_count(self._handle, C.byref(n)))
+        return int(n.value)
+
+    def update_weights(self, flat):
+        """Replace the MLP weights of the live handle (layout of `train.flatten_weights`)."""
+        flat = np.ascontiguousarray(flat, dtype=np.float64).ravel()
+        self._check(self._lib.ta_update_weights(self._handle, _lib.as_dp(flat), len(flat)))
+
+    def energy_gradient(self, frame_coeff) -> np.ndarray:
+        """sum_f frame_coeff[f] dE_f/dtheta for the resident batch, flat parameter layout."""
+        coeff = np.ascontiguousarray(frame_coeff, dtype=np.float64).ravel()
+        if len(coeff) != int(self.info.n_frames):
+            raise ValueError("one coefficient per resident frame")
+        grad = np.zeros(self.param_count())
+        self._check(self._lib.ta_energy_gradient(self._handle, _lib.as_dp(coeff), _lib.as_dp(grad), len(grad)))
+        return grad
+
+    def energies(self, reuse_descriptors=True) -> np.ndarray:
+        """Frame energies of the resident batch; with `reuse_descriptors` only the MLP is re-run."""
+        want = _lib.TA_WANT_ENERGY | (_lib.TA_WANT_REUSE_DESCRIPTORS if reuse_descriptors else 0)
+        self.compute(want)
+        return self.fetch(_lib.TA_WANT_ENERGY)["energy"]
+
     def set_batch_energy_target(self, dst_device_ptr):
         """Later `compute` calls write the batch energy straight to this device address
         (None = the library's own buffer): no copy before a collective."""

@@ -7,7 +7,7 @@ each owning a contiguous block of frames and its own model copy; the only
 exchange is ONE all-reduce of the 8-byte batch energy (RCCL over xGMI when the
 backend is "nccl"; gloo on CPU for tests). The reference has no inference-side
 collective; its only collective is the training gradient all-reduce
-(train/distribute_utils.py:56-81), which is out of scope.
+(train/distribute_utils.py:56-81): see `tensoralloy_amd/train.py::allreduce_mean`.
 """
 from __future__ import annotations
 

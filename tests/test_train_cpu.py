@@ -1,0 +1,119 @@
+"""Host logic of the training support (no GPU): loss derivative, Adam, weight layout, the oracle's
+weight gradient against finite differences, and the gradient all-reduce on two gloo ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from tests.helpers import fcc, make_nn, oracle_model
+from tests.test_gpu_sf import _alloy
+
+
+def test_energy_loss_matches_its_derivative():
+    from tensoralloy_amd.train import energy_loss
+    rng = np.random.RandomState(0)
+    pred, lab, n = rng.randn(7) * 3, rng.randn(7) * 3, rng.randint(2, 40, 7)
+    for method in ("rmse", "logcosh"):
+        for per_atom in (True, False):
+            loss, mae, dl = energy_loss(pred, lab, n, method, per_atom, weight=0.7)
+            for k in (0, 3, 6):
+                d = 1e-6
+                p = pred.copy(); p[k] += d
+                lp = energy_loss(p, lab, n, method, per_atom, weight=0.7)[0]
+                p = pred.copy(); p[k] -= d
+                lm = energy_loss(p, lab, n, method, per_atom, weight=0.7)[0]
+                assert abs((lp - lm) / (2 * d) - dl[k]) < 1e-8
+    # losses.py:88-90: sqrt(mean(diff^2) + eps)
+    x, y, nn_ = np.array([1.0, 2.0]), np.array([1.5, 1.0]), np.array([2, 4])
+    loss, mae, _ = energy_loss(y, x, nn_)
+    diff = y / nn_ - x / nn_
+    assert abs(loss - np.sqrt(np.mean(diff ** 2) + np.finfo(float).eps)) < 1e-15
+    assert abs(mae - np.mean(np.abs(diff))) < 1e-15
+
+
+def test_adam_first_steps():
+    from tensoralloy_amd.train import Adam
+    opt = Adam(2, learning_rate=0.1)
+    th = opt.step(np.array([1.0, -1.0]), np.array([0.5, -2.0]))
+    assert np.allclose(th, [0.9, -0.9], atol=1e-6)   # first Adam step = lr * sign(g)
+    opt = Adam(1, learning_rate=0.1, decay_rate=0.5, decay_steps=10)
+    opt.t = 10
+    assert abs(opt.learning_rate() - 0.05) < 1e-15
+
+
+def test_weight_layout_roundtrip():
+    from tensoralloy_amd.train import flatten_weights, unflatten_weights, trainable_mask
+    nn = make_nn(["Mo", "Ni"], 6.0, True, [8, 8])
+    nn.weights["Mo"][0] = (nn.weights["Mo"][0][0], None)           # a layer without bias
+    flat = flatten_weights(nn)
+    back = unflatten_weights(nn, flat)
+    for el in nn.elements:
+        for (w, b), (w2, b2) in zip(nn.weights[el], back[el]):
+            assert np.array_equal(np.asarray(w), w2)
+            assert (b is None and b2 is None) or np.array_equal(np.ravel(b), b2)
+    D = nn.ndim()
+    assert len(flat) == 2 * (D * 8 + 8 + 64 + 8 + 8 + 1)
+    assert trainable_mask(nn)[D * 8:D * 8 + 8].sum() == 0 and trainable_mask(nn).sum() == len(flat) - 8
+
+
+def test_oracle_weight_gradient_finite_differences():
+    from oracle.sf import evaluate
+    from oracle.train import weight_gradients
+    nn = make_nn(["Mo", "Ni"], 6.0, True, [6, 6], minmax=True, resnet=True)
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    m = oracle_model(nn)
+    sym, cell = atoms.get_chemical_symbols(), np.asarray(atoms.get_cell())
+    out = evaluate(m, sym, atoms.positions, cell, atoms.pbc, want_forces=False)
+    c = np.random.RandomState(1).randn(len(atoms))
+    g = weight_gradients(m, sym, out["descriptors"], c)
+    d = 1e-6
+    for el, l, idx in (("Ni", 0, (2, 3)), ("Mo", 1, (0, 5)), ("Ni", 2, (4, 0))):
+        W = m.weights[el][l][0]
+        keep = W[idx]
+        W[idx] = keep + d
+        ep = float(c @ evaluate(m, sym, atoms.positions, cell, atoms.pbc, want_forces=False)["atomic"])
+        W[idx] = keep - d
+        em = float(c @ evaluate(m, sym, atoms.positions, cell, atoms.pbc, want_forces=False)["atomic"])
+        W[idx] = keep
+        assert abs((ep - em) / (2 * d) - g[el][l][0][idx]) < 1e-7
+    b = m.weights["Ni"][1][1]
+    keep = b[2]
+    b[2] = keep + d
+    ep = float(c @ evaluate(m, sym, atoms.positions, cell, atoms.pbc, want_forces=False)["atomic"])
+    b[2] = keep - d
+    em = float(c @ evaluate(m, sym, atoms.positions, cell, atoms.pbc, want_forces=False)["atomic"])
+    b[2] = keep
+    assert abs((ep - em) / (2 * d) - g["Ni"][1][1][2]) < 1e-7
+
+
+def test_gradient_allreduce_two_gloo_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from tensoralloy_amd.train import Adam, allreduce_mean
+        dist.init_process_group("gloo")
+        rank = dist.get_rank()
+        g = np.arange(5, dtype=float) * (rank + 1)          # rank 0: k, rank 1: 2k -> mean 1.5 k
+        m = allreduce_mean(g)
+        assert np.allclose(m, 1.5 * np.arange(5)), m
+        opt = Adam(5, learning_rate=0.1)
+        th = opt.step(np.ones(5), m)
+        out = np.zeros(5) if rank else th
+        import torch
+        t = torch.from_numpy(th.copy()); dist.broadcast(t, 0)
+        assert np.allclose(t.numpy(), th)                   # identical weights on both ranks
+        dist.destroy_process_group()
+        print("ok", rank)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
