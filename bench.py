@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=1)
     ap.add_argument("--rep", type=int, default=10, help="fcc cells per edge (10 -> 4000 atoms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-evals", type=int, default=6)
+    ap.add_argument("--cpu-evals", type=int, default=40)  # ~10 s of 16-thread CPU work
     args = ap.parse_args()
 
     from tensoralloy_amd.parallel import world_from_env
@@ -200,7 +200,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this
         # same command (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950)
-        traffic = None
+        traffic = valu = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and fpg == 1 and args.rep == 10:
             try:
@@ -208,8 +208,18 @@ def main():
                     for name, rec in json.load(fp).items():
                         if name.startswith(dom_key):
                             traffic = rec["hbm_bytes_per_launch"]
+                            valu = rec.get("valu_wave_insts_per_launch")
             except Exception:
-                traffic = None
+                traffic = valu = None
+        # what actually bounds this kernel: FP64 VALU issue. One wavefront instruction occupies a
+        # SIMD for 4 cycles (16 lanes/cycle); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
+        valu_obj = None
+        if valu and bwd_ms > 0:
+            peak_issue = 256 * 4 * 2.4e9 / 4.0            # wavefront instructions per second
+            valu_obj = {"wave_insts_per_launch": valu, "achieved_Ginst_per_s": valu / (bwd_ms * 1e-3) / 1e9,
+                        "peak_Ginst_per_s": peak_issue / 1e9,
+                        "frac": valu / (bwd_ms * 1e-3) / peak_issue,
+                        "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
@@ -217,8 +227,10 @@ def main():
                     "kernel_ms": bwd_ms,
                     "whole_eval_bytes": eval_bytes,
                     "whole_eval_frac": eval_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    "valu_issue": valu_obj,
                     "note": "triples are generated on the fly from LDS-staged pair records, so "
-                            "HBM traffic is far below the packed-record bytes the formula prices"}
+                            "HBM traffic is far below the packed-record bytes the formula prices "
+                            "(frac > 1); the kernel is bounded by FP64 VALU issue, see valu_issue"}
 
         # ---- parity gate + CPU baseline (oracle = checker, timed on host cores) ----
         res = eng.fetch(want)

@@ -52,6 +52,9 @@ def main(out):
         if f and w:
             traffic[k] = {"fetch_KiB_raw": sum(f) / len(f), "write_KiB": sum(w) / len(w),
                           "hbm_bytes_per_launch": (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0}
+            v = counters[k].get("SQ_INSTS_VALU")
+            if v:  # wavefront-level VALU instructions per launch (issue-bound kernels)
+                traffic[k]["valu_wave_insts_per_launch"] = sum(v) / len(v)
     with open(os.path.join(out, "pmc_traffic.json"), "w") as fp:
         json.dump(traffic, fp, indent=1)
 
