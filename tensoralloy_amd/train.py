@@ -186,3 +186,147 @@ class EnergyTrainer:
 
     def close(self):
         self.engine.close()
+
+
+# ---- forces and stress terms -----------------------------------------------------------------------
+
+def forces_loss(predictions, labels, method="rmse", weight=1.0):
+    """(loss, mae, [dloss/dF per frame]) of nn/losses.py:285-332 over all real atoms' components:
+    sqrt(mean(dF^2) + eps) or mean log-cosh. `predictions` / `labels`: lists of [N_f, 3] arrays."""
+    diff = np.concatenate([np.asarray(l, dtype=np.float64) - np.asarray(p, dtype=np.float64)
+                           for p, l in zip(predictions, labels)])          # labels - predictions
+    n = diff.size
+    mae = float(np.mean(np.abs(diff)))
+    if method == "rmse":
+        loss = np.sqrt(float(np.mean(diff * diff)) + np.finfo(np.float64).eps)
+        d_all = -diff / (n * loss)
+    elif method == "logcosh":
+        loss = float(np.mean(diff + np.logaddexp(0.0, -2.0 * diff) - np.log(2.0)))
+        d_all = -np.tanh(diff) / n
+    else:
+        raise ValueError(f"loss method '{method}' is not implemented for training")
+    out, k = [], 0
+    for p in predictions:
+        m = len(p)
+        out.append(weight * d_all[k:k + m])
+        k += m
+    return float(weight * loss), mae, out
+
+
+def stress_loss(predictions, labels, method="rmse", weight=1.0):
+    """(loss, mae, dloss/dstress [B, 6]) of nn/losses.py:384-437 on Voigt stresses in eV/A^3."""
+    y = np.asarray(predictions, dtype=np.float64).reshape(-1, 6)
+    x = np.asarray(labels, dtype=np.float64).reshape(-1, 6)
+    diff = y - x
+    mae = float(np.mean(np.abs(diff)))
+    if method == "rmse":
+        loss = np.sqrt(float(np.mean(diff * diff)) + np.finfo(np.float64).eps)
+        d = diff / (diff.size * loss)
+    elif method == "logcosh":
+        e = x - y
+        loss = float(np.mean(e + np.logaddexp(0.0, -2.0 * e) - np.log(2.0)))
+        d = -np.tanh(e) / diff.size
+    else:
+        raise ValueError(f"loss method '{method}' is not implemented for training")
+    return float(weight * loss), mae, weight * d
+
+
+class Trainer:
+    """Energy + forces + stress loss (nn/basic.py `get_total_loss`: the sum of the weighted terms).
+
+    The weight gradient of the force and stress terms needs second derivatives of the energy. They
+    are taken as a DIRECTIONAL derivative instead of a new backward pass: with u = dL/dF per atom and
+    the symmetric Y built from dL/dstress,
+        sum u.F + sum Y.W = D_delta E,   delta R = R.Y - u,  delta h = h.Y,
+    so   d/dtheta (that sum) = [g(R + e dR, h + e dh) - g(R - e dR, h - e dh)] / (2 e)
+    with g = dE/dtheta from `ta_energy_gradient` on two displaced copies of every frame (central
+    difference, step `fd_step` Angstrom on the largest displacement; error O(step^2)).
+    """
+
+    def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
+                 energy_weight=1.0, forces_weight=1.0, stress_weight=1.0, method="rmse",
+                 per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, **adam_kwargs):
+        from .engine import Engine
+        rank, local_rank, world = world_from_env()
+        lo, hi = shard_range(len(frames), rank, world)
+        self.nn = nn
+        self.rank, self.world = rank, world
+        self.device = local_rank if device is None else device
+        self.engine = Engine(nn, device=self.device)
+        self.frames = list(frames[lo:hi])
+        self.e_ref = np.asarray(energies, dtype=np.float64)[lo:hi]
+        self.f_ref = None if forces is None else [np.asarray(f, dtype=np.float64) for f in forces[lo:hi]]
+        self.s_ref = None if stresses is None else np.asarray(stresses, dtype=np.float64).reshape(-1, 6)[lo:hi]
+        self.n_atoms = np.array([len(a) for a in self.frames], dtype=np.float64)
+        self.weights = (energy_weight, forces_weight, stress_weight)
+        self.method, self.per_atom_loss, self.fd_step = method, per_atom_loss, fd_step
+        self.theta = flatten_weights(nn)
+        self.mask = trainable_mask(nn)
+        self.opt = Adam(len(self.theta), learning_rate=learning_rate, **adam_kwargs)
+        self.history: List[dict] = []
+
+    def loss_and_gradient(self):
+        from .atoms import Atoms
+        eng = self.engine
+        res = eng.evaluate(self.frames)
+        pred_e = np.array([r["energy"] for r in res])
+        we, wf, ws = self.weights
+        terms = {}
+        loss_e, mae_e, c = energy_loss(pred_e, self.e_ref, self.n_atoms, self.method, self.per_atom_loss, we)
+        terms["energy"] = loss_e
+        grad = eng.energy_gradient(c)          # the resident batch is the undisplaced one
+        u = [np.zeros((len(a), 3)) for a in self.frames]
+        Y = [np.zeros((3, 3)) for _ in self.frames]
+        second = False
+        if self.f_ref is not None and wf != 0.0:
+            lf, _, du = forces_loss([r["forces"] for r in res], self.f_ref, self.method, wf)
+            terms["forces"] = lf
+            u = du
+            second = True
+        if self.s_ref is not None and ws != 0.0:
+            ls, _, ds = stress_loss(np.array([r["stress"] for r in res]), self.s_ref, self.method, ws)
+            terms["stress"] = ls
+            for k, a in enumerate(self.frames):
+                V = abs(np.linalg.det(np.asarray(a.get_cell(complete=True))))
+                xx, yy, zz, yz, xz, xy = ds[k] / V
+                Y[k] = np.array([[xx, xy / 2, xz / 2], [xy / 2, yy, yz / 2], [xz / 2, yz / 2, zz]])
+            second = True
+        if second:
+            disp, coeff = [], []
+            for k, a in enumerate(self.frames):
+                h = np.asarray(a.get_cell(complete=True), dtype=np.float64)
+                dR = a.positions @ Y[k] - u[k]
+                dh = h @ Y[k]
+                scale = max(np.abs(dR).max(initial=0.0), np.abs(dh).max(), 1e-300)
+                e = self.fd_step / scale
+                for sgn in (1.0, -1.0):
+                    disp.append(Atoms(numbers=np.asarray(a.numbers).copy(), positions=a.positions + sgn * e * dR,
+                                      cell=h + sgn * e * dh, pbc=np.asarray(a.pbc).copy()))
+                    coeff.append(sgn / (2.0 * e))
+            eng.set_frames(disp)
+            grad = grad + eng.energy_gradient(np.array(coeff))
+        total = float(sum(terms.values()))
+        return total, terms, grad * self.mask
+
+    def step(self):
+        total, terms, grad = self.loss_and_gradient()
+        torch_dev = None
+        try:
+            import torch
+            torch_dev = torch.device("cuda", self.device) if torch.cuda.is_available() else None
+        except Exception:
+            pass
+        grad = allreduce_mean(grad, torch_dev)
+        self.theta = self.opt.step(self.theta, grad)
+        self.engine.update_weights(self.theta)
+        self.history.append(dict(terms, total=total))
+        return total, terms
+
+    def fit(self, steps: int):
+        for _ in range(steps):
+            self.step()
+        self.nn.weights = unflatten_weights(self.nn, self.theta)
+        return self.history
+
+    def close(self):
+        self.engine.close()

@@ -79,3 +79,63 @@ def test_short_fit_recovers_a_teacher(lib):
         pred = np.array([r["energy"] for r in eng.evaluate(frames)])
     per_atom = np.abs(pred - np.array(labels)) / 32
     assert per_atom.max() < 5 * hist[-1] + 1e-6
+
+
+def _oracle_total_loss(nn, frames, e_ref, f_ref, s_ref):
+    from tensoralloy_amd.train import energy_loss, forces_loss, stress_loss
+    outs = [oracle_eval(nn, a) for a in frames]
+    n = np.array([len(a) for a in frames], dtype=float)
+    le = energy_loss(np.array([o["energy"] for o in outs]), e_ref, n)[0]
+    lf = forces_loss([o["forces"] for o in outs], f_ref)[0]
+    ls = stress_loss(np.array([o["stress_voigt"] for o in outs]), s_ref)[0]
+    return le + lf + ls
+
+
+def test_force_and_stress_loss_gradient(lib):
+    """Gradient of the full loss (energy + forces + stress RMSE) with respect to the weights: the
+    GPU path (analytic energy gradient + directional central difference for the second-derivative
+    terms) against central differences of the ORACLE's loss in single weights."""
+    from tensoralloy_amd.train import Trainer, flatten_weights, unflatten_weights
+    nn = make_nn(["Mo", "Ni"], 5.0, True, [8, 8], seed=3)
+    teacher = make_nn(["Mo", "Ni"], 5.0, True, [8, 8], seed=11)
+    frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2), seed=1), _alloy(["Ni", "Mo"], rep=(2, 2, 2), seed=2)]
+    refs = [oracle_eval(teacher, a) for a in frames]
+    e_ref = np.array([o["energy"] for o in refs])
+    f_ref = [o["forces"] for o in refs]
+    s_ref = np.array([o["stress_voigt"] for o in refs])
+    tr = Trainer(nn, frames, e_ref, f_ref, s_ref, device=0)
+    total, terms, grad = tr.loss_and_gradient()
+    tr.close()
+    assert set(terms) == {"energy", "forces", "stress"}
+    assert abs(total - _oracle_total_loss(nn, frames, e_ref, f_ref, s_ref)) < 1e-9
+    theta = flatten_weights(nn)
+    rng = np.random.RandomState(0)
+    d = 1e-5
+    for k in rng.choice(len(theta), 6, replace=False):
+        if grad[k] == 0.0 and tr.mask[k] == 0.0:
+            continue
+        th = theta.copy(); th[k] += d
+        nn.weights = unflatten_weights(nn, th)
+        lp = _oracle_total_loss(nn, frames, e_ref, f_ref, s_ref)
+        th[k] -= 2 * d
+        nn.weights = unflatten_weights(nn, th)
+        lm = _oracle_total_loss(nn, frames, e_ref, f_ref, s_ref)
+        nn.weights = unflatten_weights(nn, theta)
+        fd = (lp - lm) / (2 * d)
+        assert abs(fd - grad[k]) < 2e-6 * max(1.0, abs(fd)), (k, fd, grad[k])
+
+
+def test_fit_with_forces_lowers_force_error(lib):
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import Trainer
+    teacher = make_nn(["Ni"], 5.0, True, [12, 12], seed=5)
+    student = make_nn(["Ni"], 5.0, True, [12, 12], seed=77)
+    frames = [fcc(rep=(2, 2, 2), a=3.4 + 0.05 * k, seed=k, jitter=0.1) for k in range(6)]
+    with Engine(teacher) as eng:
+        ref = eng.evaluate(frames)
+    tr = Trainer(student, frames, [r["energy"] for r in ref], [r["forces"] for r in ref],
+                 [r["stress"] for r in ref], device=0, learning_rate=0.01)
+    hist = tr.fit(150)
+    tr.close()
+    assert hist[-1]["forces"] < 0.5 * hist[0]["forces"]
+    assert hist[-1]["total"] < 0.5 * hist[0]["total"]

@@ -117,3 +117,28 @@ def test_gradient_allreduce_two_gloo_ranks(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_forces_and_stress_loss_derivatives():
+    from tensoralloy_amd.train import forces_loss, stress_loss
+    rng = np.random.RandomState(5)
+    pred = [rng.randn(4, 3), rng.randn(7, 3)]
+    lab = [rng.randn(4, 3), rng.randn(7, 3)]
+    for method in ("rmse", "logcosh"):
+        loss, mae, d = forces_loss(pred, lab, method, weight=2.0)
+        h = 1e-6
+        p = [x.copy() for x in pred]; p[1][3, 2] += h
+        lp = forces_loss(p, lab, method, weight=2.0)[0]
+        p[1][3, 2] -= 2 * h
+        lm = forces_loss(p, lab, method, weight=2.0)[0]
+        assert abs((lp - lm) / (2 * h) - d[1][3, 2]) < 1e-8
+        s_pred, s_lab = rng.randn(3, 6) * 0.01, rng.randn(3, 6) * 0.01
+        loss, mae, ds = stress_loss(s_pred, s_lab, method, weight=0.5)
+        q = s_pred.copy(); q[2, 4] += h
+        lp = stress_loss(q, s_lab, method, weight=0.5)[0]
+        q[2, 4] -= 2 * h
+        lm = stress_loss(q, s_lab, method, weight=0.5)[0]
+        assert abs((lp - lm) / (2 * h) - ds[2, 4]) < 1e-8
+    # nn/losses.py:285-332: one RMSE over every component of every real atom
+    allc = np.concatenate([l - p for p, l in zip(pred, lab)])
+    assert abs(forces_loss(pred, lab)[0] - np.sqrt(np.mean(allc ** 2) + np.finfo(float).eps)) < 1e-15
