@@ -91,12 +91,24 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:
             return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + [str(s) for s in srcs] + \
-          ["-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    # several ranks may get here at once (torchrun): one builds, the others wait for the lock and
+    # then find the library up to date; the output appears atomically
+    import fcntl
+    lock_path = str(LIB_PATH) + ".lock"
+    with open(lock_path, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in deps):
+                return LIB_PATH
+            tmp = str(LIB_PATH) + f".tmp{os.getpid()}"
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + [str(s) for s in srcs] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
