@@ -13,7 +13,8 @@
 // and the tf.gradients that give forces and virial (nn/basic.py:277-331).
 //
 // Two passes over the packed pair list:
-//   eam_atom_kernel  one wavefront per atom: rho_i, sum phi, and (ADP) the
+//   eam_atom_kernel  one wavefront per atom: pair geometry (written to the pair records),
+//                    rho_i, sum phi, and (ADP) the
 //                    dipole / quadrupole moments per neighbour species; lane 0
 //                    applies the embedding function and stores F'(rho_i).
 //   eam_pair_kernel  one lane per directed pair: dE/dD from the centre's F',
@@ -168,7 +169,7 @@ __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, dou
 // moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
 // in the order xx yy zz yz xz xy
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
-                                                          double *mom) {
+                                                          double *mom, double eps) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
@@ -180,7 +181,25 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double *pp = P.pair[pair_type(sA, sb, nel)];
     for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
-      const double *rec = b.rec + kRecDoubles * (size_t)q;
+      // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
+      // left in the pair record for the pair kernel and the force gather
+      double rec[5];
+      {
+        const int j = b.pair_j[q];
+        const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
+        const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
+                     sz = (double)b.pair_shift[3 * (size_t)q + 2];
+        const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+        rec[0] = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+        rec[1] = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+        rec[2] = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+        rec[3] = rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2] + eps;
+        rec[4] = 1.0 / sqrt(rec[3]);
+        double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
+        dst[0] = make_double2(rec[0], rec[1]);
+        dst[1] = make_double2(rec[2], rec[3]);
+        dst[2] = make_double2(rec[4], 0.0);
+      }
       const double r = sqrt(rec[3]);
       double f, df;
       zjw_rho(P.el[sb], r, f, df);  // density function of the NEIGHBOUR's element (alloy.py:176)
@@ -419,9 +438,8 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   std::memset(&sf, 0, sizeof(sf));
   sf.n_elements = m->p.nel;
   sf.eps = m->eps;
-  launch_pair_geometry(sf, b, s);
   hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);
+                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps);
   if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
     hipLaunchKernelGGL(eam_pair_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);

@@ -284,9 +284,11 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   {
     const int c = comp_code(m16);
     const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
-    ix0 = comp_index(ex - 1, ey, ez);
-    iy0 = comp_index(ex, ey - 1, ez);
-    iz0 = comp_index(ex, ey, ez - 1);
+    // lanes beyond the last component must not touch table entries that were never written
+    // (0 * NaN from stale LDS would poison the row sum): they read entry 0
+    ix0 = d0_ok ? comp_index(ex - 1, ey, ez) : 0;
+    iy0 = d0_ok ? comp_index(ex, ey - 1, ez) : 0;
+    iz0 = d0_ok ? comp_index(ex, ey, ez - 1) : 0;
     nx0 = d0_ok ? ex : 0;
     ny0 = d0_ok ? ey : 0;
     nz0 = d0_ok ? ez : 0;
@@ -295,9 +297,9 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   {
     const int c = comp_code(d1);
     const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
-    ix1 = comp_index(ex - 1, ey, ez);
-    iy1 = comp_index(ex, ey - 1, ez);
-    iz1 = comp_index(ex, ey, ez - 1);
+    ix1 = d1_ok ? comp_index(ex - 1, ey, ez) : 0;
+    iy1 = d1_ok ? comp_index(ex, ey - 1, ez) : 0;
+    iz1 = d1_ok ? comp_index(ex, ey, ez - 1) : 0;
     nx1 = d1_ok ? ex : 0;
     ny1 = d1_ok ? ey : 0;
     nz1 = d1_ok ? ez : 0;
