@@ -278,32 +278,28 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
   const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
   const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
-  // per-lane constants of the two components this lane owns in the output tiles
-  int ix0, iy0, iz0, ix1, iy1, iz1;
-  double nx0, ny0, nz0, nx1, ny1, nz1, deg0, deg1;
-  {
-    const int c = comp_code(m16);
+  // The pair tiles are computed transposed (rows = components, columns = pairs): accumulator
+  // register r of this lane then holds component d = q4 + 4 r (tile 0) or 16 + q4 (tile 1, r = 0)
+  // of ITS OWN pair j = m16, so the sum over components is 5 terms in registers plus one
+  // exchange between the four 16-lane rows, and the pair's unit vector is read once.
+  // Per-lane constants of those 5 components: table indices of M_{d - e_c}, exponents, degree.
+  int cix[5], ciy[5], ciz[5], cd[5];
+  double cnx[5], cny[5], cnz[5], cdeg[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int d = r < 4 ? q4 + 4 * r : 16 + q4;
+    const bool ok = d < nd;
+    const int c = comp_code(ok ? d : 0);
     const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
-    // lanes beyond the last component must not touch table entries that were never written
-    // (0 * NaN from stale LDS would poison the row sum): they read entry 0
-    ix0 = d0_ok ? comp_index(ex - 1, ey, ez) : 0;
-    iy0 = d0_ok ? comp_index(ex, ey - 1, ez) : 0;
-    iz0 = d0_ok ? comp_index(ex, ey, ez - 1) : 0;
-    nx0 = d0_ok ? ex : 0;
-    ny0 = d0_ok ? ey : 0;
-    nz0 = d0_ok ? ez : 0;
-    deg0 = ex + ey + ez;
-  }
-  {
-    const int c = comp_code(d1);
-    const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
-    ix1 = d1_ok ? comp_index(ex - 1, ey, ez) : 0;
-    iy1 = d1_ok ? comp_index(ex, ey - 1, ez) : 0;
-    iz1 = d1_ok ? comp_index(ex, ey, ez - 1) : 0;
-    nx1 = d1_ok ? ex : 0;
-    ny1 = d1_ok ? ey : 0;
-    nz1 = d1_ok ? ez : 0;
-    deg1 = ex + ey + ez;
+    // components beyond nd read a written table entry with zero weights (0 * stale LDS = NaN)
+    cd[r] = ok ? d : 0;
+    cix[r] = ok ? comp_index(ex - 1, ey, ez) : 0;
+    ciy[r] = ok ? comp_index(ex, ey - 1, ez) : 0;
+    ciz[r] = ok ? comp_index(ex, ey, ez - 1) : 0;
+    cnx[r] = ok ? ex : 0;
+    cny[r] = ok ? ey : 0;
+    cnz[r] = ok ? ez : 0;
+    cdeg[r] = ok ? ex + ey + ez : 0;
   }
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
   for (int sb = 0; sb < nel; ++sb) {
@@ -347,59 +343,55 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
       stage_pairs(g, b, first, n, L, lane);
       __syncthreads();
       for (int j0 = 0; j0 < n; j0 += 16) {
-        // A-operand rows: this lane's pair (zero-filled beyond n: f = df = 0)
+        // B-operand columns: this lane's pair (zero-filled beyond n: f = df = 0)
         const int ta = j0 + m16;
-        const double r = L.r[ta], logr = L.logr[ta], inv_ra = L.inv_r[ta], f = L.f[ta], df = L.df[ta];
+        const double r = L.r[ta], logr = L.logr[ta], inv_r = L.inv_r[ta], f = L.f[ta], df = L.df[ta];
         f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
         for (int k0 = 0; k0 < Kp; k0 += 4) {
           const int k = k0 + q4;
           double H = 0.0, dH = 0.0;
           if (k < K) {
             double v, dv;
-            filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_ra, v, dv);
+            filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_r, v, dv);
             H = v * f;
             dH = dv * f + v * df;
           }
-          const double B0 = d0_ok ? A[k * nd + m16] : 0.0;
-          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B0, a0, 0, 0, 0);
-          b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B0, b0, 0, 0, 0);
+          // A operand = A^T[d = m16 (+ 16)][k], B operand = H[k][pair = m16]
+          const double A0 = d0_ok ? A[k * nd + m16] : 0.0;
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, H, a0, 0, 0, 0);
+          b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, dH, b0, 0, 0, 0);
           if (nd > 16) {
-            const double B1 = d1_ok ? A[k * nd + d1] : 0.0;
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(H, B1, a1, 0, 0, 0);
-            b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dH, B1, b1, 0, 0, 0);
+            const double A1 = d1_ok ? A[k * nd + d1] : 0.0;
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, H, a1, 0, 0, 0);
+            b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, dH, b1, 0, 0, 0);
           }
         }
-        // register rr: pair j0 + q4 + 4 rr, component d = m16 (+ 16)
+        // this lane: pair ta, components cd[0..4]
+        const double ux = L.ux[ta], uy = L.uy[ta], uz = L.uz[ta];
+        const double *M = L.M[ta];
+        double gx = 0.0, gy = 0.0, gz = 0.0;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int t = j0 + q4 + 4 * rr;
-          const double inv_r = L.inv_r[t];
-          const double ux = L.ux[t], uy = L.uy[t], uz = L.uz[t];
-          const double *M = L.M[t];
-          double gx, gy, gz;
-          {
-            const double at = a0[rr] * inv_r;
-            const double rad = (b0[rr] - deg0 * at) * (d0_ok ? M[m16] : 0.0);  // multiplies u
-            gx = fma(rad, ux, at * nx0 * M[ix0]);
-            gy = fma(rad, uy, at * ny0 * M[iy0]);
-            gz = fma(rad, uz, at * nz0 * M[iz0]);
-          }
-          if (nd > 16) {
-            const double at = a1[rr] * inv_r;
-            const double rad = (b1[rr] - deg1 * at) * (d1_ok ? M[d1] : 0.0);
-            gx += fma(rad, ux, at * nx1 * M[ix1]);
-            gy += fma(rad, uy, at * ny1 * M[iy1]);
-            gz += fma(rad, uz, at * nz1 * M[iz1]);
-          }
-          gx = row16_sum(gx);
-          gy = row16_sum(gy);
-          gz = row16_sum(gz);
-          if (t < n && m16 == 0) {
-            double *dst = b.g + 4 * (size_t)(first + t);
-            dst[0] = gx;
-            dst[1] = gy;
-            dst[2] = gz;
-          }
+        for (int rr = 0; rr < 5; ++rr) {
+          if (rr == 4 && nd <= 16) break;
+          const double ad = rr < 4 ? a0[rr] : a1[0], bd = rr < 4 ? b0[rr] : b1[0];
+          const double at = ad * inv_r;
+          const double rad = (bd - cdeg[rr] * at) * M[cd[rr]];  // multiplies u (zero for d >= nd: ad = bd = 0)
+          gx = fma(rad, ux, fma(at * cnx[rr], M[cix[rr]], gx));
+          gy = fma(rad, uy, fma(at * cny[rr], M[ciy[rr]], gy));
+          gz = fma(rad, uz, fma(at * cnz[rr], M[ciz[rr]], gz));
+        }
+        // components live in the four 16-lane rows: lanes m16, m16 + 16, + 32, + 48
+        gx += __shfl_xor(gx, 16);
+        gy += __shfl_xor(gy, 16);
+        gz += __shfl_xor(gz, 16);
+        gx += __shfl_xor(gx, 32);
+        gy += __shfl_xor(gy, 32);
+        gz += __shfl_xor(gz, 32);
+        if (ta < n && q4 == 0) {
+          double *dst = b.g + 4 * (size_t)(first + ta);
+          dst[0] = gx;
+          dst[1] = gy;
+          dst[2] = gz;
         }
       }
     }
