@@ -283,8 +283,8 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   // of ITS OWN pair j = m16, so the sum over components is 5 terms in registers plus one
   // exchange between the four 16-lane rows, and the pair's unit vector is read once.
   // Per-lane constants of those 5 components: table indices of M_{d - e_c}, exponents, degree.
-  int cix[5], ciy[5], ciz[5], cd[5];
-  double cnx[5], cny[5], cnz[5], cdeg[5];
+  // packed into one word each to keep the register count (and so the occupancy) down
+  int cw[5];
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int d = r < 4 ? q4 + 4 * r : 16 + q4;
@@ -292,14 +292,12 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
     const int c = comp_code(ok ? d : 0);
     const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
     // components beyond nd read a written table entry with zero weights (0 * stale LDS = NaN)
-    cd[r] = ok ? d : 0;
-    cix[r] = ok ? comp_index(ex - 1, ey, ez) : 0;
-    ciy[r] = ok ? comp_index(ex, ey - 1, ez) : 0;
-    ciz[r] = ok ? comp_index(ex, ey, ez - 1) : 0;
-    cnx[r] = ok ? ex : 0;
-    cny[r] = ok ? ey : 0;
-    cnz[r] = ok ? ez : 0;
-    cdeg[r] = ok ? ex + ey + ez : 0;
+    const int id = ok ? d : 0;
+    const int ix = ok ? comp_index(ex - 1, ey, ez) : 0;
+    const int iy = ok ? comp_index(ex, ey - 1, ez) : 0;
+    const int iz = ok ? comp_index(ex, ey, ez - 1) : 0;
+    cw[r] = id | (ix << 5) | (iy << 10) | (iz << 15) | ((ok ? ex : 0) << 20) | ((ok ? ey : 0) << 22) |
+            ((ok ? ez : 0) << 24);
   }
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
   for (int sb = 0; sb < nel; ++sb) {
@@ -375,10 +373,12 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
           if (rr == 4 && nd <= 16) break;
           const double ad = rr < 4 ? a0[rr] : a1[0], bd = rr < 4 ? b0[rr] : b1[0];
           const double at = ad * inv_r;
-          const double rad = (bd - cdeg[rr] * at) * M[cd[rr]];  // multiplies u (zero for d >= nd: ad = bd = 0)
-          gx = fma(rad, ux, fma(at * cnx[rr], M[cix[rr]], gx));
-          gy = fma(rad, uy, fma(at * cny[rr], M[ciy[rr]], gy));
-          gz = fma(rad, uz, fma(at * cnz[rr], M[ciz[rr]], gz));
+          const int w = cw[rr];
+          const int ex = (w >> 20) & 3, ey = (w >> 22) & 3, ez = (w >> 24) & 3;
+          const double rad = (bd - (double)(ex + ey + ez) * at) * M[w & 31];  // multiplies u
+          gx = fma(rad, ux, fma(at * (double)ex, M[(w >> 5) & 31], gx));
+          gy = fma(rad, uy, fma(at * (double)ey, M[(w >> 10) & 31], gy));
+          gz = fma(rad, uz, fma(at * (double)ez, M[(w >> 15) & 31], gz));
         }
         // components live in the four 16-lane rows: lanes m16, m16 + 16, + 32, + 48
         gx += __shfl_xor(gx, 16);
