@@ -35,7 +35,7 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err);
 int grap_ndim(const GrapModel *g);
 void grap_destroy(GrapModel *);
 void grap_ensure(GrapModel *, const DeviceBatch &b);
-void launch_grap_forward(GrapModel *, const DeviceBatch &b, hipStream_t s);
+void launch_grap_forward(GrapModel *, const DeviceBatch &b, double eps, hipStream_t s);
 void launch_grap_backward(GrapModel *, const DeviceBatch &b, hipStream_t s);
 // EAM / ADP (ta_eam.hip)
 struct EamModel;
@@ -597,12 +597,8 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       used[TA_K_FORCE_GATHER] = true;
     }
   } else if (h->kind == TA_MODEL_GRAP_MLP) {
-    begin(TA_K_PAIR_GEOMETRY);
-    launch_pair_geometry(h->sf, db, s);
-    end(TA_K_PAIR_GEOMETRY);
-    used[TA_K_PAIR_GEOMETRY] = true;
     begin(TA_K_GRAP);
-    launch_grap_forward(h->grap, db, s);
+    launch_grap_forward(h->grap, db, h->sf.eps, s);  // computes the pair geometry while staging
     end(TA_K_GRAP);
     used[TA_K_GRAP] = true;
     begin(TA_K_MLP);

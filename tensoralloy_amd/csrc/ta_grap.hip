@@ -126,20 +126,44 @@ struct PairLds {
   double M[CH][kMaxComp];
 };
 
-template <int CH>
+// GEOM: the pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474) is computed here
+// (forward pass) and left in the pair record for the backward kernel and the force gather.
+template <int CH, bool GEOM>
 __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBatch &b, int first, int n,
-                                            PairLds<CH> &L, int lane) {
+                                            PairLds<CH> &L, int lane, int64_t centre = 0, double eps = 0.0) {
   const int npad = min(CH, (n + 15) & ~15);
   for (int t = lane; t < npad; t += kWave) {
     double ux = 0.0, uy = 0.0, uz = 0.0, r = 1.0, inv_r = 1.0, f = 0.0, df = 0.0, one = 0.0;
     if (t < n) {
-      const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
-      const double r2 = rec[3];
-      inv_r = rec[4];
-      r = r2 * inv_r;  // sqrt(r2): rec[4] = 1 / sqrt(r2)
-      ux = rec[0] * inv_r;
-      uy = rec[1] * inv_r;
-      uz = rec[2] * inv_r;
+      double dx, dy, dz, r2;
+      if constexpr (GEOM) {
+        const size_t q = (size_t)(first + t);
+        const int j = b.pair_j[q];
+        const double *h = b.cells + 9 * (size_t)b.frame_of_atom[centre];
+        const double sx = (double)b.pair_shift[3 * q], sy = (double)b.pair_shift[3 * q + 1],
+                     sz = (double)b.pair_shift[3 * q + 2];
+        const double *ri = b.pos + 3 * (size_t)centre, *rj = b.pos + 3 * (size_t)j;
+        dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+        dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+        dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+        r2 = dx * dx + dy * dy + dz * dz + eps;
+        inv_r = 1.0 / sqrt(r2);
+        double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * q);
+        dst[0] = make_double2(dx, dy);
+        dst[1] = make_double2(dz, r2);
+        dst[2] = make_double2(inv_r, 0.0);
+      } else {
+        const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
+        dx = rec[0];
+        dy = rec[1];
+        dz = rec[2];
+        r2 = rec[3];
+        inv_r = rec[4];
+      }
+      r = r2 * inv_r;  // sqrt(r2)
+      ux = dx * inv_r;
+      uy = dy * inv_r;
+      uz = dz * inv_r;
       const double u = r2 * g.inv_rc2;
       double dfdu = 0.0;
       if (u < 1.0) cutoff_u(g.cutoff, u, f, dfdu);
@@ -187,7 +211,7 @@ __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBat
 
 // One wavefront (= workgroup) per atom: P (kept for the backward pass) and the features.
 __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, DeviceBatch b, double *Pbuf,
-                                                            int ndim) {
+                                                            int ndim, double eps) {
   __shared__ PairLds<kFwdChunk> L;
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
@@ -209,7 +233,10 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
       for (int first = lo; first < hi; first += kFwdChunk) {
         const int n = min(kFwdChunk, hi - first);
         __syncthreads();
-        stage_pairs(g, b, first, n, L, lane);
+        if (kt == 0)
+          stage_pairs<kFwdChunk, true>(g, b, first, n, L, lane, i, eps);
+        else
+          stage_pairs<kFwdChunk, false>(g, b, first, n, L, lane);
         __syncthreads();
         for (int base = 0; base < n; base += 4) {
           const int t = base + q4;  // < round_up(n, 16): staged (zero beyond n)
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
     for (int first = lo; first < hi; first += kBwdChunk) {
       const int n = min(kBwdChunk, hi - first);
       __syncthreads();
-      stage_pairs(g, b, first, n, L, lane);
+      stage_pairs<kBwdChunk, false>(g, b, first, n, L, lane);
       __syncthreads();
       for (int j0 = 0; j0 < n; j0 += 16) {
         // B-operand columns: this lane's pair (zero-filled beyond n: f = df = 0)
@@ -541,10 +568,10 @@ void grap_ensure(GrapModel *g, const DeviceBatch &b) {
   g->cap_atoms = cap;
 }
 
-void launch_grap_forward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
+void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStream_t s) {
   if (b.n_atoms == 0) return;
   hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
-                     g->ndim);
+                     g->ndim, eps);
 }
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
