@@ -102,7 +102,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 return LIB_PATH
             tmp = str(LIB_PATH) + f".tmp{os.getpid()}"
             cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                   "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + [str(s) for s in srcs] + ["-o", tmp]
+                   "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + os.environ.get("TA_EXTRA_HIPCC_FLAGS", "").split() + \
+                  [str(s) for s in srcs] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

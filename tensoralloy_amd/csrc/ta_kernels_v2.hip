@@ -422,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
     // flags & 4: this launch holds every angular channel of the model, and the partial sums fit
     // behind r2 in LDS: the descriptors are assembled without a round trip through part4
     constexpr int kLocal = NSPEC * NG * NZ;
-    if ((flags & 4) && kLocal <= 6) {
+    // room: x .. G (6 cap doubles) and the rings behind them (3 cap doubles), all dead by now
+    if ((flags & 4) && kLocal <= 9) {
       double mine[kLocal];
 #pragma unroll
       for (int k = 0; k < kLocal; ++k) mine[k] = 0.0;
@@ -466,7 +467,12 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
 }
 
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
-__global__ __launch_bounds__(kBlock) void backward_v2_kernel(SFParams sf, AngChunk ch,
+// Occupancy: the backward body is latency-bound at the 3 wavefronts per SIMD the compiler settles for
+// (133 VGPRs); asking for 5 (96 VGPRs, 10 spilled) measured 72 -> 66 us on the benchmark frame and
+// 51 -> 45 us per frame in batches (4: 69 / 47, 6: 68 / 45). Only the default-grid instantiations
+// are constrained; the generic ones keep the compiler's choice.
+__global__ __launch_bounds__(kBlock)
+    __attribute__((amdgpu_waves_per_eu(DEFZ ? (NSPEC == 1 ? 5 : 4) : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
                                                              DeviceBatch b, int first) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   extern __shared__ double lds[];
