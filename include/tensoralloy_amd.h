@@ -212,7 +212,8 @@ int ta_batch_energy_device_ptr(ta_handle h, void **dptr);
 int ta_copy_batch_energy(ta_handle h, void *dst_device);
 /* Alternative without the copy: later ta_compute calls write the batch energy (one double) straight
  * to `dst_device` (caller-owned device memory, e.g. the buffer a collective reduces in place);
- * NULL restores the library's own buffer. Takes effect for launches made after the call. */
+ * NULL restores the library's own buffer. Takes effect for launches made after the call;
+ * ta_set_frames restores the library's own buffer. */
 int ta_set_batch_energy_target(ta_handle h, void *dst_device);
 
 /* debugging / parity: host copy of the pair list of the resident batch
