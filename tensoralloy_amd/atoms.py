@@ -230,9 +230,17 @@ def compare_atoms(a, b, tol=1e-15):
     changes = []
     if len(a) != len(b) or not np.array_equal(np.asarray(a.numbers), np.asarray(b.numbers)):
         return list(all_changes)
-    if not np.allclose(np.asarray(a.positions), np.asarray(b.positions), rtol=0, atol=tol):
+    def differ(x, y):
+        x, y = np.asarray(x), np.asarray(y)
+        if x.shape != y.shape:
+            return True
+        if np.array_equal(x, y):       # the common case on an MD trajectory is decided here, cheaply
+            return False
+        return bool((np.abs(x - y) > tol).any())
+
+    if differ(a.positions, b.positions):
         changes.append("positions")
-    if not np.allclose(np.asarray(a.get_cell()), np.asarray(b.get_cell()), rtol=0, atol=tol):
+    if differ(a.get_cell(), b.get_cell()):
         changes.append("cell")
     if not np.array_equal(np.asarray(a.pbc), np.asarray(b.pbc)):
         changes.append("pbc")

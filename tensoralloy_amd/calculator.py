@@ -144,7 +144,14 @@ class TensorAlloyCalculator(BaseCalculator):
 
     def get_forces(self, atoms=None):
         atoms = atoms if atoms is not None else self.atoms
-        forces = np.insert(self.get_property("forces", atoms), 0, 0, 0)
+        gsl = self.get_property("forces", atoms)
+        # the engine delivers the caller's order; `results` holds the GSL-ordered copy the reference
+        # exposes. When that copy is the one made by the last `calculate`, mapping it back
+        # (calculator.py:247-249) would only undo the permutation.
+        cached = getattr(self, "_forces_local", None)
+        if cached is not None and cached[0] is gsl:
+            return cached[1].copy()
+        forces = np.insert(gsl, 0, 0, 0)
         clf = self.transformer.get_vap_transformer(atoms)
         return clf.map_forces(forces, reverse=True)
 
@@ -266,6 +273,7 @@ class TensorAlloyCalculator(BaseCalculator):
             second["elastic"] = self._elastic(atoms)
         res = self._engine.evaluate([atoms], want=want, descriptors=debug_mode)[0]
         results = dict(second)
+        local_forces = None
         for target in properties:
             if target == "energy":
                 results[target] = res["energy"]
@@ -274,6 +282,7 @@ class TensorAlloyCalculator(BaseCalculator):
                 results[target] = vap.map_array(res["atomic"].reshape(-1, 1))[1:, 0]
             elif target == "forces":
                 results[target] = vap.map_forces(res["forces"])[1:]
+                local_forces = res["forces"]
             elif target in ("stress", "virial", "total_pressure"):
                 results[target] = res[target]
         if debug_mode:
@@ -281,7 +290,10 @@ class TensorAlloyCalculator(BaseCalculator):
         if self._fp_dtype is not np.float64:
             results = {k: (np.asarray(v, dtype=self._fp_dtype) if isinstance(v, np.ndarray)
                            else self._fp_dtype(v)) for k, v in results.items()}
+            if local_forces is not None:
+                local_forces = np.asarray(local_forces, dtype=self._fp_dtype)
         self.results = results
+        self._forces_local = (results["forces"], local_forces) if local_forces is not None else None
         self._ncalls += 1
 
     def reset_call_counter(self):
