@@ -88,8 +88,8 @@ def oracle_sfmodel(nn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames-per-gpu", type=int, default=1)
     ap.add_argument("--rep", type=int, default=10, help="fcc cells per edge (10 -> 4000 atoms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
