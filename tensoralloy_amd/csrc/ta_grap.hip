@@ -114,7 +114,7 @@ __device__ __forceinline__ int term_block(int sA, int sb) { return sb == sA ? 0 
 
 constexpr int kWave = 64;  // one wavefront per workgroup = per centre atom
 constexpr int kFwdChunk = 64;  // pairs of one (centre, species) segment staged in LDS at a time
-constexpr int kBwdChunk = 32;
+constexpr int kBwdChunk = 64;
 
 // Per-pair fields staged in LDS: r, ln r, 1/r, fc(r), dfc/dr, the unit vector and the table of
 // all packed monomials M[t][d] (every lane of a 16-lane row needs a different component of the
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   const int m16 = lane & 15, q4 = lane >> 4;
   const int nel = g.nel, K = g.K, nd = g.nd;
   const int Kp = (K + 3) & ~3;
-  double *A = dyn, *FP = dyn + Kp * nd;
+  double *A = dyn, *FP = dyn + Kp * nd, *wrow = FP + 4 * K;  // wrow: this atom's dE/dG row
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
   const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
             ((ok ? ez : 0) << 24);
   }
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
+  for (int t = lane; t < ndim; t += kWave) wrow[t] = b.dEdG[(size_t)i * ndim + t];
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     if (lo == hi) continue;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
       if (k < K) {
         const size_t row = (((size_t)i * nel + tb) * K + k) * nd;
         const double P = Pbuf[row + d];
-        const double *w = b.dEdG + (size_t)i * ndim + ((size_t)tb * K + k) * g.nf;
+        const double *w = wrow + ((size_t)tb * K + k) * g.nf;
         double s = 0.0, lin = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -577,7 +578,7 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStre
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
   const int Kp = (g->p.K + 3) & ~3;
-  const size_t lds = ((size_t)Kp * g->p.nd + 4 * (size_t)g->p.K) * sizeof(double);
+  const size_t lds = ((size_t)Kp * g->p.nd + 4 * (size_t)g->p.K + (size_t)g->ndim) * sizeof(double);
   hipLaunchKernelGGL(grap_backward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), lds, s, g->p, b,
                      g->Pbuf, g->ndim);
 }
