@@ -863,7 +863,14 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
                                hipMemcpyDeviceToHost, h->stream));
     }
     // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
-    h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && h->n_elements <= 3 &&
+    // second-generation kernels: 1-3 elements for every channel grid; 4 and 5 elements for
+    // launches of 2 gammas x 2 zetas (the default grid) only
+    bool shapes_ok = h->n_elements <= 3;
+    if (h->n_elements == 4 || h->n_elements == 5) {
+      shapes_ok = !h->chunks_v2.empty();
+      for (const ChunkPlan &cp : h->chunks_v2) shapes_ok = shapes_ok && cp.ng == 2 && cp.nz == 2;
+    }
+    h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && shapes_ok &&
                 h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
     const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
     h->db.cap = cap;
@@ -877,12 +884,12 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       }
       // one-launch variant: measured on MI355X at parity for one frame and slower in batches
       // (every workgroup pays a 16-row MFMA tile for its ~2 centres), so it is opt-in
-      h->use_fused = h->use_v2 && h->chunks_v2.size() == 1 && h->hp.nnl_max <= 128 &&
+      h->use_fused = h->use_v2 && h->n_elements <= 3 && h->chunks_v2.size() == 1 && h->hp.nnl_max <= 128 &&
                      std::getenv("TA_USE_FUSED") != nullptr && std::getenv("TA_USE_FUSED")[0] == '1' &&
                      ta::fused_plan(h->sf, h->n_elements, h->chunks_v2[0].ng, h->chunks_v2[0].nz, cap,
                                     stride_max, h->fplan);
     }
-    h->use_v3 = h->use_v2 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
+    h->use_v3 = h->use_v2 && h->n_elements <= 3 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
                 std::getenv("TA_USE_V3")[0] == '1';
     {
       int32_t *blk = reinterpret_cast<int32_t *>(hb + o_blk);

@@ -710,6 +710,8 @@ size_t v2_lds_bytes(bool backward, int cap) {
       case 312: FN<3, 1, 2>(__VA_ARGS__); break;                  \
       case 321: FN<3, 2, 1>(__VA_ARGS__); break;                  \
       case 322: FN<3, 2, 2>(__VA_ARGS__); break;                  \
+      case 422: FN<4, 2, 2>(__VA_ARGS__); break;                  \
+      case 522: FN<5, 2, 2>(__VA_ARGS__); break;                  \
       default: break;                                             \
     }                                                             \
   } while (0)

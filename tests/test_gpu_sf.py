@@ -74,9 +74,19 @@ def test_ternary_alloy(lib):
     _compare(nn, [_alloy(["Al", "Cu", "Ni"], rep=(2, 2, 2))])
 
 
-def test_four_elements_use_generic_kernels(lib):
+def test_four_and_five_elements(lib):
+    # default channel grid: second-generation kernels with 4 / 5 partner species
     nn = make_nn(["Al", "Cu", "Mo", "Ni"], 4.5, True, [16], activation="relu")
     _compare(nn, [_alloy(["Al", "Cu", "Ni", "Mo"], rep=(2, 2, 2))])
+    nn = make_nn(["Al", "Co", "Cu", "Fe", "Ni"], 5.0, True, [16, 16], minmax=True)
+    _compare(nn, [_alloy(["Al", "Co", "Cu", "Fe", "Ni"], rep=(2, 2, 3)),
+                  _alloy(["Ni", "Fe", "Ni", "Co", "Al", "Cu", "Ni"], rep=(2, 2, 2), seed=9)])
+    # another grid (one zeta): first-generation kernels
+    nn = make_nn(["Al", "Cu", "Mo", "Ni"], 4.5, True, [16], sf_kwargs=dict(zeta=[2.0]))
+    _compare(nn, [_alloy(["Al", "Cu", "Ni", "Mo"], rep=(2, 2, 2))])
+    # six elements: first-generation kernels
+    nn = make_nn(["Al", "Co", "Cu", "Fe", "Mo", "Ni"], 4.5, True, [8])
+    _compare(nn, [_alloy(["Al", "Co", "Cu", "Fe", "Mo", "Ni"], rep=(2, 2, 2))])
 
 
 def test_first_generation_kernels(lib, monkeypatch):
