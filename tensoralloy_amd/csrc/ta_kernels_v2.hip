@@ -243,14 +243,10 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
   }
 }
 
-// Descriptor vectors of the workgroup's centres from data that is still in LDS: G2 from r^2
-// (sf.py:79-119), G4 from the per-pair partial sums `red[local channel][item]` the lanes left
-// there (local channel = (partner species * NG + ig) * NZ + iz), concatenated as sf.py:184-215.
-// One wavefront per centre, round robin.
-template <int NSPEC, int NG, int NZ>
-__device__ __forceinline__ void reduce_from_lds(const SFParams &sf, const AngChunk &ch,
-                                                const DeviceBatch &b, const Fields &f,
-                                                const double *red, int cap, int c0, int c1, int s0) {
+// Descriptor vectors of the workgroup's centres from data that is still in LDS, one wavefront per
+// centre, round robin. G2 from r^2 (sf.py:79-119):
+__device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const DeviceBatch &b,
+                                                       const Fields &f, int c0, int c1, int s0) {
   const int nel = sf.n_elements;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   for (int64_t i = c0 + w; i < c1; i += nwaves) {
@@ -281,24 +277,37 @@ __device__ __forceinline__ void reduce_from_lds(const SFParams &sf, const AngChu
         }
       }
     }
-#pragma unroll
-    for (int s1 = 0; s1 < NSPEC; ++s1)
-#pragma unroll
-      for (int s2 = s1; s2 < NSPEC; ++s2) {
-        const int t = angular_term2(s1, s2, nel);
-        const int a0 = seg[s1] - s0, a1 = seg[s1 + 1] - s0;
-        const int b0 = seg[s2] - s0, b1 = seg[s2 + 1] - s0;
+  }
+}
+
+// G4 (sf.py:121-182, :184-215) from the per-pair partial sums the lanes left in LDS for the partner
+// species [sp_lo, sp_hi): red[((sp - sp_lo) * NG + ig) * NZ + iz][item]. The term {A, B} (A < B) gets
+// the pairs of species B paired with partners A and the pairs of species A paired with partners B;
+// with the partner loop outermost and ascending, the first of the two always comes first (also
+// across passes), so it stores and the second adds.
+template <int NSPEC, int NG, int NZ>
+__device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, const AngChunk &ch,
+                                                        const DeviceBatch &b, const double *red, int cap,
+                                                        int c0, int c1, int s0, int sp_lo, int sp_hi) {
+  const int nel = sf.n_elements;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  for (int64_t i = c0 + w; i < c1; i += nwaves) {
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    double *Gi = b.G + (size_t)i * sf.ndim + sf.n_radial_dim;
+    for (int sp = sp_lo; sp < sp_hi; ++sp)
+      for (int sg = 0; sg < NSPEC; ++sg) {
+        const int t = angular_term2(sg, sp, nel);
+        const int q0 = seg[sg] - s0, q1 = seg[sg + 1] - s0;
 #pragma unroll
         for (int gz = 0; gz < NG * NZ; ++gz) {
           double v = 0.0;
-          const double *colA = red + (size_t)(s2 * NG * NZ + gz) * cap;
-          for (int q = a0 + l; q < a1; q += 64) v += colA[q];
-          if (s1 != s2) {
-            const double *colB = red + (size_t)(s1 * NG * NZ + gz) * cap;
-            for (int q = b0 + l; q < b1; q += 64) v += colB[q];
+          const double *col = red + (size_t)((sp - sp_lo) * NG * NZ + gz) * cap;
+          for (int q = q0 + l; q < q1; q += 64) v += col[q];
+          v = wave_sum(v) * sf.ang_scale;
+          if (l == 0) {
+            double *dst = Gi + t * sf.n_ang + ch.chan[gz];
+            *dst = (sg >= sp) ? v : *dst + v;
           }
-          v = wave_sum(v);
-          if (l == 0) Gi[sf.n_radial_dim + t * sf.n_ang + ch.chan[gz]] = sf.ang_scale * v;
         }
       }
   }
@@ -419,23 +428,33 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       if (b.masks) b.masks[p] = mask;
     }
     deal_by_popcount(f, b.cap, M, item, mask);
-    // flags & 4: this launch holds every angular channel of the model, and the partial sums fit
-    // behind r2 in LDS: the descriptors are assembled without a round trip through part4
+    // flags & 4: this launch holds every angular channel of the model: the descriptors are
+    // assembled from LDS, without a round trip through part4. The partial sums of up to 9 local
+    // channels at a time go behind r2: x .. G (6 cap doubles) and the rings behind them (3 cap
+    // doubles) are dead by now; more partner species take more passes.
     constexpr int kLocal = NSPEC * NG * NZ;
-    // room: x .. G (6 cap doubles) and the rings behind them (3 cap doubles), all dead by now
-    if ((flags & 4) && kLocal <= 9) {
+    constexpr int kGZ = NG * NZ;
+    constexpr int kSpPerPass = 9 / kGZ;
+    if (flags & 4) {
       double mine[kLocal];
 #pragma unroll
       for (int k = 0; k < kLocal; ++k) mine[k] = 0.0;
       if (active) run_item(item, true, mask, mine);
       __syncthreads();  // nobody reads x .. G or the sort scratch any more
       double *red = f.x;
-      if (active) {
 #pragma unroll
-        for (int k = 0; k < kLocal; ++k) red[(size_t)k * b.cap + item] = mine[k];
+      for (int sp_lo = 0; sp_lo < NSPEC; sp_lo += kSpPerPass) {
+        const int sp_hi = sp_lo + kSpPerPass < NSPEC ? sp_lo + kSpPerPass : NSPEC;
+        if (active) {
+#pragma unroll
+          for (int k = 0; k < kSpPerPass * kGZ; ++k)
+            if (sp_lo * kGZ + k < kLocal) red[(size_t)k * b.cap + item] = mine[sp_lo * kGZ + k];
+        }
+        __syncthreads();
+        if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+        reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, red, b.cap, c0, c1, s0, sp_lo, sp_hi);
+        __syncthreads();
       }
-      __syncthreads();
-      reduce_from_lds<NSPEC, NG, NZ>(sf, ch, b, f, red, b.cap, c0, c1, s0);
       return;
     }
     if (active) run_item(item, true, mask, nullptr);
