@@ -113,6 +113,15 @@ typedef struct {
    * pexp (rl, pl, -)].                                                                    */
   int32_t n_grap_params;
   const double *grap_params;
+
+  /* EAM / ADP "nn" functions -- the reference's default potentials (nn/eam/alloy.py:110-112,
+   * adp.py:120-124): rho(r), F(rho), phi(r), u(r), w(r) given by `convolution1x1` on the scalar
+   * argument (nn/eam/eam.py:174-190; no output bias). 0 = every function is analytic. Otherwise
+   * the number of function slots, 2 n_elements + n_pairs (ADP: + 2 n_pairs), in the order
+   * rho[element], embed[element], phi[pair a <= b], dipole[pair], quadrupole[pair]; `n_layers`
+   * [slot] (0 = analytic function, read from `eam_params`), `layer_sizes` ([1, h1, ..., 1] per
+   * nn slot) and `weights` (as above, per nn slot) describe them, `activation` applies to all. */
+  int32_t n_eam_nets;
 } ta_model_desc;
 
 /* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`

@@ -13,6 +13,9 @@ virial.
   F(rho_i), stitching ............ nn/eam/eam.py:401-493
   dipole / quadrupole energies ... nn/eam/adp.py:315-498 (squared PER k-body term)
   y = phi + embed (+ dip + quad) . nn/eam/eam.py:568, nn/eam/adp.py:584
+  "nn" functions (the default) ... nn/eam/eam.py:174-190 (`convolution1x1` on the scalar r or
+                                   rho, nn/convolutional.py:154-300: no output bias, no cutoff;
+                                   padded slots are removed by the masks, eam.py:344, alloy.py:181)
 
 The parameter values below are the published Zhou-Johnson-Wadley constants
 (Phys. Rev. B 69, 144113) as listed at zjw04.py:19-152, and Mishin's Ni-Ni
@@ -161,16 +164,48 @@ def mishin_polar(r, p1, p2, p3, rc, h):
     return left * psi, dleft * psi + left * dpsi
 
 
+def nn_function(x, layers, act="softplus", resnet=False):
+    """Scalar function f(x) given by a 1x1 CNN (eam.py:174-190; convolutional.py:257-290) and its
+    derivative f'(x), by forward-mode differentiation. `layers` = [(W [in, out], b or None), ...],
+    the last one being the linear output layer."""
+    from .sf import activation
+    x = np.asarray(x, dtype=np.float64)
+    h = x[:, None]
+    dh = np.ones_like(h)
+    n = len(layers)
+    for l, (W, b) in enumerate(layers):
+        W = np.asarray(W, dtype=np.float64)
+        z = h @ W + (0.0 if b is None else np.asarray(b, dtype=np.float64))
+        dz = dh @ W
+        if l < n - 1:
+            a, da = activation(act, z)
+            da = da * dz
+            if resnet and l > 0 and W.shape[0] == W.shape[1]:
+                a = a + h
+                da = da + dh
+            h, dh = a, da
+        else:
+            h, dh = z, dz
+    return h[:, 0], dh[:, 0]
+
+
 # ---- model ----------------------------------------------------------------------
 
 class EamModel:
     """elements (sorted), rcut, per-element Zjw04 parameters, optional ADP pair parameters
     keyed by the sorted pair 'AB' (dict with d1..q3, h, rc)."""
 
-    def __init__(self, elements, rcut, params=None, adp=None, blended_embed=False, phi_pairs=None):
+    def __init__(self, elements, rcut, params=None, adp=None, blended_embed=False, phi_pairs=None,
+                 nets=None, activation="softplus"):
         self.elements = sorted(set(elements))
         self.rcut = float(rcut)
-        self.params = params or {e: dict(ZJW04[e]) for e in self.elements}
+        # "nn" functions: {'rho': {el: layers}, 'embed': {el: layers}, 'phi': {'AB': layers},
+        # 'dipole': {'AB': layers}, 'quadrupole': {'AB': layers}}; a function without an entry is
+        # the analytic one
+        self.nets = nets or {}
+        self.activation = activation
+        self.params = params if params is not None else {
+            e: dict(ZJW04[e]) for e in self.elements if e in ZJW04}
         self.adp = adp  # {'NiNi': {...}} or None
         self.blended_embed = bool(blended_embed)  # Zjw04xc / uxc / xcp embedding
         self.phi_pairs = phi_pairs or {}          # Zjw04xcp: {'MoNi': {r_eq, A, B, ...}}
@@ -195,11 +230,16 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
     dphi_pair = np.zeros(len(pi))
     for b, eb in enumerate(els):
         m = sj == b
-        rho_pair[m], drho_pair[m] = zjw04_rho(r[m], model.params[eb])  # neighbour's element, alloy.py:176
+        if eb in model.nets.get("rho", {}):
+            rho_pair[m], drho_pair[m] = nn_function(r[m], model.nets["rho"][eb], model.activation)
+        else:
+            rho_pair[m], drho_pair[m] = zjw04_rho(r[m], model.params[eb])  # neighbour's element, alloy.py:176
         for a, ea in enumerate(els):
             mm = m & (si == a)
             key = "".join(sorted([ea, eb]))
-            if a != b and key in model.phi_pairs:
+            if key in model.nets.get("phi", {}):
+                phi_pair[mm], dphi_pair[mm] = nn_function(r[mm], model.nets["phi"][key], model.activation)
+            elif a != b and key in model.phi_pairs:
                 phi_pair[mm], dphi_pair[mm] = zjw04xcp_phi_ab(r[mm], model.phi_pairs[key])
             else:
                 phi_pair[mm], dphi_pair[mm] = zjw04_phi(r[mm], model.params[ea], model.params[eb], a == b)
@@ -211,6 +251,9 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
     dF = np.zeros(N)
     for a, ea in enumerate(els):
         m = spec == a
+        if ea in model.nets.get("embed", {}):
+            F[m], dF[m] = nn_function(rho[m], model.nets["embed"][ea], model.activation)
+            continue
         embed = zjw04xc_embed if model.blended_embed else zjw04_embed
         F[m], dF[m] = embed(rho[m], model.params[ea])
     atomic = F + 0.5 * phisum
@@ -229,12 +272,16 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
         for a, ea in enumerate(els):
             for b, eb in enumerate(els):
                 key = "".join(sorted([ea, eb]))
-                if key not in model.adp:
-                    continue
-                p = model.adp[key]
                 m = (si == a) & (sj == b)
-                u[m], du[m] = mishin_polar(r[m], p["d1"], p["d2"], p["d3"], p["rc"], p["h"])
-                w[m], dw[m] = mishin_polar(r[m], p["q1"], p["q2"], p["q3"], p["rc"], p["h"])
+                p = model.adp.get(key)
+                if key in model.nets.get("dipole", {}):
+                    u[m], du[m] = nn_function(r[m], model.nets["dipole"][key], model.activation)
+                elif p is not None:
+                    u[m], du[m] = mishin_polar(r[m], p["d1"], p["d2"], p["d3"], p["rc"], p["h"])
+                if key in model.nets.get("quadrupole", {}):
+                    w[m], dw[m] = nn_function(r[m], model.nets["quadrupole"][key], model.activation)
+                elif p is not None:
+                    w[m], dw[m] = mishin_polar(r[m], p["q1"], p["q2"], p["q3"], p["rc"], p["h"])
         np.add.at(mu, (pi, sj), u[:, None] * D)
         np.add.at(lam, (pi, sj), w[:, None, None] * D[:, :, None] * D[:, None, :])
         nu = np.trace(lam, axis1=2, axis2=3)

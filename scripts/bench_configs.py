@@ -64,8 +64,31 @@ def nimo_frame(seed=611):
     return Atoms(symbols=list(syms), positions=pts, cell=np.diag([a * r for r in rep]), pbc=True)
 
 
+def bench_nn_eam(steps=50):
+    from tests.helpers import make_eam, oracle_eam_eval
+    out = {}
+    atoms = ni_frame(611)
+    for tag, adp, rc in (("C4_nn_eam", False, 6.0), ("C4_nn_eam", False, 6.5), ("C4_nn_adp", True, 6.5)):
+        nn = make_eam(["Ni"], rc, adp=adp, potential=None)
+        with Engine(nn) as eng:
+            r = eng.evaluate([atoms])[0]
+            ms, slots = timeit(eng, WANT, steps=steps)
+            o = oracle_eam_eval(nn, atoms)
+            out[f"{tag}_rc{rc}"] = {
+                "atoms": len(atoms), "pairs": int(eng.info.n_pairs), "ms_per_eval": ms,
+                "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+                "hidden_sizes": nn.hidden_sizes["Ni"]["rho"],
+                "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
+                           "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
+                           "dW_max": float(np.abs(o["virial"] - r["virial"]).max())}}
+    return out
+
+
 def main():
     _lib.build()
+    if "--nn-eam" in sys.argv:
+        print(json.dumps(bench_nn_eam(), indent=1))
+        return
     out = {}
 
     # ---- C1
@@ -137,6 +160,9 @@ def main():
                     "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
                                "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
                                "dW_max": float(np.abs(o["virial"] - r["virial"]).max())}}
+    # nn-EAM: the reference's default potentials (rho, phi, embed = 1 -> 64 -> 32 -> 1 networks,
+    # alloy.py:110-112, Defaults.hidden_sizes)
+    out.update(bench_nn_eam())
     # ---- N1: the reference's default production descriptor (io/input/defaults.toml:131-155):
     # GRAP, pexp, 16 filters, moments 0..3, new mode, cosine cutoff, rc = 6.0; MLP 2 x 64
     from oracle import grap as ograp

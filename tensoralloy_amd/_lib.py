@@ -61,6 +61,7 @@ class ModelDesc(C.Structure):
         ("n_eam_params", C.c_int32), ("eam_params", _dp),
         ("eps", C.c_double),
         ("n_grap_params", C.c_int32), ("grap_params", _dp),
+        ("n_eam_nets", C.c_int32),
     ]
 
 

@@ -21,15 +21,34 @@
 //                    moments and the pair functions' derivatives.
 // Forces / virial / energy then use the same force_gather and frame_reduce
 // kernels as the symmetry-function path.
+//
+// "nn" functions (the reference's default potentials, alloy.py:110-112, adp.py:120-124): rho(r),
+// phi(r), u(r), w(r) and F(rho) given by `convolution1x1` on the scalar argument (eam.py:174-190,
+// convolutional.py:154-300). They run as 16-row tiles of the fp64 MFMA MLP (ta_mlp_tile.h), whose
+// backward sweep to the single input gives f'(x) with the value:
+//   eam_nn_pair_kernel   16 consecutive pairs per workgroup: geometry, then one tile pass per
+//                        (function class, slot) present among the 16 pairs (pairs are sorted by
+//                        centre and neighbour species, so that is one slot per class except at
+//                        segment boundaries); f, f' -> per-pair columns `pf`
+//   eam_atom_kernel      reads the columns instead of evaluating the analytic function
+//   eam_nn_embed_kernel  16 atoms of one element per workgroup: F(rho_i), F'(rho_i)
+//   eam_pair_kernel      reads f' from the columns
+// Any mix of nn and analytic functions is handled per function by the bit masks of `EamParams`.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ta_device.h"
 #include "ta_math.h"
+#include "ta_mlp_tile.h"
 
 namespace ta {
+
+struct EamModel;
+void eam_destroy(EamModel *);
 
 namespace {
 
@@ -45,7 +64,12 @@ struct EamParams {
   double el[kMaxEamElements][20];   // ZJW04_KEYS order (tensoralloy_amd/eam.py)
   double phi[kMaxPairTypes][7];     // r_eq A B alpha beta kappa lamda of a Zjw04xcp cross term
   double pair[kMaxPairTypes][8];    // d1 d2 d3 q1 q2 q3 h rc
+  // bit k set: the function of element / pair type k is an nn function
+  uint32_t nn_rho, nn_embed, nn_phi, nn_u, nn_w;
 };
+
+// columns of the per-pair function buffer `pf` (each `ps` doubles long)
+enum { PF_RHO = 0, PF_DRHO, PF_PHI, PF_DPHI, PF_U, PF_DU, PF_W, PF_DW };
 
 enum { R_EQ, F_EQ, RHO_E, RHO_S, ALPHA, BETA, PA, PB, KAPPA, LAMDA, FN0, FN1, FN2, FN3, F0, F1, F2, F3, ETA, FE };
 
@@ -169,7 +193,9 @@ __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, dou
 // moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
 // in the order xx yy zz yz xz xy
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
-                                                          double *mom, double eps) {
+                                                          double *mom, double eps,
+                                                          const double *__restrict__ pf, size_t ps,
+                                                          double *rho_buf) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
@@ -179,7 +205,10 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
   double rho = 0.0, phis = 0.0, eadp = 0.0;
   for (int sb = 0; sb < nel; ++sb) {
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double *pp = P.pair[pair_type(sA, sb, nel)];
+    const int pt = pair_type(sA, sb, nel);
+    const double *pp = P.pair[pt];
+    const bool rho_nn = (P.nn_rho >> sb) & 1u, phi_nn = (P.nn_phi >> pt) & 1u;
+    const bool u_nn = (P.nn_u >> pt) & 1u, w_nn = (P.nn_w >> pt) & 1u;
     for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
@@ -202,15 +231,20 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       }
       const double r = sqrt(rec[3]);
       double f, df;
-      zjw_rho(P.el[sb], r, f, df);  // density function of the NEIGHBOUR's element (alloy.py:176)
+      // density function of the NEIGHBOUR's element (alloy.py:176)
+      if (rho_nn) f = pf[PF_RHO * ps + q];
+      else zjw_rho(P.el[sb], r, f, df);
       rho += f;
-      zjw_phi(P, sA, sb, r, f, df);
+      if (phi_nn) f = pf[PF_PHI * ps + q];
+      else zjw_phi(P, sA, sb, r, f, df);
       phis += f;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
         double u, du, w, dw;
-        mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
-        mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        if (u_nn) u = pf[PF_U * ps + q];
+        else mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        if (w_nn) w = pf[PF_W * ps + q];
+        else mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
         m[0] = fma(u, dx, m[0]);
         m[1] = fma(u, dy, m[1]);
         m[2] = fma(u, dz, m[2]);
@@ -248,15 +282,116 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
   rho = wave_sum(rho);
   phis = wave_sum(phis);
   if (lane == 0) {
-    double F, d;
-    zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
-    b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
-    dF[i] = d;
+    if ((P.nn_embed >> sA) & 1u) {  // F(rho) is added by eam_nn_embed_kernel
+      rho_buf[i] = rho;
+      b.eatom[i] = 0.5 * phis + eadp;
+    } else {
+      double F, d;
+      zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
+      b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
+      dF[i] = d;
+    }
   }
 }
 
+// ---- nn functions ------------------------------------------------------------------------
+// slot order of the function networks: rho[element], embed[element], phi[pair type],
+// dipole[pair type], quadrupole[pair type]
+__host__ __device__ __forceinline__ int slot_rho(int e) { return e; }
+__host__ __device__ __forceinline__ int slot_embed(int nel, int e) { return nel + e; }
+__host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u, 3 w */, int pt) {
+  return 2 * nel + (cls - 1) * (nel * (nel + 1) / 2) + pt;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void eam_nn_pair_kernel(EamParams P, const MlpDev *__restrict__ nets,
+                                                              int act, DeviceBatch b, double *pf, size_t ps,
+                                                              double eps, int stride) {
+  extern __shared__ double lds[];
+  double *buf0 = lds, *buf1 = lds + kMlpRows * stride, *da = lds + 2 * kMlpRows * stride;
+  __shared__ double xr[kMlpRows];
+  __shared__ int key_sb[kMlpRows], key_pt[kMlpRows];
+  const int nel = P.nel, npt = nel * (nel + 1) / 2;
+  const int64_t p0 = (int64_t)blockIdx.x * kMlpRows;
+  const int nrows = (int)min((int64_t)kMlpRows, b.n_pairs - p0);
+  const int tid = threadIdx.x;
+  if (tid < kMlpRows) {
+    double r = 0.0;
+    int sb = -1, pt = -1;
+    if (tid < nrows) {
+      // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474)
+      const int64_t q = p0 + tid;
+      const int i = b.pair_i[q], j = b.pair_j[q];
+      const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
+      const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
+                   sz = (double)b.pair_shift[3 * (size_t)q + 2];
+      const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+      const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+      const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+      const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+      r = sqrt(dx * dx + dy * dy + dz * dz + eps);
+      sb = b.species[j];
+      pt = pair_type(b.species[i], sb, nel);
+    }
+    xr[tid] = r;
+    key_sb[tid] = sb;
+    key_pt[tid] = pt;
+  }
+  __syncthreads();
+  const int ncls = P.adp ? 4 : 2;
+  for (int cls = 0; cls < ncls; ++cls) {
+    const uint32_t nn = cls == 0 ? P.nn_rho : cls == 1 ? P.nn_phi : cls == 2 ? P.nn_u : P.nn_w;
+    if (!nn) continue;
+    const int *key = cls == 0 ? key_sb : key_pt;
+    const int nk = cls == 0 ? nel : npt;
+    for (int k = 0; k < nk; ++k) {
+      if (!((nn >> k) & 1u)) continue;
+      bool need = false;  // the same for every thread: read from LDS
+      for (int row = 0; row < nrows; ++row) need |= key[row] == k;
+      if (!need) continue;
+      if (tid < kMlpRows) buf0[tid * stride] = xr[tid];
+      __syncthreads();
+      const MlpDev &net = nets[cls == 0 ? slot_rho(k) : slot_pair(nel, cls, k)];
+      double *val = pf + (size_t)(2 * cls) * ps + p0, *der = pf + (size_t)(2 * cls + 1) * ps + p0;
+      mlp_tile<16>(
+          net, act, 1, nrows, buf0, buf1, stride, da,
+          [&](int row, double y) { if (key[row] == k) val[row] = y; },
+          [&](int row, int, double d) { if (key[row] == k) der[row] = d; });
+    }
+  }
+}
+
+struct EmbedTiles {
+  int32_t tile_start[kMaxEamElements + 1];  // first workgroup of every element (nn embeddings only)
+  int32_t elem_start[kMaxEamElements + 1];  // first entry of every element in `elem_atoms`
+  int nel;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void eam_nn_embed_kernel(const MlpDev *__restrict__ nets, EmbedTiles t,
+                                                               int act, DeviceBatch b,
+                                                               const double *__restrict__ rho_buf,
+                                                               double *dF, int stride) {
+  extern __shared__ double lds[];
+  double *buf0 = lds, *buf1 = lds + kMlpRows * stride, *da = lds + 2 * kMlpRows * stride;
+  int e = 0;
+  while (e + 1 < t.nel && (int)blockIdx.x >= t.tile_start[e + 1]) ++e;
+  const int32_t *atoms = b.elem_atoms + t.elem_start[e];
+  const int n_atoms = t.elem_start[e + 1] - t.elem_start[e];
+  const int a0 = ((int)blockIdx.x - t.tile_start[e]) * kMlpRows;
+  const int nrows = min(kMlpRows, n_atoms - a0);
+  if (threadIdx.x < kMlpRows)
+    buf0[threadIdx.x * stride] = (int)threadIdx.x < nrows ? rho_buf[atoms[a0 + threadIdx.x]] : 0.0;
+  __syncthreads();
+  mlp_tile<16>(
+      nets[slot_embed(t.nel, e)], act, 1, nrows, buf0, buf1, stride, da,
+      [&](int row, double y) { b.eatom[atoms[a0 + row]] += y; },  // eam.py:568: y = phi + embed
+      [&](int row, int, double d) { dF[atoms[a0 + row]] = d; });
+}
+
 __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBatch b,
-                                                          const double *dF, const double *mom) {
+                                                          const double *dF, const double *mom,
+                                                          const double *__restrict__ pf, size_t ps) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= b.n_pairs) return;
   const int nel = P.nel;
@@ -266,17 +401,30 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const double dx = rec[0], dy = rec[1], dz = rec[2], inv_r = rec[4];
   const double r = sqrt(rec[3]);
   double f, drho, dphi;
-  zjw_rho(P.el[sa], r, f, drho);
-  zjw_phi(P, sA, sa, r, f, dphi);
+  const int pt = pair_type(sA, sa, nel);
+  if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
+  else zjw_rho(P.el[sa], r, f, drho);
+  if ((P.nn_phi >> pt) & 1u) dphi = pf[PF_DPHI * ps + p];
+  else zjw_phi(P, sA, sa, r, f, dphi);
   // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
   double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
   double gx = c * dx, gy = c * dy, gz = c * dz;
   if (P.adp) {
-    const double *pp = P.pair[pair_type(sA, sa, nel)];
+    const double *pp = P.pair[pt];
     const double *m = mom + ((size_t)i * nel + sa) * 9;
     double u, du, w, dw;
-    mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
-    mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+    if ((P.nn_u >> pt) & 1u) {
+      u = pf[PF_U * ps + p];
+      du = pf[PF_DU * ps + p];
+    } else {
+      mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+    }
+    if ((P.nn_w >> pt) & 1u) {
+      w = pf[PF_W * ps + p];
+      dw = pf[PF_DW * ps + p];
+    } else {
+      mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+    }
     const double muD = m[0] * dx + m[1] * dy + m[2] * dz;
     const double lx = m[3] * dx + m[8] * dy + m[7] * dz;
     const double ly = m[8] * dx + m[4] * dy + m[6] * dz;
@@ -341,6 +489,24 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
   }
 }
 
+// table of one nn function on caller-supplied abscissae (setfl export)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void eam_nn_table_kernel(const MlpDev *__restrict__ nets, int slot,
+                                                               int act, const double *__restrict__ x,
+                                                               int n, double *out, int stride) {
+  extern __shared__ double lds[];
+  double *buf0 = lds, *buf1 = lds + kMlpRows * stride, *da = lds + 2 * kMlpRows * stride;
+  const int a0 = blockIdx.x * kMlpRows;
+  const int nrows = min(kMlpRows, n - a0);
+  if (threadIdx.x < kMlpRows) buf0[threadIdx.x * stride] = (int)threadIdx.x < nrows ? x[a0 + threadIdx.x] : 0.0;
+  __syncthreads();
+  mlp_tile<16>(
+      nets[slot], act, 1, nrows, buf0, buf1, stride, da, [&](int row, double y) { out[a0 + row] = y; },
+      [&](int, int, double) {});
+}
+
+constexpr int kNetThreads = 256;
+
 }  // namespace
 
 struct EamModel {
@@ -348,7 +514,92 @@ struct EamModel {
   double *dF = nullptr, *mom = nullptr;
   size_t cap_atoms = 0;
   double eps = 1e-14;
+  // nn functions
+  int n_slots = 0;
+  int activation = TA_ACT_SOFTPLUS;
+  std::vector<MlpDev> nets;       // host copies (device pointers inside), n_layers == 0: analytic
+  MlpDev *nets_dev = nullptr;
+  std::vector<double *> owned;    // device allocations of the weights
+  int stride = 0, max_layers = 0; // LDS row stride / deepest network
+  bool pair_nets = false, embed_nets = false;
+  double *pf = nullptr;           // [8 or 4][cap_pairs] value / derivative columns
+  size_t cap_pairs = 0;
+  double *rho_buf = nullptr;      // [cap_atoms]
 };
+
+namespace {
+
+template <typename T>
+T *eam_upload(EamModel *e, const std::vector<T> &v) {
+  T *d = nullptr;
+  if (hipMalloc((void **)&d, std::max<size_t>(1, v.size()) * sizeof(T)) != hipSuccess) throw std::bad_alloc();
+  e->owned.push_back(reinterpret_cast<double *>(d));
+  if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    throw std::runtime_error("hipMemcpy of the EAM function networks failed");
+  return d;
+}
+
+int round16(int x) { return (x + 15) / 16 * 16; }
+
+// function networks of the model description -> padded device copies, both orientations
+// (same layout as the per-element MLPs, ta_api.hip build_mlp)
+void build_nets(EamModel *e, const ta_model_desc *m, int n_slots) {
+  if (!m->n_layers || !m->layer_sizes || !m->weights)
+    throw std::invalid_argument("n_eam_nets set but the network description is missing");
+  if (m->activation < 0 || m->activation > TA_ACT_ELU) throw std::invalid_argument("unknown activation");
+  e->activation = m->activation;
+  e->n_slots = n_slots;
+  e->nets.assign(n_slots, MlpDev());
+  const int32_t *sizes = m->layer_sizes;
+  const double *wsrc = m->weights;
+  for (int sl = 0; sl < n_slots; ++sl) {
+    const int L = m->n_layers[sl];
+    if (L == 0) continue;
+    if (L < 2 || L > kMaxLayers) throw std::domain_error("nn function depth out of range (2..8 layers)");
+    if (sizes[0] != 1 || sizes[L] != 1)
+      throw std::invalid_argument("an nn function maps one input to one output");
+    MlpDev &md = e->nets[sl];
+    md.n_layers = L;
+    for (int l = 0; l < L; ++l) {
+      MlpLayerDev &ly = md.layer[l];
+      ly.k = sizes[l];
+      ly.n = sizes[l + 1];
+      if (ly.k < 1 || ly.n < 1 || ly.k > 512 || ly.n > 512)
+        throw std::domain_error("nn function layer width out of range (1..512)");
+      ly.kp = round16(ly.k);
+      ly.np = round16(ly.n);
+      ly.act = (l < L - 1) ? 1 : 0;
+      ly.res = (m->use_resnet_dt && l > 0 && l < L - 1 && ly.k == ly.n) ? 1 : 0;
+      std::vector<double> w((size_t)ly.kp * ly.np, 0.0), wt((size_t)ly.np * ly.kp, 0.0), bb(ly.np, 0.0);
+      for (int k = 0; k < ly.k; ++k)
+        for (int n = 0; n < ly.n; ++n) {
+          const double v = wsrc[(size_t)k * ly.n + n];
+          w[(size_t)k * ly.np + n] = v;
+          wt[(size_t)n * ly.kp + k] = v;
+        }
+      wsrc += (size_t)ly.k * ly.n;
+      for (int n = 0; n < ly.n; ++n) bb[n] = wsrc[n];
+      wsrc += ly.n;
+      ly.w = eam_upload(e, w);
+      ly.wt = eam_upload(e, wt);
+      ly.b = eam_upload(e, bb);
+      md.max_np = std::max(md.max_np, ly.np);
+      md.max_kp = std::max(md.max_kp, ly.kp);
+    }
+    sizes += L + 1;
+    e->stride = std::max(e->stride, mlp_stride(md));
+    e->max_layers = std::max(e->max_layers, L);
+  }
+  if ((size_t)(2 + e->max_layers) * kMlpRows * e->stride * sizeof(double) > 150 * 1024)
+    throw std::domain_error("nn functions too wide / deep for the LDS tile");
+  e->nets_dev = eam_upload(e, e->nets);
+}
+
+size_t net_lds_bytes(const EamModel *e) {
+  return (size_t)(2 + e->max_layers) * kMlpRows * e->stride * sizeof(double);
+}
+
+}  // namespace
 
 EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   const int nel = m->n_elements;
@@ -368,11 +619,36 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     err = "EAM/ADP models support at most 5 elements";
     return nullptr;
   }
+  const int n_slots = 2 * nel + npair * (adp ? 3 : 1);
+  if (m->n_eam_nets != 0 && m->n_eam_nets != n_slots) {
+    err = "n_eam_nets must be 0 or " + std::to_string(n_slots) + " for this model";
+    return nullptr;
+  }
   EamModel *e = new EamModel();
   std::memset(&e->p, 0, sizeof(e->p));
   e->p.nel = nel;
   e->p.adp = adp ? 1 : 0;
   e->eps = m->eps > 0.0 ? m->eps : 1e-14;
+  if (m->n_eam_nets) {
+    try {
+      build_nets(e, m, n_slots);
+    } catch (const std::exception &ex) {
+      err = ex.what();
+      eam_destroy(e);
+      return nullptr;
+    }
+    for (int k = 0; k < nel; ++k) {
+      if (e->nets[slot_rho(k)].n_layers) e->p.nn_rho |= 1u << k;
+      if (e->nets[slot_embed(nel, k)].n_layers) e->p.nn_embed |= 1u << k;
+    }
+    for (int k = 0; k < npair; ++k) {
+      if (e->nets[slot_pair(nel, 1, k)].n_layers) e->p.nn_phi |= 1u << k;
+      if (adp && e->nets[slot_pair(nel, 2, k)].n_layers) e->p.nn_u |= 1u << k;
+      if (adp && e->nets[slot_pair(nel, 3, k)].n_layers) e->p.nn_w |= 1u << k;
+    }
+    e->pair_nets = e->p.nn_rho || e->p.nn_phi || e->p.nn_u || e->p.nn_w;
+    e->embed_nets = e->p.nn_embed != 0;
+  }
   for (int k = 0; k < nel; ++k) {
     for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 21 + c];
     e->p.embed_kind[k] = m->eam_params[k * 21 + 20] != 0.0 ? 1 : 0;
@@ -382,7 +658,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     e->p.phi_kind[k] = pp[k * 8] != 0.0 ? 1 : 0;
     for (int c = 0; c < 7; ++c) e->p.phi[k][c] = pp[k * 8 + 1 + c];
     if (e->p.phi_kind[k] == 1 && !(e->p.phi[k][0] > 0.0)) {
-      delete e;
+      eam_destroy(e);
       err = "r_eq of a zjw04xcp pair term must be positive";
       return nullptr;
     }
@@ -395,7 +671,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   }
   for (int k = 0; k < nel; ++k)
     if (!(e->p.el[k][R_EQ] > 0.0) || !(e->p.el[k][RHO_E] > 0.0) || !(e->p.el[k][RHO_S] > 0.0)) {
-      delete e;
+      eam_destroy(e);
       err = "r_eq, rho_e and rho_s must be positive";
       return nullptr;
     }
@@ -406,20 +682,37 @@ void eam_destroy(EamModel *m) {
   if (!m) return;
   if (m->dF) (void)hipFree(m->dF);
   if (m->mom) (void)hipFree(m->mom);
+  if (m->pf) (void)hipFree(m->pf);
+  if (m->rho_buf) (void)hipFree(m->rho_buf);
+  for (double *d : m->owned) (void)hipFree(d);
   delete m;
 }
 
 void eam_ensure(EamModel *m, const DeviceBatch &b) {
   const size_t n = (size_t)b.n_atoms;
-  if (n <= m->cap_atoms) return;
-  if (m->dF) (void)hipFree(m->dF);
-  if (m->mom) (void)hipFree(m->mom);
-  m->dF = m->mom = nullptr;
-  const size_t cap = n + n / 8 + 64;
-  if (hipMalloc((void **)&m->dF, cap * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&m->mom, cap * (size_t)m->p.nel * 9 * sizeof(double)) != hipSuccess)
-    throw std::bad_alloc();
-  m->cap_atoms = cap;
+  if (n > m->cap_atoms) {
+    if (m->dF) (void)hipFree(m->dF);
+    if (m->mom) (void)hipFree(m->mom);
+    if (m->rho_buf) (void)hipFree(m->rho_buf);
+    m->dF = m->mom = m->rho_buf = nullptr;
+    m->cap_atoms = 0;
+    const size_t cap = n + n / 8 + 64;
+    if (hipMalloc((void **)&m->dF, cap * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&m->mom, cap * (size_t)m->p.nel * 9 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&m->rho_buf, cap * sizeof(double)) != hipSuccess)
+      throw std::bad_alloc();
+    m->cap_atoms = cap;
+  }
+  const size_t np = (size_t)b.n_pairs;
+  if (m->pair_nets && np > m->cap_pairs) {
+    if (m->pf) (void)hipFree(m->pf);
+    m->pf = nullptr;
+    m->cap_pairs = 0;
+    const size_t cap = np + np / 8 + 64;
+    if (hipMalloc((void **)&m->pf, cap * (m->p.adp ? 8 : 4) * sizeof(double)) != hipSuccess)
+      throw std::bad_alloc();
+    m->cap_pairs = cap;
+  }
 }
 
 void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double *rho, double *rho_of_r,
@@ -430,6 +723,25 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
   if (total == 0) return;
   hipLaunchKernelGGL(eam_tabulate_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock),
                      0, s, m->p, n_r, r, n_rho, rho, rho_of_r, phi_of_r, embed_of_rho, u_of_r, w_of_r);
+  if (!m->n_slots) return;
+  // rows of nn functions: one launch per function over the same abscissae
+  const size_t lds = net_lds_bytes(m);
+  auto table = [&](int slot, const double *x, int n, double *out) {
+    if (!out || n == 0 || m->nets[slot].n_layers == 0) return;
+    hipLaunchKernelGGL(eam_nn_table_kernel<kNetThreads>, dim3((unsigned)((n + kMlpRows - 1) / kMlpRows)),
+                       dim3(kNetThreads), lds, s, m->nets_dev, slot, m->activation, x, n, out, m->stride);
+  };
+  for (int e = 0; e < nel; ++e) {
+    table(slot_rho(e), r, n_r, rho_of_r + (size_t)e * n_r);
+    table(slot_embed(nel, e), rho, n_rho, embed_of_rho + (size_t)e * n_rho);
+  }
+  for (int pt = 0; pt < npair; ++pt) {
+    table(slot_pair(nel, 1, pt), r, n_r, phi_of_r + (size_t)pt * n_r);
+    if (m->p.adp && u_of_r && w_of_r) {
+      table(slot_pair(nel, 2, pt), r, n_r, u_of_r + (size_t)pt * n_r);
+      table(slot_pair(nel, 3, pt), r, n_r, w_of_r + (size_t)pt * n_r);
+    }
+  }
 }
 
 void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {
@@ -438,11 +750,34 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   std::memset(&sf, 0, sizeof(sf));
   sf.n_elements = m->p.nel;
   sf.eps = m->eps;
+  const size_t ps = m->cap_pairs;
+  if (m->pair_nets && b.n_pairs > 0)
+    hipLaunchKernelGGL(eam_nn_pair_kernel<kNetThreads>,
+                       dim3((unsigned)((b.n_pairs + kMlpRows - 1) / kMlpRows)), dim3(kNetThreads),
+                       net_lds_bytes(m), s, m->p, m->nets_dev, m->activation, b, m->pf, ps, m->eps,
+                       m->stride);
   hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps);
+                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf, ps, m->rho_buf);
+  if (m->embed_nets) {
+    EmbedTiles t;
+    std::memset(&t, 0, sizeof(t));
+    t.nel = m->p.nel;
+    int blocks = 0;
+    for (int e = 0; e < t.nel; ++e) {
+      t.tile_start[e] = blocks;
+      t.elem_start[e] = b.elem_start[e];
+      if ((m->p.nn_embed >> e) & 1u) blocks += (b.elem_start[e + 1] - b.elem_start[e] + kMlpRows - 1) / kMlpRows;
+    }
+    t.tile_start[t.nel] = blocks;
+    t.elem_start[t.nel] = b.elem_start[t.nel];
+    if (blocks)
+      hipLaunchKernelGGL(eam_nn_embed_kernel<kNetThreads>, dim3((unsigned)blocks), dim3(kNetThreads),
+                         net_lds_bytes(m), s, m->nets_dev, t, m->activation, b, m->rho_buf, m->dF,
+                         m->stride);
+  }
   if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
     hipLaunchKernelGGL(eam_pair_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom);
+                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps);
     launch_force_gather(sf, b, s);
   } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
     launch_force_gather(sf, b, s);

@@ -10,14 +10,25 @@ Supported potentials: the Zhou-Johnson-Wadley family for rho / embed / phi --
 blended embedding, :415-568; the two differ only in which constants are
 trainable) and `zjw04xcp` (own constants for cross-element phi, :571-696) -- and
 `mishinh` for the ADP dipole / quadrupole (nn/eam/potentials/mishin.py:269-315).
-One family per model. "nn" potentials (MLP-based rho / phi / embed) and the other
-empirical parameterisations are out of scope and raise `ValueError`.
+One family per model; the other empirical parameterisations raise `ValueError`.
+
+"nn" functions -- the reference's default (alloy.py:110-112, adp.py:120-124): rho(r), phi(r),
+F(rho), u(r), w(r) each given by a 1x1 CNN on the scalar argument (eam.py:174-190,
+`convolution1x1` with `Defaults.hidden_sizes`, no output bias) -- run on the GPU as 16-row fp64
+MFMA tiles over the pair list / the atoms (csrc/ta_eam.hip). Any mix of "nn" and analytic
+functions inside one model is allowed, as in the reference. Weights live in
+`nn.weights[section][function] = [(W [in, out], b), ..., (W_out, None)]` with section = element
+symbol or sorted pair key, and are written to / read from `<stem>.npz` under
+`<section>/<function>/weights_<j>`, `.../biases_<j>`.
 
 Flat parameter block handed to the C ABI (`ta_model_desc.eam_params`):
   per element (sorted): 20 doubles in `ZJW04_KEYS` order + embed kind (0 / 1);
   per unordered element pair (a <= b, row-major upper triangle): phi kind
   (0 = Zjw04, 1 = Zjw04xcp constants) + [r_eq, A, B, alpha, beta, kappa, lamda];
   for ADP, per pair: 8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = none).
+Function networks travel in the MLP fields of `ta_model_desc` as `n_eam_nets` slots in the order
+rho[element], embed[element], phi[pair], then for ADP dipole[pair], quadrupole[pair]; a slot with
+0 layers is an analytic function.
 """
 from __future__ import annotations
 
@@ -29,7 +40,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 
 from . import _lib
-from .utils import get_elements_from_kbody_term, get_kbody_terms
+from .utils import Defaults, get_elements_from_kbody_term, get_kbody_terms
 
 ZJW04_KEYS = ["r_eq", "f_eq", "rho_e", "rho_s", "alpha", "beta", "A", "B", "kappa", "lamda",
               "Fn0", "Fn1", "Fn2", "Fn3", "F0", "F1", "F2", "F3", "eta", "Fe"]
@@ -88,12 +99,13 @@ class EamAlloyNN:
 
     def __init__(self, elements: Sequence[str], custom_potentials=None, hidden_sizes=None,
                  fixed_functions=None, minimize_properties=("energy", "forces"),
-                 export_properties=("energy", "forces", "stress"), parameters=None):
+                 export_properties=("energy", "forces", "stress"), parameters=None,
+                 activation=None):
         self._elements = sorted(list(elements))
+        self._activation = activation or Defaults.activation
         self._fixed_functions = list(fixed_functions or [])
         self._minimize_properties = list(minimize_properties)
         self._export_properties = list(export_properties)
-        self._hidden_sizes = hidden_sizes
         kbody = get_kbody_terms(self._elements, angular=False)[1]
         unique = []
         for el in self._elements:
@@ -103,6 +115,8 @@ class EamAlloyNN:
                 if ab not in unique:
                     unique.append(ab)
         self._unique_kbody_terms = unique
+        self._hidden_sizes = self._get_hidden_sizes(hidden_sizes)
+        self.weights = {}
         self._custom_potentials = custom_potentials
         self._potentials = self._setup_potentials(custom_potentials)
         # overrides of the default constants: {"Ni": {"r_eq": ...}, "NiNi": {"d1": ...}}
@@ -114,11 +128,31 @@ class EamAlloyNN:
     def _extra_functions(self):
         return ()
 
+    def _pair_functions(self):
+        return ("phi",) + tuple(self._extra_functions())
+
+    def _get_hidden_sizes(self, hidden_sizes):
+        """Nested dict {section: {function: [sizes]}} from an int, a list or a nested dict
+        (alloy.py:39-90, adp.py:51-105)."""
+        default = list(Defaults.hidden_sizes)
+        res = {el: {"rho": list(default), "embed": list(default)} for el in self._elements}
+        res.update({t: {fn: list(default) for fn in self._pair_functions()}
+                    for t in self._unique_kbody_terms})
+        if hidden_sizes is None:
+            return res
+        for sec in res:
+            if isinstance(hidden_sizes, dict):
+                for fn, v in hidden_sizes.get(sec, {}).items():
+                    if fn in res[sec]:
+                        res[sec][fn] = [int(x) for x in np.atleast_1d(v)]
+            else:
+                for fn in res[sec]:
+                    res[sec][fn] = [int(x) for x in np.atleast_1d(hidden_sizes)]
+        return res
+
     def _setup_potentials(self, custom):
-        if custom is None:
-            raise ValueError("nn-EAM ('nn' potentials) is not implemented by tensoralloy_amd; "
-                             "pass custom_potentials='zjw04'")
         pots = {}
+        custom = {} if custom is None else custom
         if isinstance(custom, str):
             for el in self._elements:
                 pots[el] = {"rho": custom, "embed": custom}
@@ -140,6 +174,8 @@ class EamAlloyNN:
             for fn, name in sec.items():
                 ok = {"rho": ZJW04_FAMILY, "embed": ZJW04_FAMILY, "phi": ZJW04_FAMILY,
                       "dipole": ("mishinh",), "quadrupole": ("mishinh",)}[fn]
+                if str(name).lower() == "nn":
+                    continue
                 if str(name).lower() not in ok:
                     raise ValueError(f"potential '{name}' for {key}/{fn} is not implemented by "
                                      f"tensoralloy_amd (available: {ok})")
@@ -186,8 +222,51 @@ class EamAlloyNN:
             raise ValueError("EAM models need a radial-only transformer (angular=False)")
         self._transformer = clf
 
+    @property
+    def hidden_sizes(self):
+        return self._hidden_sizes
+
+    def is_nn(self, section: str, fn: str) -> bool:
+        return str(self._potentials[section][fn]).lower() == "nn"
+
+    def nn_functions(self):
+        """(section, function) of every "nn" function in ABI slot order; analytic ones as None."""
+        slots = [(el, "rho") for el in self._elements] + [(el, "embed") for el in self._elements]
+        n = len(self._elements)
+        pairs = [self._elements[i] + self._elements[j] for i in range(n) for j in range(i, n)]
+        for fn in self._pair_functions():
+            slots += [(t, fn) for t in pairs]
+        return [(sec, fn) if self.is_nn(sec, fn) else None for sec, fn in slots]
+
+    def initialize(self, seed=Defaults.seed, bias_scale=0.0):
+        """He-normal kernels truncated at 2 sigma, zero (or small random) hidden biases, no output
+        bias (nn/init_ops.py:20-30; `convolution1x1(..., output_bias=False)`, eam.py:184-190)."""
+        rng = np.random.RandomState(seed)
+        self.weights = {}
+        for slot in self.nn_functions():
+            if slot is None:
+                continue
+            sec, fn = slot
+            sizes = [1] + list(self._hidden_sizes[sec][fn]) + [1]
+            layers = []
+            for l in range(len(sizes) - 1):
+                fan_in, fan_out = sizes[l], sizes[l + 1]
+                sigma = np.sqrt(2.0 / fan_in)
+                w = rng.normal(0.0, sigma, size=(fan_in, fan_out))
+                bad = np.abs(w) > 2 * sigma
+                while bad.any():
+                    w[bad] = rng.normal(0.0, sigma, size=int(bad.sum()))
+                    bad = np.abs(w) > 2 * sigma
+                if l == len(sizes) - 2:
+                    b = None
+                else:
+                    b = bias_scale * rng.normal(size=fan_out) if bias_scale else np.zeros(fan_out)
+                layers.append((w, b))
+            self.weights.setdefault(sec, {})[fn] = layers
+
     def as_dict(self):
         return {"class": self.__class__.__name__, "elements": self._elements,
+                "activation": self._activation,
                 "custom_potentials": self._potentials, "hidden_sizes": self._hidden_sizes,
                 "fixed_functions": self._fixed_functions,
                 "minimize_properties": self._minimize_properties,
@@ -207,6 +286,10 @@ class EamAlloyNN:
         if self._family != "zjw04":
             table["Be"] = table["Mo"]
         if el not in table:
+            if self._element_is_all_nn(el):  # no analytic function reads these constants
+                p = dict.fromkeys(ZJW04_KEYS, 0.0)
+                p.update(r_eq=1.0, rho_e=1.0, rho_s=1.0)
+                return p
             raise ValueError(f"{self._family} has no parameters for element {el}")
         p = dict(zip(ZJW04_KEYS, table[el]))
         if self._family == "zjw04xcp" and el in ZJW04XCP_ELEMENTS:
@@ -214,11 +297,21 @@ class EamAlloyNN:
         p.update(self._parameters.get(el, {}))
         return p
 
+    def _element_is_all_nn(self, el: str) -> bool:
+        if not (self.is_nn(el, "rho") and self.is_nn(el, "embed")):
+            return False
+        for t in self._unique_kbody_terms:
+            if el in get_elements_from_kbody_term(t) and not self.is_nn(t, "phi"):
+                return False
+        return True
+
     def phi_parameters(self, a: str, b: str):
         """Constants of a cross-element phi of Zjw04xcp, else None (Zjw04 mixing rule)."""
         if a == b or self._family != "zjw04xcp":
             return None
         key = "".join(sorted([a, b]))
+        if self.is_nn(key, "phi"):
+            return None
         p = dict(ZJW04XCP_PAIRS.get(key, {}))
         p.update({k: v for k, v in self._parameters.get(key, {}).items() if k in PHI_KEYS})
         missing = [k for k in PHI_KEYS if k not in p]
@@ -264,6 +357,41 @@ class EamAlloyNN:
         desc.n_eam_params = len(params)
         desc.eam_params = _lib.as_dp(params)
         desc.eps = 1e-8 if self.precision == "medium" else 1e-14  # precision.py:113-114
+        slots = self.nn_functions()
+        if any(s is not None for s in slots):
+            n_layers, sizes, flat = [], [], []
+            for slot in slots:
+                if slot is None:
+                    n_layers.append(0)
+                    continue
+                sec, fn = slot
+                try:
+                    layers = self.weights[sec][fn]
+                except KeyError:
+                    raise ValueError(f"no weights for the nn function {sec}/{fn}: call initialize() "
+                                     f"or set .weights['{sec}']['{fn}']") from None
+                n_layers.append(len(layers))
+                sz = [1]
+                for w, b in layers:
+                    w = np.asarray(w, dtype=np.float64)
+                    if w.ndim != 2 or w.shape[0] != sz[-1]:
+                        raise ValueError(f"{sec}/{fn}: weight shape {w.shape} does not chain from {sz[-1]}")
+                    sz.append(w.shape[1])
+                    flat.append(w.ravel())
+                    flat.append(np.zeros(w.shape[1]) if b is None
+                                else np.asarray(b, dtype=np.float64).ravel())
+                if sz[-1] != 1:
+                    raise ValueError(f"{sec}/{fn}: the output layer must have one unit")
+                sizes.extend(sz)
+            il = np.ascontiguousarray(n_layers, dtype=np.int32)
+            isz = np.ascontiguousarray(sizes, dtype=np.int32)
+            fw = np.ascontiguousarray(np.concatenate(flat))
+            keep += [il, isz, fw]
+            desc.n_eam_nets = len(slots)
+            desc.n_layers = _lib.as_ip(il)
+            desc.layer_sizes = _lib.as_ip(isz)
+            desc.weights = _lib.as_dp(fw)
+            desc.activation = _lib.TA_ACT[self._activation.lower()]
         return desc, keep
 
     def export(self, output_graph_path: str, **_ignored):
@@ -296,6 +424,18 @@ class EamAlloyNN:
             "nn": self.as_dict(),
             "weights": None,
         }
+        data = {}
+        for slot in self.nn_functions():
+            if slot is None:
+                continue
+            sec, fn = slot
+            for j, (w, b) in enumerate(self.weights[sec][fn]):
+                data[f"{sec}/{fn}/weights_{j}"] = np.asarray(w, dtype=np.float64)
+                if b is not None:
+                    data[f"{sec}/{fn}/biases_{j}"] = np.asarray(b, dtype=np.float64)
+        if data:
+            meta["weights"] = os.path.basename(stem) + ".npz"
+            np.savez(stem + ".npz", **data)
         with open(stem + ".json", "w") as fp:
             json.dump(meta, fp, indent=1)
         return stem + ".json"
@@ -378,13 +518,33 @@ class AdpNN(EamAlloyNN):
             for j in range(i, n):
                 term = self._elements[i] + self._elements[j]
                 p = self.pair_parameters(term)
+                if p is None and self.is_nn(term, "dipole") and self.is_nn(term, "quadrupole"):
+                    p = dict(zip(ADP_KEYS, [0.0] * 6 + [1.0, 0.0]))  # not read by nn functions
                 if p is None:
                     raise ValueError(f"mishinh has no dipole/quadrupole parameters for {term}")
                 out.extend(p[k] for k in ADP_KEYS)
         return np.array(out, dtype=np.float64)
 
 
-def nn_from_dict(cls_name: str, cfg: dict):
+def nn_from_dict(cls_name: str, cfg: dict, npz=None):
+    """Rebuild a model from `as_dict()`; `npz` = the weight archive of its nn functions."""
     cfg = dict(cfg)
     cls = {"EamAlloyNN": EamAlloyNN, "AdpNN": AdpNN}[cls_name]
-    return cls(**cfg)
+    nn = cls(**cfg)
+    for slot in nn.nn_functions():
+        if slot is None:
+            continue
+        sec, fn = slot
+        if npz is None:
+            raise ValueError(f"the model has nn functions ({sec}/{fn}) but no weight file")
+        layers, j = [], 0
+        while f"{sec}/{fn}/weights_{j}" in npz:
+            w = np.array(npz[f"{sec}/{fn}/weights_{j}"], dtype=np.float64)
+            b = np.array(npz[f"{sec}/{fn}/biases_{j}"], dtype=np.float64).ravel() \
+                if f"{sec}/{fn}/biases_{j}" in npz else None
+            layers.append((w, b))
+            j += 1
+        if not layers:
+            raise ValueError(f"the weight file holds nothing for {sec}/{fn}")
+        nn.weights.setdefault(sec, {})[fn] = layers
+    return nn

@@ -567,7 +567,10 @@ def load_model(graph_model_path: str):
                 nn.minmax[el] = (np.array(npz[f"xlo_{i}"]), np.array(npz[f"xhi_{i}"]))
     elif nn_cls in ("EamAlloyNN", "AdpNN"):
         from .eam import nn_from_dict
-        nn = nn_from_dict(nn_cls, cfg)
+        npz = None
+        if meta.get("weights"):
+            npz = np.load(os.path.join(os.path.dirname(stem) or ".", meta["weights"]))
+        nn = nn_from_dict(nn_cls, cfg, npz)
         nn.attach_transformer(clf)
     else:
         raise ValueError(f"Unsupported model class: {nn_cls}")

@@ -224,8 +224,23 @@ def test_model_argument_checks():
         SymmetryFunction(["Ni"], cutoff_function="tanh")
     with pytest.raises(ValueError):
         EamAlloyNN(["Ni"], custom_potentials="sutton90")
-    with pytest.raises(ValueError):
-        EamAlloyNN(["Ni"])                                                # nn-EAM not implemented
+    d = EamAlloyNN(["Mo", "Ni"])                                          # default: all "nn" (alloy.py:110-112)
+    assert d.potentials == {"Mo": {"rho": "nn", "embed": "nn"}, "Ni": {"rho": "nn", "embed": "nn"},
+                            "MoMo": {"phi": "nn"}, "MoNi": {"phi": "nn"}, "NiNi": {"phi": "nn"}}
+    assert d.hidden_sizes["MoNi"] == {"phi": [64, 32]}                     # Defaults.hidden_sizes
+    assert d.nn_functions() == [("Mo", "rho"), ("Ni", "rho"), ("Mo", "embed"), ("Ni", "embed"),
+                                ("MoMo", "phi"), ("MoNi", "phi"), ("NiNi", "phi")]
+    d.attach_transformer(UniversalTransformer(["Mo", "Ni"], rcut=6.0))
+    with pytest.raises(ValueError, match="no weights"):
+        d.to_desc()
+    d.initialize()
+    desc, keep = d.to_desc()
+    assert desc.n_eam_nets == 7 and [desc.n_layers[k] for k in range(7)] == [3] * 7
+    assert [desc.layer_sizes[k] for k in range(4)] == [1, 64, 32, 1]
+    assert d.weights["Ni"]["rho"][-1][1] is None                          # no output bias (eam.py:184-190)
+    mixed = EamAlloyNN(["Ni"], custom_potentials={"Ni": {"rho": "zjw04"}, "NiNi": {"phi": "zjw04"}},
+                       hidden_sizes={"Ni": {"embed": [8]}})
+    assert mixed.nn_functions() == [None, ("Ni", "embed"), None] and mixed.hidden_sizes["Ni"]["embed"] == [8]
     with pytest.raises(ValueError, match="one Zjw04 variant"):
         EamAlloyNN(["Ni"], custom_potentials={"Ni": {"rho": "zjw04", "embed": "zjw04xc"},
                                               "NiNi": {"phi": "zjw04"}})

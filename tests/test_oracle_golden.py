@@ -182,6 +182,43 @@ def test_c_oracle_matches_numpy_oracle():
             assert np.abs(np.asarray(o[k]) - np.asarray(c[k])).max() < 1e-9
 
 
+def test_nn_eam_oracle_finite_differences():
+    """nn functions (eam.py:174-190): value/derivative pairs of the scalar networks and the
+    whole-structure forces / virial built on them, against central differences."""
+    from oracle.eam import nn_function
+    from tests.test_gpu_sf import _alloy
+    nn = make_eam(["Mo", "Ni"], 6.0, adp=True, potential=None, hidden_sizes=[16, 8])
+    x = np.linspace(0.5, 6.0, 23)
+    for sec, fns in nn.weights.items():
+        for fn, layers in fns.items():
+            assert layers[-1][1] is None and layers[0][0].shape == (1, 16)
+            f, df = nn_function(x, layers)
+            d = 1e-6
+            num = (nn_function(x + d, layers)[0] - nn_function(x - d, layers)[0]) / (2 * d)
+            assert np.abs(df - num).max() < 1e-8
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    o = oracle_eam_eval(nn, atoms)
+    d = 1e-5
+    for (i, k) in [(0, 0), (7, 1), (20, 2)]:
+        e = []
+        for sgn in (1, -1):
+            a2 = atoms.copy()
+            p = a2.positions.copy(); p[i, k] += sgn * d
+            a2.positions = p
+            e.append(oracle_eam_eval(nn, a2)["energy"])
+        assert abs(o["forces"][i, k] + (e[0] - e[1]) / (2 * d)) < 1e-6 * max(1.0, abs(o["energy"]) * 1e-3)
+    # virial = dE/d(strain)
+    eps = np.zeros((3, 3)); eps[0, 1] = eps[1, 0] = 1e-6
+    e = []
+    for sgn in (1, -1):
+        a2 = atoms.copy()
+        F = np.eye(3) + sgn * eps
+        a2.set_cell(np.asarray(atoms.get_cell()) @ F)
+        a2.positions = atoms.positions @ F
+        e.append(oracle_eam_eval(nn, a2)["energy"])
+    assert abs((e[0] - e[1]) / 2e-6 - (o["virial"][0, 1] + o["virial"][1, 0])) < 1e-5 * max(1.0, abs(o["energy"]) * 1e-3)
+
+
 def test_adp_oracle_finite_differences():
     from oracle.eam import EamModel, evaluate
     nn = make_eam(["Mo", "Ni"], 6.0, adp=True)
