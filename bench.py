@@ -220,8 +220,11 @@ def main():
                         "peak_Ginst_per_s": peak_issue / 1e9,
                         "frac": valu / (bwd_ms * 1e-3) / peak_issue,
                         "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
+        copy_gbs = eng.measure_hbm_copy(1 << 30, 10)  # achievable copy rate on this box, SURVEY 8(d)
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "peak_measured_copy": copy_gbs,
+                    "frac_of_measured_copy": achieved / copy_gbs if copy_gbs > 0 else None,
                     "traffic": traffic,
                     "algorithmic_bytes_per_launch": bwd_bytes,
                     "kernel_ms": bwd_ms,

@@ -212,6 +212,11 @@ int ta_synchronize(ta_handle h);
 int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
                     double *total_ms, double *kernel_ms /*[TA_N_KERNEL_SLOTS]*/);
 
+/* Measurement (bench.py, SURVEY 8(d) "achievable-copy figure"): device-to-device copy of `bytes`
+ * bytes by a grid-stride kernel (16 B per lane) on the handle's stream, `reps` timed repetitions
+ * after 2 untimed ones; *gbs = (bytes read + bytes written) / average time, in GB/s. */
+int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs);
+
 /* sum of the resident batch's frame energies, left on the device for a
  * collective: returns a device pointer to one double (valid until destroy). */
 int ta_batch_energy_device_ptr(ta_handle h, void **dptr);

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
-    "ta_energy_gradient",
+    "ta_energy_gradient", "ta_measure_hbm_copy",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -140,6 +140,7 @@ def load():
     lib.ta_synchronize.argtypes = [H]
     lib.ta_set_stream.argtypes = [H, C.c_void_p]
     lib.ta_time_compute.argtypes = [H, C.c_uint32, C.c_int32, C.c_int32, _dp, _dp]
+    lib.ta_measure_hbm_copy.argtypes = [H, C.c_int64, C.c_int32, _dp]
     lib.ta_batch_energy_device_ptr.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.ta_copy_batch_energy.argtypes = [H, C.c_void_p]
     lib.ta_set_batch_energy_target.argtypes = [H, C.c_void_p]

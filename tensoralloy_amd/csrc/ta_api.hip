@@ -1042,6 +1042,45 @@ int ta_batch_energy_device_ptr(ta_handle h, void **dptr) {
   return TA_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const double2 *__restrict__ src,
+                                                       double2 *__restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = src[k];
+}
+}  // namespace
+
+int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs) {
+  if (!h || !gbs || bytes < 16 || reps < 1) return fail(h, TA_ERR_INVALID, "bad argument");
+  return guarded(h, [&]() {
+    const size_t n = (size_t)bytes / 16;
+    double2 *src = nullptr, *dst = nullptr;
+    HIP_CHECK(hipMalloc((void **)&src, n * 16));
+    if (hipMalloc((void **)&dst, n * 16) != hipSuccess) {
+      (void)hipFree(src);
+      throw std::bad_alloc();
+    }
+    hipStream_t s = h->stream;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipMemsetAsync(src, 0, n * 16, s));
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    HIP_CHECK(hipEventRecord(e0, s));
+    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    *gbs = ms > 0.f ? 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+  });
+}
+
 int ta_set_stream(ta_handle h, void *stream) {
   if (!h) return TA_ERR_INVALID;
   return guarded(h, [&]() {

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -195,7 +196,7 @@ __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, dou
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
                                                           double *mom, double eps,
                                                           const double *__restrict__ pf, size_t ps,
-                                                          double *rho_buf) {
+                                                          double *rho_buf, int geom_done) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
@@ -213,7 +214,14 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
       double rec[5];
-      {
+      if (geom_done) {  // eam_geom_kernel has been here
+        const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)q);
+        const double2 a = src[0], c = src[1];
+        rec[0] = a.x;
+        rec[1] = a.y;
+        rec[2] = c.x;
+        rec[3] = c.y;
+      } else {
         const int j = b.pair_j[q];
         const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
         const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
@@ -303,10 +311,141 @@ __host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u
   return 2 * nel + (cls - 1) * (nel * (nel + 1) / 2) + pt;
 }
 
+// pair geometry for the nn path: D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474) into the
+// pair records, r into `rbuf`; one lane per pair
+__global__ __launch_bounds__(kBlock) void eam_geom_kernel(DeviceBatch b, double eps, double *rbuf) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= b.n_pairs) return;
+  const int i = b.pair_i[q], j = b.pair_j[q];
+  const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
+  const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
+               sz = (double)b.pair_shift[3 * (size_t)q + 2];
+  const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+  const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+  const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+  const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+  const double r2 = dx * dx + dy * dy + dz * dz + eps;
+  const double r = sqrt(r2);
+  double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
+  dst[0] = make_double2(dx, dy);
+  dst[1] = make_double2(dz, r2);
+  dst[2] = make_double2(1.0 / r, 0.0);
+  rbuf[q] = r;
+}
+
+// nn functions the launch evaluates: (class, element or pair type), one per blockIdx.y
+struct NnFnList {
+  int n;
+  int8_t cls[3 * kMaxPairTypes + kMaxEamElements];
+  int8_t k[3 * kMaxPairTypes + kMaxEamElements];
+};
+
+// Fast path for the usual shape 1 -> H1 -> H2 -> 1 (Defaults.hidden_sizes = [64, 32]): one
+// wavefront evaluates f and f' for 16 pairs without leaving its registers.
+//   layer 1 has K = 1: lane (m = l & 15, kq = l >> 4) forms h1 = act(w1[k] r_m + b1[k]) and
+//     h1' = act'(.) w1[k] for k = 4 kk + kq itself -- exactly the A operand of the next MFMA;
+//   layer 2: [h1; h1'] . W2 as v_mfma_f64_16x16x4_f64 (value and derivative share the B operand,
+//     read from the workgroup's LDS copy of W2; row stride = 16 mod 32 doubles: conflict-free);
+//   layer 3 has N = 1: h2 . w3 is a 16-lane DPP row sum of the accumulator columns.
+// The four wavefronts of a workgroup share one function's weights in LDS and stride over tiles.
+template <int ACT, int NT>
+__global__ __launch_bounds__(kBlock) void eam_nn_pair_fast_kernel(EamParams P, const MlpDev *__restrict__ nets,
+                                                                  int act_rt, NnFnList fl, DeviceBatch b,
+                                                                  const double *__restrict__ rbuf,
+                                                                  double *pf, size_t ps) {
+  extern __shared__ double lds[];
+  const int act = ACT >= 0 ? ACT : act_rt;
+  const int cls = fl.cls[blockIdx.y], k = fl.k[blockIdx.y];
+  const int nel = P.nel;
+  const MlpDev &net = nets[cls == 0 ? slot_rho(k) : slot_pair(nel, cls, k)];
+  const int H1 = net.layer[0].np, H2 = 16 * NT;
+  const int s2 = (H2 % 32 == 0) ? H2 + 16 : H2;
+  double *w1 = lds, *b1 = w1 + H1, *W2 = b1 + H1, *b2 = W2 + (size_t)H1 * s2, *w3 = b2 + H2;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < H1; idx += kBlock) {
+    w1[idx] = net.layer[0].w[idx];  // row 0 of [16][H1]
+    b1[idx] = net.layer[0].b[idx];
+  }
+  for (int idx = tid; idx < H1 * H2; idx += kBlock) {
+    const int row = idx / H2, col = idx - row * H2;
+    W2[row * s2 + col] = net.layer[1].w[idx];
+  }
+  for (int idx = tid; idx < H2; idx += kBlock) {
+    b2[idx] = net.layer[1].b[idx];
+    w3[idx] = net.layer[2].w[(size_t)idx * net.layer[2].np];  // column 0 of [H2][16]
+  }
+  const double b3 = net.layer[2].b[0];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+  const int64_t ntiles = (b.n_pairs + kMlpRows - 1) / kMlpRows;
+  double *val = pf + (size_t)(2 * cls) * ps, *der = pf + (size_t)(2 * cls + 1) * ps;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t p = t * kMlpRows + m;
+    const bool valid = p < b.n_pairs;
+    int match = 0;
+    double r = 0.0;
+    if (valid) {
+      const int sb = b.species[b.pair_j[p]];
+      const int key = cls == 0 ? sb : pair_type(b.species[b.pair_i[p]], sb, nel);
+      match = key == k;
+      r = rbuf[p];
+    }
+    if (!__any(match)) continue;
+    mlp_f64x4 accv[NT], accd[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const double bb = b2[16 * nt + m];
+      accv[nt] = {bb, bb, bb, bb};
+      accd[nt] = {0.0, 0.0, 0.0, 0.0};
+    }
+    for (int kk = 0; kk < H1 / 4; ++kk) {
+      const int ki = 4 * kk + kq;
+      const double wk = w1[ki];
+      double h, dh;
+      activation_fn(act, fma(wk, r, b1[ki]), h, dh);
+      dh *= wk;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const double B = W2[ki * s2 + 16 * nt + m];
+        accv[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, B, accv[nt], 0, 0, 0);
+        accd[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dh, B, accd[nt], 0, 0, 0);
+      }
+    }
+    // accv[nt][q] = z2[pair kq + 4 q][unit 16 nt + m]
+    double fv[4] = {0.0, 0.0, 0.0, 0.0}, fd[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const double wo = w3[16 * nt + m];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double h, dh;
+        activation_fn(act, accv[nt][q], h, dh);
+        fv[q] = fma(h, wo, fv[q]);
+        fd[q] = fma(dh * accd[nt][q], wo, fd[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fv[q] = row16_sum(fv[q]);
+      fd[q] = row16_sum(fd[q]);
+    }
+    // lane m = q (< 4) of row group kq stores pair kq + 4 q
+    const int q = m & 3, pr = kq + 4 * q;
+    const int ok = __shfl(match, pr, 64);
+    const double ov = q == 0 ? fv[0] : q == 1 ? fv[1] : q == 2 ? fv[2] : fv[3];
+    const double od = q == 0 ? fd[0] : q == 1 ? fd[1] : q == 2 ? fd[2] : fd[3];
+    if (m < 4 && ok) {
+      val[t * kMlpRows + pr] = ov + b3;
+      der[t * kMlpRows + pr] = od;
+    }
+  }
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void eam_nn_pair_kernel(EamParams P, const MlpDev *__restrict__ nets,
-                                                              int act, DeviceBatch b, double *pf, size_t ps,
-                                                              double eps, int stride) {
+                                                              int act, DeviceBatch b,
+                                                              const double *__restrict__ rbuf, double *pf,
+                                                              size_t ps, int stride) {
   extern __shared__ double lds[];
   double *buf0 = lds, *buf1 = lds + kMlpRows * stride, *da = lds + 2 * kMlpRows * stride;
   __shared__ double xr[kMlpRows];
@@ -319,19 +458,10 @@ __global__ __launch_bounds__(THREADS) void eam_nn_pair_kernel(EamParams P, const
     double r = 0.0;
     int sb = -1, pt = -1;
     if (tid < nrows) {
-      // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474)
       const int64_t q = p0 + tid;
-      const int i = b.pair_i[q], j = b.pair_j[q];
-      const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
-      const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
-                   sz = (double)b.pair_shift[3 * (size_t)q + 2];
-      const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
-      const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
-      const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
-      const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
-      r = sqrt(dx * dx + dy * dy + dz * dz + eps);
-      sb = b.species[j];
-      pt = pair_type(b.species[i], sb, nel);
+      r = rbuf[q];
+      sb = b.species[b.pair_j[q]];
+      pt = pair_type(b.species[b.pair_i[q]], sb, nel);
     }
     xr[tid] = r;
     key_sb[tid] = sb;
@@ -522,8 +652,11 @@ struct EamModel {
   std::vector<double *> owned;    // device allocations of the weights
   int stride = 0, max_layers = 0; // LDS row stride / deepest network
   bool pair_nets = false, embed_nets = false;
-  double *pf = nullptr;           // [8 or 4][cap_pairs] value / derivative columns
+  double *pf = nullptr;           // [8 or 4][cap_pairs] value / derivative columns, then r [cap_pairs]
   size_t cap_pairs = 0;
+  int fast_nt = 0;                // > 0: every pair function is 1 -> H1 -> 16 fast_nt -> 1 (fast kernel)
+  size_t fast_lds = 0;
+  NnFnList fns;                   // the pair functions that are nn functions
   double *rho_buf = nullptr;      // [cap_atoms]
 };
 
@@ -648,6 +781,33 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     }
     e->pair_nets = e->p.nn_rho || e->p.nn_phi || e->p.nn_u || e->p.nn_w;
     e->embed_nets = e->p.nn_embed != 0;
+    // list of the pair functions; the fast kernel applies when all of them are 1 -> H1 -> H2 -> 1
+    // with the same padded H2 <= 64 and the LDS image of one function stays below 64 KB
+    std::memset(&e->fns, 0, sizeof(e->fns));
+    bool fast = true;
+    int h2 = 0;
+    size_t lds = 0;
+    auto add = [&](int cls, int k) {
+      const MlpDev &n = e->nets[cls == 0 ? slot_rho(k) : slot_pair(nel, cls, k)];
+      if (!n.n_layers) return;
+      e->fns.cls[e->fns.n] = (int8_t)cls;
+      e->fns.k[e->fns.n] = (int8_t)k;
+      ++e->fns.n;
+      if (n.n_layers != 3 || n.layer[1].res || n.layer[1].np > 64 || (h2 && n.layer[1].np != h2)) {
+        fast = false;
+        return;
+      }
+      h2 = n.layer[1].np;
+      const int H1 = n.layer[0].np, s2 = (h2 % 32 == 0) ? h2 + 16 : h2;
+      lds = std::max(lds, (size_t)(2 * H1 + (size_t)H1 * s2 + 2 * h2 + 2) * sizeof(double));
+    };
+    for (int k = 0; k < nel; ++k) add(0, k);
+    for (int cls = 1; cls < (adp ? 4 : 2); ++cls)
+      for (int k = 0; k < npair; ++k) add(cls, k);
+    if (fast && e->fns.n && lds <= 64 * 1024 && !getenv("TA_EAM_NN_GENERIC")) {
+      e->fast_nt = h2 / 16;
+      e->fast_lds = lds;
+    }
   }
   for (int k = 0; k < nel; ++k) {
     for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 21 + c];
@@ -709,7 +869,7 @@ void eam_ensure(EamModel *m, const DeviceBatch &b) {
     m->pf = nullptr;
     m->cap_pairs = 0;
     const size_t cap = np + np / 8 + 64;
-    if (hipMalloc((void **)&m->pf, cap * (m->p.adp ? 8 : 4) * sizeof(double)) != hipSuccess)
+    if (hipMalloc((void **)&m->pf, cap * ((m->p.adp ? 8 : 4) + 1) * sizeof(double)) != hipSuccess)
       throw std::bad_alloc();
     m->cap_pairs = cap;
   }
@@ -751,13 +911,41 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   sf.n_elements = m->p.nel;
   sf.eps = m->eps;
   const size_t ps = m->cap_pairs;
-  if (m->pair_nets && b.n_pairs > 0)
-    hipLaunchKernelGGL(eam_nn_pair_kernel<kNetThreads>,
-                       dim3((unsigned)((b.n_pairs + kMlpRows - 1) / kMlpRows)), dim3(kNetThreads),
-                       net_lds_bytes(m), s, m->p, m->nets_dev, m->activation, b, m->pf, ps, m->eps,
-                       m->stride);
+  const bool pair_nets = m->pair_nets && b.n_pairs > 0;
+  if (pair_nets) {
+    double *rbuf = m->pf + (size_t)(m->p.adp ? 8 : 4) * ps;
+    hipLaunchKernelGGL(eam_geom_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       s, b, m->eps, rbuf);
+    const unsigned tiles = (unsigned)((b.n_pairs + kMlpRows - 1) / kMlpRows);
+    if (m->fast_nt) {
+      // workgroups of 4 wavefronts stride over the tiles; enough of them to fill the chip a few
+      // times over, few enough that the LDS image of the weights is amortised
+      const dim3 grid(std::min((tiles + 3) / 4, 2048u), (unsigned)m->fns.n);
+#define TA_NN_FAST(ACT, NT)                                                                              \
+  hipLaunchKernelGGL((eam_nn_pair_fast_kernel<ACT, NT>), grid, dim3(kBlock), m->fast_lds, s, m->p,        \
+                     m->nets_dev, m->activation, m->fns, b, rbuf, m->pf, ps)
+#define TA_NN_FAST_NT(ACT)                                                                               \
+  switch (m->fast_nt) {                                                                                  \
+    case 1: TA_NN_FAST(ACT, 1); break;                                                                   \
+    case 2: TA_NN_FAST(ACT, 2); break;                                                                   \
+    case 3: TA_NN_FAST(ACT, 3); break;                                                                   \
+    default: TA_NN_FAST(ACT, 4); break;                                                                  \
+  }
+      if (m->activation == TA_ACT_SOFTPLUS) {
+        TA_NN_FAST_NT(TA_ACT_SOFTPLUS)
+      } else {
+        TA_NN_FAST_NT(-1)
+      }
+#undef TA_NN_FAST_NT
+#undef TA_NN_FAST
+    } else {
+      hipLaunchKernelGGL(eam_nn_pair_kernel<kNetThreads>, dim3(tiles), dim3(kNetThreads), net_lds_bytes(m), s,
+                         m->p, m->nets_dev, m->activation, b, rbuf, m->pf, ps, m->stride);
+    }
+  }
   hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf, ps, m->rho_buf);
+                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf, ps, m->rho_buf,
+                     pair_nets ? 1 : 0);
   if (m->embed_nets) {
     EmbedTiles t;
     std::memset(&t, 0, sizeof(t));

@@ -146,15 +146,69 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// 1 / d for d in [1, 3]: hardware seed + two Newton steps (no scaling / fix-up needed in that range)
+__device__ __forceinline__ double rcp_1_3(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  e = fma(-d, x, 1.0);
+  return fma(x, e, x);
+}
+
+// softplus(x) = max(x, 0) + log1p(e) and its derivative 1 / (1 + exp(-x)), e = exp(-|x|), to 2-3 ulp
+// in about a quarter of the instructions of libm's exp + log1p + two IEEE divisions (the per-pair
+// nn functions of nn-EAM spend nearly all their time here):
+//   e: |x| = n ln2 + r, |r| <= ln2 / 2, degree-13 Taylor of exp(-r), ldexp;
+//   log1p(e) = [ln2 +] 2 atanh(s), s = f / (2 + f) with f = e, or (e - 1) / 2 when e > sqrt2 - 1
+//   (|s| <= 0.172: ten odd terms); both quotients by rcp_1_3.
+__device__ __forceinline__ void softplus_fn(double x, double &h, double &dh) {
+  const double a = fmin(fabs(x), 708.0);
+  const double n = __builtin_rint(a * 1.4426950408889634);
+  double y = fma(n, -6.93147180369123816490e-01, a);
+  y = -fma(n, -1.90821492927058770002e-10, y);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, y, 1.0 / 479001600.0);
+  p = fma(p, y, 1.0 / 39916800.0);
+  p = fma(p, y, 1.0 / 3628800.0);
+  p = fma(p, y, 1.0 / 362880.0);
+  p = fma(p, y, 1.0 / 40320.0);
+  p = fma(p, y, 1.0 / 5040.0);
+  p = fma(p, y, 1.0 / 720.0);
+  p = fma(p, y, 1.0 / 120.0);
+  p = fma(p, y, 1.0 / 24.0);
+  p = fma(p, y, 1.0 / 6.0);
+  p = fma(p, y, 0.5);
+  p = fma(p, y, 1.0);
+  p = fma(p, y, 1.0);
+  const double e = __builtin_amdgcn_ldexp(p, -(int)n);
+  const double inv = rcp_1_3(1.0 + e);
+  dh = (x >= 0.0) ? inv : e * inv;
+  const bool big = e > 0.41421356237309503;
+  const double f = big ? 0.5 * (e - 1.0) : e;
+  const double s = f * rcp_1_3(2.0 + f);
+  const double z = s * s;
+  double q = 1.0 / 21.0;
+  q = fma(q, z, 1.0 / 19.0);
+  q = fma(q, z, 1.0 / 17.0);
+  q = fma(q, z, 1.0 / 15.0);
+  q = fma(q, z, 1.0 / 13.0);
+  q = fma(q, z, 1.0 / 11.0);
+  q = fma(q, z, 1.0 / 9.0);
+  q = fma(q, z, 1.0 / 7.0);
+  q = fma(q, z, 1.0 / 5.0);
+  q = fma(q, z, 1.0 / 3.0);
+  q *= z;
+  double l = fma(2.0 * s, q, 2.0 * s);
+  if (big) l += 0.69314718055994531;
+  h = fmax(x, 0.0) + l;
+}
+
 // activation value and derivative (reference nn/utils.py:39-74)
 __device__ __forceinline__ void activation_fn(int act, double x, double &h, double &dh) {
   switch (act) {
-    case TA_ACT_SOFTPLUS: {
-      double e = exp(-fabs(x));
-      h = fmax(x, 0.0) + log1p(e);
-      dh = (x >= 0.0) ? 1.0 / (1.0 + e) : e / (1.0 + e);
+    case TA_ACT_SOFTPLUS:
+      softplus_fn(x, h, dh);
       break;
-    }
     case TA_ACT_RELU:
       h = fmax(x, 0.0);
       dh = x > 0.0 ? 1.0 : 0.0;

@@ -149,6 +149,12 @@ class Engine:
             _lib.as_dp(slots) if per_kernel else C.POINTER(C.c_double)()))
         return total.value, dict(zip(_lib.KERNEL_SLOTS, slots.tolist()))
 
+    def measure_hbm_copy(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
+        """Achievable device-to-device copy rate in GB/s (read + written bytes)."""
+        g = C.c_double(0.0)
+        self._check(self._lib.ta_measure_hbm_copy(self._handle, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
     def batch_energy_device_ptr(self) -> int:
         p = C.c_void_p()
         self._check(self._lib.ta_batch_energy_device_ptr(self._handle, C.byref(p)))

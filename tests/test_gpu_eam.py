@@ -45,9 +45,13 @@ def test_adp_binary(lib):
     _compare(make_eam(["Mo", "Ni"], 6.0, adp=True), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
 
 
-def test_nn_eam_default_potentials(lib):
+@pytest.mark.parametrize("generic", [False, True])
+def test_nn_eam_default_potentials(lib, monkeypatch, generic):
     """The reference's default `EamAlloyNN(elements)`: rho, phi and embed are all "nn" functions
-    with `Defaults.hidden_sizes` = [64, 32] (alloy.py:110-112, eam.py:174-190)."""
+    with `Defaults.hidden_sizes` = [64, 32] (alloy.py:110-112, eam.py:174-190). Both device paths:
+    the one-wavefront kernel for 1 -> H1 -> H2 -> 1 and the generic 16-row MLP tile."""
+    if generic:
+        monkeypatch.setenv("TA_EAM_NN_GENERIC", "1")
     nn = make_eam(["Ni"], 6.0, potential=None)
     assert nn.potentials == {"Ni": {"rho": "nn", "embed": "nn"}, "NiNi": {"phi": "nn"}}
     assert nn.hidden_sizes["Ni"]["rho"] == [64, 32]
@@ -105,6 +109,26 @@ def test_nn_eam_model_file_and_tables(lib, tmp_path):
     back = read_setfl(path)
     assert np.abs(back["rho"]["Mo"] - nn_function(r, nn.weights["Mo"]["rho"])[0]).max() < 1e-12
     assert np.abs(back["rphi"]["MoNi"] - r * nn_function(r, nn.weights["MoNi"]["phi"])[0]).max() < 1e-11
+
+
+def test_device_softplus_accuracy(lib):
+    """The device softplus (own exp / log1p / reciprocals, ta_math.h) against NumPy in extended
+    precision, through the table of an nn function whose only live unit is softplus(x)."""
+    from tensoralloy_amd import Engine
+    nn = make_eam(["Ni"], 6.0, potential=None, hidden_sizes=[4])
+    w1 = np.zeros((1, 4)); w1[0, 0] = 1.0; w1[0, 1] = -1.0
+    for sec, fn in (("Ni", "rho"), ("Ni", "embed"), ("NiNi", "phi")):
+        nn.weights[sec][fn] = [(w1, np.zeros(4)), (np.array([[1.0], [0.0], [0.0], [0.0]]), None)]
+    nn.weights["Ni"]["embed"][1] = (np.array([[0.0], [1.0], [0.0], [0.0]]), None)   # softplus(-x)
+    x = np.concatenate([np.linspace(0.0, 45.0, 4001), np.geomspace(1e-12, 700.0, 3000)])
+    with Engine(nn) as eng:
+        tab = eng.eam_tabulate(x, x)
+    xl = x.astype(np.longdouble)
+    ref_pos = (xl + np.log1p(np.exp(-xl))).astype(np.float64)
+    ref_neg = np.log1p(np.exp(-xl)).astype(np.float64)
+    assert np.abs(tab["rho"][0] / ref_pos - 1.0).max() < 2e-15
+    ok = ref_neg > 1e-300
+    assert np.abs(tab["embed"][0][ok] / ref_neg[ok] - 1.0).max() < 2e-15
 
 
 def test_zjw04xc_blended_embedding(lib):
