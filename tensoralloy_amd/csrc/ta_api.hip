@@ -186,8 +186,8 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Power series in u of Hd(u) = exp(-beta u) * 0.5 (1 + cos(pi sqrt(u))) on [0, 1]
 // (cosine cutoff nn/cutoff.py:43-48 times the Gaussian of sf.py:166-168 for the
-// third side of a triple), in long double. Picks 16 or 24 coefficients when
-// the truncated tail is below 1e-17, otherwise leaves n_hd = 0 (exact path).
+// third side of a triple), in long double, economised to 12, 16 or 24 coefficients when
+// the error bound is below 1e-17 (1e-15 for the derivative), otherwise n_hd = 0 (exact path).
 void hd_series(int cutoff, double beta, ta::AngChunk &ch) {
   ch.n_hd = 0;
   for (double &c : ch.hd) c = 0.0;
@@ -210,15 +210,44 @@ void hd_series(int cutoff, double beta, ta::AngChunk &ch) {
     for (int j = 0; j <= k; ++j) acc += fc[j] * ex[k - j];
     prod[k] = acc;
   }
-  for (int n : {16, 24}) {
-    long double tail = 0.0L;
-    for (int k = n; k < NT; ++k) tail += fabsl(prod[k]);
-    // the derivative series loses one more order: bound k |c_k| as well
-    long double dtail = 0.0L;
-    for (int k = n; k < NT; ++k) dtail += (long double)k * fabsl(prod[k]);
-    if (tail < 1e-17L && dtail < 1e-15L) {
+  // Chebyshev economisation: starting from the degree-(N0 - 1) Taylor polynomial, the leading term
+  // a_n u^n is replaced by a_n (u^n - T*_n(u) / L_n), T*_n(u) = T_n(2u - 1) with leading coefficient
+  // L_n = 2^(2n-1); that changes the polynomial by at most |a_n| / L_n on [0, 1] and its derivative
+  // by at most 2 n^2 |a_n| / L_n, and lowers the degree by one. Repeated down to n coefficients, this
+  // reaches the fp64 rounding floor with 12 coefficients for the default beta where the plain
+  // series needs 16 (4 / 8 fewer FMAs per triple in the forward / backward kernels).
+  constexpr int N0 = 40;
+  static long double tstar[N0][N0];  // tstar[n][k]: coefficient of u^k in T*_n
+  static bool have_t = false;
+  if (!have_t) {
+    for (auto &row : tstar)
+      for (auto &c : row) c = 0.0L;
+    tstar[0][0] = 1.0L;
+    tstar[1][0] = -1.0L;
+    tstar[1][1] = 2.0L;
+    for (int n = 1; n + 1 < N0; ++n)
+      for (int k = 0; k <= n + 1; ++k)
+        tstar[n + 1][k] = (k > 0 ? 4.0L * tstar[n][k - 1] : 0.0L) - 2.0L * tstar[n][k] - tstar[n - 1][k];
+    have_t = true;
+  }
+  long double tail0 = 0.0L, dtail0 = 0.0L;
+  for (int k = N0; k < NT; ++k) {
+    tail0 += fabsl(prod[k]);
+    dtail0 += (long double)k * fabsl(prod[k]);
+  }
+  for (int n : {12, 16, 24}) {
+    long double a[N0];
+    for (int k = 0; k < N0; ++k) a[k] = prod[k];
+    long double err = tail0, derr = dtail0;
+    for (int d = N0 - 1; d >= n; --d) {
+      const long double q = a[d] / tstar[d][d];
+      for (int k = 0; k <= d; ++k) a[k] -= q * tstar[d][k];
+      err += fabsl(q);
+      derr += 2.0L * (long double)d * (long double)d * fabsl(q);
+    }
+    if (err < 1e-17L && derr < 1e-15L) {
       ch.n_hd = n;
-      for (int k = 0; k < n; ++k) ch.hd[k] = (double)prod[k];
+      for (int k = 0; k < n; ++k) ch.hd[k] = (double)a[k];
       return;
     }
   }

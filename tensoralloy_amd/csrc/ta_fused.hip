@@ -503,12 +503,12 @@ static void fused_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = (size_t)pl.total * sizeof(double);
   if constexpr (NZ == 2) {
-    if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+    if (ch.n_hd > 0 && ch.n_hd <= 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((sf_fused_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, pl, mlps, act, want_forces, scratch);
       return;
     }
   }
-  if (ch.n_hd == 16)
+  if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
     hipLaunchKernelGGL((sf_fused_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, pl, mlps, act, want_forces, scratch);
   else if (ch.n_hd == 24)
     hipLaunchKernelGGL((sf_fused_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, pl, mlps, act, want_forces, scratch);

@@ -676,12 +676,16 @@ void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geo
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = v2_lds_bytes(false, b.cap);
   if constexpr (NZ == 2) {
+    if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true>), grid, block, lds, s, sf, ch, b, geom);
+      return;
+    }
     if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
   }
-  if (ch.n_hd == 16)
+  if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
     hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, geom);
   else if (ch.n_hd == 24)
     hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, geom);
@@ -693,12 +697,16 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
   const size_t lds = v2_lds_bytes(true, b.cap);
   if constexpr (NZ == 2) {
+    if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+      hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true>), grid, block, lds, s, sf, ch, b, first);
+      return;
+    }
     if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, first);
       return;
     }
   }
-  if (ch.n_hd == 16)
+  if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
     hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, first);
   else if (ch.n_hd == 24)
     hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, first);

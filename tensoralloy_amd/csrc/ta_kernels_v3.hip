@@ -553,12 +553,12 @@ void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geo
   const dim3 grid((unsigned)b.n_blk), block((unsigned)threads);
   const size_t lds = common_bytes(b.cap, threads / 64) + (size_t)NSPEC * NG * NZ * b.cap * 8;
   if constexpr (NZ == 2) {
-    if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+    if (ch.n_hd > 0 && ch.n_hd <= 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((g4_forward_v3_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
   }
-  if (ch.n_hd == 16)
+  if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
     hipLaunchKernelGGL((g4_forward_v3_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, geom);
   else if (ch.n_hd == 24)
     hipLaunchKernelGGL((g4_forward_v3_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, geom);
@@ -572,12 +572,12 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
   const size_t lds = common_bytes(b.cap, threads / 64) +
                      (3 * (size_t)b.cap + 2 * (size_t)kMaxCentersPerBlock * NSPEC * NSPEC * NG * NZ) * 8;
   if constexpr (NZ == 2) {
-    if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
+    if (ch.n_hd > 0 && ch.n_hd <= 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((backward_v3_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, first);
       return;
     }
   }
-  if (ch.n_hd == 16)
+  if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
     hipLaunchKernelGGL((backward_v3_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, first);
   else if (ch.n_hd == 24)
     hipLaunchKernelGGL((backward_v3_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, first);
