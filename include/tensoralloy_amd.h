@@ -122,6 +122,18 @@ typedef struct {
    * [slot] (0 = analytic function, read from `eam_params`), `layer_sizes` ([1, h1, ..., 1] per
    * nn slot) and `weights` (as above, per nn slot) describe them, `activation` applies to all. */
   int32_t n_eam_nets;
+
+  /* EAM / ADP tabulated functions: a LAMMPS setfl / adp file's rho(r), F(rho), phi(r), u(r), w(r)
+   * (io/lammps.py:62-235), evaluated as natural cubic splines the way the reference's
+   * `CubicInterpolator(x, y, natural_boundary=True)` does (potentials/tests/test_mishin.py:60-70;
+   * `spline@...` potentials, train/training.py:258-262). Same slots as the nn functions
+   * (`n_eam_nets` must be set): `eam_table_n[slot]` = number of knots (0 = not tabulated; knots at
+   * k * eam_table_dx[slot]), `eam_table_coef` = per tabulated slot (n - 1) x 4 doubles, the cubic
+   * c0 + c1 t + c2 t^2 + c3 t^3 of every interval with t = x - x_k. Arguments beyond the last knot
+   * use the last interval's cubic. All three NULL = no tables. */
+  const int32_t *eam_table_n;
+  const double *eam_table_dx;
+  const double *eam_table_coef;
 } ta_model_desc;
 
 /* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`

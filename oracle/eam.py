@@ -189,6 +189,17 @@ def nn_function(x, layers, act="softplus", resnet=False):
     return h[:, 0], dh[:, 0]
 
 
+def spline_function(x, table):
+    """Tabulated function (knots, values) as the natural cubic spline the reference builds with
+    `CubicInterpolator(x, y, natural_boundary=True)` (potentials/tests/test_mishin.py:60-70), here
+    by SciPy; beyond the last knot the last cubic continues. Returns f(x), f'(x)."""
+    from scipy.interpolate import CubicSpline
+    cs = CubicSpline(np.asarray(table[0], dtype=np.float64), np.asarray(table[1], dtype=np.float64),
+                     bc_type="natural", extrapolate=True)
+    x = np.asarray(x, dtype=np.float64)
+    return cs(x), cs(x, 1)
+
+
 # ---- model ----------------------------------------------------------------------
 
 class EamModel:
@@ -196,7 +207,7 @@ class EamModel:
     keyed by the sorted pair 'AB' (dict with d1..q3, h, rc)."""
 
     def __init__(self, elements, rcut, params=None, adp=None, blended_embed=False, phi_pairs=None,
-                 nets=None, activation="softplus"):
+                 nets=None, activation="softplus", tables=None):
         self.elements = sorted(set(elements))
         self.rcut = float(rcut)
         # "nn" functions: {'rho': {el: layers}, 'embed': {el: layers}, 'phi': {'AB': layers},
@@ -204,6 +215,8 @@ class EamModel:
         # the analytic one
         self.nets = nets or {}
         self.activation = activation
+        # tabulated functions, same nesting: {'rho': {el: (x, y)}, 'phi': {'AB': (x, y)}, ...}
+        self.tables = tables or {}
         self.params = params if params is not None else {
             e: dict(ZJW04[e]) for e in self.elements if e in ZJW04}
         self.adp = adp  # {'NiNi': {...}} or None
@@ -230,14 +243,18 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
     dphi_pair = np.zeros(len(pi))
     for b, eb in enumerate(els):
         m = sj == b
-        if eb in model.nets.get("rho", {}):
+        if eb in model.tables.get("rho", {}):
+            rho_pair[m], drho_pair[m] = spline_function(r[m], model.tables["rho"][eb])
+        elif eb in model.nets.get("rho", {}):
             rho_pair[m], drho_pair[m] = nn_function(r[m], model.nets["rho"][eb], model.activation)
         else:
             rho_pair[m], drho_pair[m] = zjw04_rho(r[m], model.params[eb])  # neighbour's element, alloy.py:176
         for a, ea in enumerate(els):
             mm = m & (si == a)
             key = "".join(sorted([ea, eb]))
-            if key in model.nets.get("phi", {}):
+            if key in model.tables.get("phi", {}):
+                phi_pair[mm], dphi_pair[mm] = spline_function(r[mm], model.tables["phi"][key])
+            elif key in model.nets.get("phi", {}):
                 phi_pair[mm], dphi_pair[mm] = nn_function(r[mm], model.nets["phi"][key], model.activation)
             elif a != b and key in model.phi_pairs:
                 phi_pair[mm], dphi_pair[mm] = zjw04xcp_phi_ab(r[mm], model.phi_pairs[key])
@@ -251,6 +268,9 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
     dF = np.zeros(N)
     for a, ea in enumerate(els):
         m = spec == a
+        if ea in model.tables.get("embed", {}):
+            F[m], dF[m] = spline_function(rho[m], model.tables["embed"][ea])
+            continue
         if ea in model.nets.get("embed", {}):
             F[m], dF[m] = nn_function(rho[m], model.nets["embed"][ea], model.activation)
             continue
@@ -274,11 +294,15 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
                 key = "".join(sorted([ea, eb]))
                 m = (si == a) & (sj == b)
                 p = model.adp.get(key)
-                if key in model.nets.get("dipole", {}):
+                if key in model.tables.get("dipole", {}):
+                    u[m], du[m] = spline_function(r[m], model.tables["dipole"][key])
+                elif key in model.nets.get("dipole", {}):
                     u[m], du[m] = nn_function(r[m], model.nets["dipole"][key], model.activation)
                 elif p is not None:
                     u[m], du[m] = mishin_polar(r[m], p["d1"], p["d2"], p["d3"], p["rc"], p["h"])
-                if key in model.nets.get("quadrupole", {}):
+                if key in model.tables.get("quadrupole", {}):
+                    w[m], dw[m] = spline_function(r[m], model.tables["quadrupole"][key])
+                elif key in model.nets.get("quadrupole", {}):
                     w[m], dw[m] = nn_function(r[m], model.nets["quadrupole"][key], model.activation)
                 elif p is not None:
                     w[m], dw[m] = mishin_polar(r[m], p["q1"], p["q2"], p["q3"], p["rc"], p["h"])

@@ -62,6 +62,7 @@ class ModelDesc(C.Structure):
         ("eps", C.c_double),
         ("n_grap_params", C.c_int32), ("grap_params", _dp),
         ("n_eam_nets", C.c_int32),
+        ("eam_table_n", _ip), ("eam_table_dx", _dp), ("eam_table_coef", _dp),
     ]
 
 

@@ -67,7 +67,28 @@ struct EamParams {
   double pair[kMaxPairTypes][8];    // d1 d2 d3 q1 q2 q3 h rc
   // bit k set: the function of element / pair type k is an nn function
   uint32_t nn_rho, nn_embed, nn_phi, nn_u, nn_w;
+  // bit k set: tabulated function (natural cubic spline of a setfl / adp table)
+  uint32_t tab_rho, tab_embed, tab_phi, tab_u, tab_w;
 };
+
+// one tabulated function: knots at k dx, (n - 1) cubics {c0, c1, c2, c3} in t = x - x_k
+struct TabDev {
+  int n;
+  double dx, inv_dx;
+  const double *c;
+};
+
+// natural cubic spline the way the reference's CubicInterpolator evaluates a setfl table
+// (potentials/tests/test_mishin.py:60-70); beyond the last knot the last cubic continues
+__device__ __forceinline__ void spline_eval(const TabDev &t, double x, double &f, double &df) {
+  int k = (int)(x * t.inv_dx);
+  k = k < 0 ? 0 : (k > t.n - 2 ? t.n - 2 : k);
+  const double tt = x - (double)k * t.dx;
+  const double2 *c = reinterpret_cast<const double2 *>(t.c + 4 * (size_t)k);
+  const double2 a = c[0], b = c[1];
+  f = fma(fma(fma(b.y, tt, b.x), tt, a.y), tt, a.x);
+  df = fma(fma(3.0 * b.y, tt, 2.0 * b.x), tt, a.y);
+}
 
 // columns of the per-pair function buffer `pf` (each `ps` doubles long)
 enum { PF_RHO = 0, PF_DRHO, PF_PHI, PF_DPHI, PF_U, PF_DU, PF_W, PF_DW };
@@ -77,6 +98,14 @@ enum { R_EQ, F_EQ, RHO_E, RHO_S, ALPHA, BETA, PA, PB, KAPPA, LAMDA, FN0, FN1, FN
 __device__ __forceinline__ int pair_type(int s1, int s2, int nel) {
   int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
   return a * nel - (a * (a - 1)) / 2 + (b - a);
+}
+
+// slot order of the function networks / tables: rho[element], embed[element], phi[pair type],
+// dipole[pair type], quadrupole[pair type]
+__host__ __device__ __forceinline__ int slot_rho(int e) { return e; }
+__host__ __device__ __forceinline__ int slot_embed(int nel, int e) { return nel + e; }
+__host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u, 3 w */, int pt) {
+  return 2 * nel + (cls - 1) * (nel * (nel + 1) / 2) + pt;
 }
 
 // f(r) = a exp(-b (r/re - 1)) / (1 + (r/re - c)^20)   (generic.py:102-117)
@@ -196,7 +225,8 @@ __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, dou
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
                                                           double *mom, double eps,
                                                           const double *__restrict__ pf, size_t ps,
-                                                          double *rho_buf, int geom_done) {
+                                                          double *rho_buf, int geom_done,
+                                                          const TabDev *__restrict__ tabs) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
@@ -210,6 +240,8 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     const double *pp = P.pair[pt];
     const bool rho_nn = (P.nn_rho >> sb) & 1u, phi_nn = (P.nn_phi >> pt) & 1u;
     const bool u_nn = (P.nn_u >> pt) & 1u, w_nn = (P.nn_w >> pt) & 1u;
+    const bool rho_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
+    const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
     for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
@@ -241,17 +273,21 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       double f, df;
       // density function of the NEIGHBOUR's element (alloy.py:176)
       if (rho_nn) f = pf[PF_RHO * ps + q];
+      else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
       else zjw_rho(P.el[sb], r, f, df);
       rho += f;
       if (phi_nn) f = pf[PF_PHI * ps + q];
+      else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, df);
       else zjw_phi(P, sA, sb, r, f, df);
       phis += f;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
         double u, du, w, dw;
         if (u_nn) u = pf[PF_U * ps + q];
+        else if (u_tab) spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
         else mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
         if (w_nn) w = pf[PF_W * ps + q];
+        else if (w_tab) spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
         else mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
         m[0] = fma(u, dx, m[0]);
         m[1] = fma(u, dy, m[1]);
@@ -295,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       b.eatom[i] = 0.5 * phis + eadp;
     } else {
       double F, d;
-      zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
+      if ((P.tab_embed >> sA) & 1u) spline_eval(tabs[slot_embed(nel, sA)], rho, F, d);
+      else zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
       b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
       dF[i] = d;
     }
@@ -303,14 +340,6 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
 }
 
 // ---- nn functions ------------------------------------------------------------------------
-// slot order of the function networks: rho[element], embed[element], phi[pair type],
-// dipole[pair type], quadrupole[pair type]
-__host__ __device__ __forceinline__ int slot_rho(int e) { return e; }
-__host__ __device__ __forceinline__ int slot_embed(int nel, int e) { return nel + e; }
-__host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u, 3 w */, int pt) {
-  return 2 * nel + (cls - 1) * (nel * (nel + 1) / 2) + pt;
-}
-
 // pair geometry for the nn path: D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474) into the
 // pair records, r into `rbuf`; one lane per pair
 __global__ __launch_bounds__(kBlock) void eam_geom_kernel(DeviceBatch b, double eps, double *rbuf) {
@@ -521,7 +550,8 @@ __global__ __launch_bounds__(THREADS) void eam_nn_embed_kernel(const MlpDev *__r
 
 __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBatch b,
                                                           const double *dF, const double *mom,
-                                                          const double *__restrict__ pf, size_t ps) {
+                                                          const double *__restrict__ pf, size_t ps,
+                                                          const TabDev *__restrict__ tabs) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= b.n_pairs) return;
   const int nel = P.nel;
@@ -533,8 +563,10 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   double f, drho, dphi;
   const int pt = pair_type(sA, sa, nel);
   if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
+  else if ((P.tab_rho >> sa) & 1u) spline_eval(tabs[slot_rho(sa)], r, f, drho);
   else zjw_rho(P.el[sa], r, f, drho);
   if ((P.nn_phi >> pt) & 1u) dphi = pf[PF_DPHI * ps + p];
+  else if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, dphi);
   else zjw_phi(P, sA, sa, r, f, dphi);
   // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
   double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
@@ -546,12 +578,16 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
     if ((P.nn_u >> pt) & 1u) {
       u = pf[PF_U * ps + p];
       du = pf[PF_DU * ps + p];
+    } else if ((P.tab_u >> pt) & 1u) {
+      spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
     } else {
       mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
     }
     if ((P.nn_w >> pt) & 1u) {
       w = pf[PF_W * ps + p];
       dw = pf[PF_DW * ps + p];
+    } else if ((P.tab_w >> pt) & 1u) {
+      spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
     } else {
       mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
     }
@@ -577,7 +613,8 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
                                                               int n_rho, const double *rho,
                                                               double *rho_of_r, double *phi_of_r,
                                                               double *embed_of_rho, double *u_of_r,
-                                                              double *w_of_r) {
+                                                              double *w_of_r,
+                                                              const TabDev *__restrict__ tabs) {
   const int nel = P.nel, npair = nel * (nel + 1) / 2;
   const int64_t n_rows_r = nel + npair;  // rho rows, then pair rows
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -587,7 +624,8 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     const double x = r[k];
     double f, df;
     if (row < nel) {
-      zjw_rho(P.el[row], x, f, df);
+      if ((P.tab_rho >> row) & 1u) spline_eval(tabs[slot_rho(row)], x, f, df);
+      else zjw_rho(P.el[row], x, f, df);
       rho_of_r[(size_t)row * n_r + k] = f;
     } else {
       const int pt = row - nel;
@@ -597,13 +635,16 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
         ++a;
       }
       const int b2 = a + rem;
-      zjw_phi(P, a, b2, x, f, df);
+      if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], x, f, df);
+      else zjw_phi(P, a, b2, x, f, df);
       phi_of_r[(size_t)pt * n_r + k] = f;
       if (P.adp && u_of_r && w_of_r) {
         const double *pp = P.pair[pt];
         double u, du, w, dw;
-        mishin_polar(x, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
-        mishin_polar(x, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        if ((P.tab_u >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 2, pt)], x, u, du);
+        else mishin_polar(x, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        if ((P.tab_w >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 3, pt)], x, w, dw);
+        else mishin_polar(x, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
         u_of_r[(size_t)pt * n_r + k] = u;
         w_of_r[(size_t)pt * n_r + k] = w;
       }
@@ -614,7 +655,8 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
   if (j < (int64_t)nel * n_rho) {
     const int row = (int)(j / n_rho), k = (int)(j % n_rho);
     double F, dF;
-    zjw_embed(P.el[row], P.embed_kind[row], rho[k], F, dF);
+    if ((P.tab_embed >> row) & 1u) spline_eval(tabs[slot_embed(nel, row)], rho[k], F, dF);
+    else zjw_embed(P.el[row], P.embed_kind[row], rho[k], F, dF);
     embed_of_rho[(size_t)row * n_rho + k] = F;
   }
 }
@@ -654,6 +696,7 @@ struct EamModel {
   bool pair_nets = false, embed_nets = false;
   double *pf = nullptr;           // [8 or 4][cap_pairs] value / derivative columns, then r [cap_pairs]
   size_t cap_pairs = 0;
+  TabDev *tabs_dev = nullptr;     // [n_slots] tabulated functions (n == 0: none)
   int fast_nt = 0;                // > 0: every pair function is 1 -> H1 -> 16 fast_nt -> 1 (fast kernel)
   size_t fast_lds = 0;
   NnFnList fns;                   // the pair functions that are nn functions
@@ -757,12 +800,53 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     err = "n_eam_nets must be 0 or " + std::to_string(n_slots) + " for this model";
     return nullptr;
   }
+  const bool have_tables = m->eam_table_n || m->eam_table_dx || m->eam_table_coef;
+  if (have_tables && (!m->n_eam_nets || !m->eam_table_n || !m->eam_table_dx || !m->eam_table_coef)) {
+    err = "tabulated functions need n_eam_nets, eam_table_n, eam_table_dx and eam_table_coef";
+    return nullptr;
+  }
   EamModel *e = new EamModel();
   std::memset(&e->p, 0, sizeof(e->p));
   e->p.nel = nel;
   e->p.adp = adp ? 1 : 0;
   e->eps = m->eps > 0.0 ? m->eps : 1e-14;
-  if (m->n_eam_nets) {
+  if (have_tables) {
+    try {
+      std::vector<TabDev> tabs(n_slots);
+      const double *src = m->eam_table_coef;
+      for (int sl = 0; sl < n_slots; ++sl) {
+        TabDev &t = tabs[sl];
+        t.n = m->eam_table_n[sl];
+        t.dx = t.inv_dx = 0.0;
+        t.c = nullptr;
+        if (t.n == 0) continue;
+        if (t.n < 3 || !(m->eam_table_dx[sl] > 0.0))
+          throw std::invalid_argument("a tabulated function needs at least 3 knots and a positive spacing");
+        if (m->n_layers && m->n_layers[sl] != 0)
+          throw std::invalid_argument("a function cannot be both tabulated and an nn function");
+        t.dx = m->eam_table_dx[sl];
+        t.inv_dx = 1.0 / t.dx;
+        std::vector<double> c(src, src + 4 * (size_t)(t.n - 1));
+        src += 4 * (size_t)(t.n - 1);
+        t.c = eam_upload(e, c);
+      }
+      e->tabs_dev = eam_upload(e, tabs);
+      for (int k = 0; k < nel; ++k) {
+        if (tabs[slot_rho(k)].n) e->p.tab_rho |= 1u << k;
+        if (tabs[slot_embed(nel, k)].n) e->p.tab_embed |= 1u << k;
+      }
+      for (int k = 0; k < npair; ++k) {
+        if (tabs[slot_pair(nel, 1, k)].n) e->p.tab_phi |= 1u << k;
+        if (adp && tabs[slot_pair(nel, 2, k)].n) e->p.tab_u |= 1u << k;
+        if (adp && tabs[slot_pair(nel, 3, k)].n) e->p.tab_w |= 1u << k;
+      }
+    } catch (const std::exception &ex) {
+      err = ex.what();
+      eam_destroy(e);
+      return nullptr;
+    }
+  }
+  if (m->n_eam_nets && m->n_layers) {
     try {
       build_nets(e, m, n_slots);
     } catch (const std::exception &ex) {
@@ -882,7 +966,8 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
   const int64_t total = (int64_t)(nel + npair) * n_r + (int64_t)nel * n_rho;
   if (total == 0) return;
   hipLaunchKernelGGL(eam_tabulate_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock),
-                     0, s, m->p, n_r, r, n_rho, rho, rho_of_r, phi_of_r, embed_of_rho, u_of_r, w_of_r);
+                     0, s, m->p, n_r, r, n_rho, rho, rho_of_r, phi_of_r, embed_of_rho, u_of_r, w_of_r,
+                     m->tabs_dev);
   if (!m->n_slots) return;
   // rows of nn functions: one launch per function over the same abscissae
   const size_t lds = net_lds_bytes(m);
@@ -945,7 +1030,7 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   }
   hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf, ps, m->rho_buf,
-                     pair_nets ? 1 : 0);
+                     pair_nets ? 1 : 0, m->tabs_dev);
   if (m->embed_nets) {
     EmbedTiles t;
     std::memset(&t, 0, sizeof(t));
@@ -965,7 +1050,7 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   }
   if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
     hipLaunchKernelGGL(eam_pair_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps);
+                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps, m->tabs_dev);
     launch_force_gather(sf, b, s);
   } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
     launch_force_gather(sf, b, s);

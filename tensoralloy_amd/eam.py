@@ -26,6 +26,13 @@ Flat parameter block handed to the C ABI (`ta_model_desc.eam_params`):
   per unordered element pair (a <= b, row-major upper triangle): phi kind
   (0 = Zjw04, 1 = Zjw04xcp constants) + [r_eq, A, B, alpha, beta, kappa, lamda];
   for ADP, per pair: 8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = none).
+Tabulated functions: a potential named `spline@<path>` (the prefix the reference's input reader
+accepts, train/training.py:258-262) takes that function from the LAMMPS setfl (`EamAlloyNN`) or
+adp (`AdpNN`) file at <path> and evaluates it as a natural cubic spline through every tabulated
+point, as the reference's `CubicInterpolator(x, y, natural_boundary=True)` does
+(nn/eam/potentials/tests/test_mishin.py:36-160). `EamAlloyNN.from_setfl(path)` /
+`AdpNN.from_setfl(path)` build a model whose every function comes from one file.
+
 Function networks travel in the MLP fields of `ta_model_desc` as `n_eam_nets` slots in the order
 rho[element], embed[element], phi[pair], then for ADP dipole[pair], quadrupole[pair]; a slot with
 0 layers is an analytic function.
@@ -174,7 +181,7 @@ class EamAlloyNN:
             for fn, name in sec.items():
                 ok = {"rho": ZJW04_FAMILY, "embed": ZJW04_FAMILY, "phi": ZJW04_FAMILY,
                       "dipole": ("mishinh",), "quadrupole": ("mishinh",)}[fn]
-                if str(name).lower() == "nn":
+                if str(name).lower() == "nn" or str(name).startswith("spline@"):
                     continue
                 if str(name).lower() not in ok:
                     raise ValueError(f"potential '{name}' for {key}/{fn} is not implemented by "
@@ -229,14 +236,57 @@ class EamAlloyNN:
     def is_nn(self, section: str, fn: str) -> bool:
         return str(self._potentials[section][fn]).lower() == "nn"
 
-    def nn_functions(self):
-        """(section, function) of every "nn" function in ABI slot order; analytic ones as None."""
+    def is_spline(self, section: str, fn: str) -> bool:
+        return str(self._potentials[section][fn]).startswith("spline@")
+
+    def _all_slots(self):
         slots = [(el, "rho") for el in self._elements] + [(el, "embed") for el in self._elements]
         n = len(self._elements)
         pairs = [self._elements[i] + self._elements[j] for i in range(n) for j in range(i, n)]
         for fn in self._pair_functions():
             slots += [(t, fn) for t in pairs]
-        return [(sec, fn) if self.is_nn(sec, fn) else None for sec, fn in slots]
+        return slots
+
+    def spline_table(self, section: str, fn: str):
+        """The `io.Spline` of a `spline@<path>` function (files are read once per model)."""
+        from . import io
+        path = str(self._potentials[section][fn])[len("spline@"):]
+        cache = self.__dict__.setdefault("_setfl_cache", {})
+        if path not in cache:
+            cache[path] = io.read_adp_setfl(path) if self._extra_functions() else io.read_eam_alloy_setfl(path)
+        fl = cache[path]
+        if fn in ("rho", "embed"):
+            group = getattr(fl, fn)
+            if section not in group:
+                raise ValueError(f"{path} has no {fn} table for {section}")
+            return group[section]
+        a, b = get_elements_from_kbody_term(section)
+        try:
+            return fl.pair(fn, a, b)
+        except KeyError as exc:
+            raise ValueError(f"{path}: {exc.args[0]}") from None
+
+    @classmethod
+    def from_setfl(cls, path: str, elements=None, **kwargs):
+        """A model whose every function is tabulated in one setfl / adp file."""
+        from . import io
+        path = os.path.abspath(str(path))
+        fl = io.read_adp_setfl(path) if cls.tag == "adp" else io.read_eam_alloy_setfl(path)
+        elements = sorted(elements or fl.elements)
+        name = "spline@" + path
+        pots = {el: {"rho": name, "embed": name} for el in elements}
+        for i, a in enumerate(elements):
+            for b in elements[i:]:
+                pots[a + b] = {"phi": name}
+                if cls.tag == "adp":
+                    pots[a + b].update(dipole=name, quadrupole=name)
+        nn = cls(elements, custom_potentials=pots, **kwargs)
+        nn.__dict__.setdefault("_setfl_cache", {})[path] = fl
+        return nn
+
+    def nn_functions(self):
+        """(section, function) of every "nn" function in ABI slot order; analytic ones as None."""
+        return [(sec, fn) if self.is_nn(sec, fn) else None for sec, fn in self._all_slots()]
 
     def initialize(self, seed=Defaults.seed, bias_scale=0.0):
         """He-normal kernels truncated at 2 sigma, zero (or small random) hidden biases, no output
@@ -298,10 +348,13 @@ class EamAlloyNN:
         return p
 
     def _element_is_all_nn(self, el: str) -> bool:
-        if not (self.is_nn(el, "rho") and self.is_nn(el, "embed")):
+        """No analytic function reads this element's Zjw04 constants."""
+        def free(sec, fn):
+            return self.is_nn(sec, fn) or self.is_spline(sec, fn)
+        if not (free(el, "rho") and free(el, "embed")):
             return False
         for t in self._unique_kbody_terms:
-            if el in get_elements_from_kbody_term(t) and not self.is_nn(t, "phi"):
+            if el in get_elements_from_kbody_term(t) and not free(t, "phi"):
                 return False
         return True
 
@@ -310,7 +363,7 @@ class EamAlloyNN:
         if a == b or self._family != "zjw04xcp":
             return None
         key = "".join(sorted([a, b]))
-        if self.is_nn(key, "phi"):
+        if self.is_nn(key, "phi") or self.is_spline(key, "phi"):
             return None
         p = dict(ZJW04XCP_PAIRS.get(key, {}))
         p.update({k: v for k, v in self._parameters.get(key, {}).items() if k in PHI_KEYS})
@@ -357,6 +410,27 @@ class EamAlloyNN:
         desc.n_eam_params = len(params)
         desc.eam_params = _lib.as_dp(params)
         desc.eps = 1e-8 if self.precision == "medium" else 1e-14  # precision.py:113-114
+        all_slots = self._all_slots()
+        if any(self.is_spline(sec, fn) for sec, fn in all_slots):
+            from .io import natural_spline_coefficients
+            tn, tdx, coef = [], [], []
+            for sec, fn in all_slots:
+                if not self.is_spline(sec, fn):
+                    tn.append(0)
+                    tdx.append(0.0)
+                    continue
+                sp = self.spline_table(sec, fn)
+                tn.append(len(sp.x))
+                tdx.append(float(sp.x[1] - sp.x[0]))
+                coef.append(natural_spline_coefficients(sp.x, sp.y).ravel())
+            tn = np.ascontiguousarray(tn, dtype=np.int32)
+            tdx = np.ascontiguousarray(tdx, dtype=np.float64)
+            coef = np.ascontiguousarray(np.concatenate(coef))
+            keep += [tn, tdx, coef]
+            desc.n_eam_nets = len(all_slots)
+            desc.eam_table_n = _lib.as_ip(tn)
+            desc.eam_table_dx = _lib.as_dp(tdx)
+            desc.eam_table_coef = _lib.as_dp(coef)
         slots = self.nn_functions()
         if any(s is not None for s in slots):
             n_layers, sizes, flat = [], [], []
@@ -518,7 +592,8 @@ class AdpNN(EamAlloyNN):
             for j in range(i, n):
                 term = self._elements[i] + self._elements[j]
                 p = self.pair_parameters(term)
-                if p is None and self.is_nn(term, "dipole") and self.is_nn(term, "quadrupole"):
+                free = all(self.is_nn(term, fn) or self.is_spline(term, fn) for fn in ("dipole", "quadrupole"))
+                if p is None and free:
                     p = dict(zip(ADP_KEYS, [0.0] * 6 + [1.0, 0.0]))  # not read by nn functions
                 if p is None:
                     raise ValueError(f"mishinh has no dipole/quadrupole parameters for {term}")

@@ -168,6 +168,30 @@ def main():
                            w_CuCu_absmax=float(np.abs(adp["w"]["CuCu"]).max()))
     with open(os.path.join(HERE, "eam_tables.json"), "w") as fp:
         json.dump(eam, fp)
+    # the setfl data file itself (a data file the reference's tests hold), gzip'ed, for the table
+    # reader and the spline-tabulated models; and the Al-Cu ADP file thinned to every 10th knot
+    # (3 MB otherwise), rewritten in the same layout
+    import gzip
+    with open(f"{REF}/test_files/lammps/Zhou_AlCu.alloy.eam", "rb") as fi, \
+            gzip.GzipFile(os.path.join(HERE, "Zhou_AlCu.alloy.eam.gz"), "wb", mtime=0) as fo:
+        fo.write(fi.read())
+    k = 10
+    with open(f"{REF}/test_files/lammps/AlCu.adp") as fp:
+        head = [fp.readline() for _ in range(5)]
+    els = adp["elements"]
+    adp_lines = [head[0], head[1], "thinned to every 10th knot by tests/golden/make_golden.py\n", head[3],
+           f"{adp['nrho'] // k} {adp['drho'] * k!r} {adp['nr'] // k} {adp['dr'] * k!r} {adp['rcut']!r}\n"]
+    zs = {"Al": "13 26.982 4.05 fcc\n", "Cu": "29 63.546 3.615 fcc\n"}
+    for el in els:
+        adp_lines.append(zs[el])
+        adp_lines += ["%.16e\n" % v for v in adp["embed"][el][::k]]
+        adp_lines += ["%.16e\n" % v for v in adp["rho"][el][::k]]
+    order = [(i, j) for i in range(len(els)) for j in range(i + 1)]
+    for group in ("rphi", "u", "w"):
+        for i, j in order:
+            adp_lines += ["%.16e\n" % v for v in adp[group][els[j] + els[i]][::k]]
+    with gzip.GzipFile(os.path.join(HERE, "AlCu_thinned.adp.gz"), "wb", mtime=0) as fo:
+        fo.write("".join(adp_lines).encode())
 
     # ---- 7. Reference-generated Hessian of Zjw04 Ni (nn/constraint/tests/test_fc2.py:29-54)
     #         with the structure it was computed for (test_files/crystals/Ni_sc.cif, P1)

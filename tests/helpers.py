@@ -77,7 +77,8 @@ def make_eam(elements, rcut=6.5, adp=False, potential="zjw04", parameters=None, 
         nn = EamAlloyNN(elements, custom_potentials=potential, parameters=parameters,
                         hidden_sizes=hidden_sizes, activation=activation)
     nn.attach_transformer(clf)
-    nn.initialize(seed=seed, bias_scale=0.1)
+    if any(s is not None for s in nn.nn_functions()):
+        nn.initialize(seed=seed, bias_scale=0.1)
     # keep randomly initialised nn functions at the scale of physical ones (rho_i of order 1-10,
     # energies of order eV), so that absolute tolerances mean what they mean for real models
     for sec in nn.weights.values():
@@ -108,11 +109,15 @@ def oracle_eam_eval(nn, atoms):
             for b in els[i:]:
                 if nn.pair_parameters(a + b) is not None:
                     adp[a + b] = nn.pair_parameters(a + b)
-    nets = {}
+    nets, tables = {}, {}
     for slot in nn.nn_functions():
         if slot is not None:
             sec, fn = slot
             nets.setdefault(fn, {})[sec] = nn.weights[sec][fn]
+    for sec, fn in nn._all_slots():
+        if nn.is_spline(sec, fn):
+            sp = nn.spline_table(sec, fn)
+            tables.setdefault(fn, {})[sec] = (sp.x, sp.y)
     phi_pairs = {}
     els = nn.elements
     for i, a in enumerate(els):
@@ -120,10 +125,12 @@ def oracle_eam_eval(nn, atoms):
             q = nn.phi_parameters(a, b)
             if q is not None:
                 phi_pairs[a + b] = q
+    if isinstance(nn, AdpNN) and not adp:
+        adp = {}
     m = EamModel(nn.elements, nn.transformer.rcut,
                  params={el: nn.element_parameters(el) for el in nn.elements}, adp=adp,
                  blended_embed=nn.family != "zjw04", phi_pairs=phi_pairs, nets=nets,
-                 activation=nn._activation)
+                 activation=nn._activation, tables=tables)
     eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
     return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
                     np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)
@@ -170,3 +177,14 @@ def oracle_grap_eval(nn, atoms):
     eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
     return evaluate(oracle_grap_model(nn), atoms.get_chemical_symbols(), atoms.positions,
                     np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)
+
+
+def golden_setfl(name, tmp_path):
+    """Unpack one of the gzip'ed setfl fixtures (tests/golden/) and return its path."""
+    import gzip
+    import os
+    src = os.path.join(os.path.dirname(__file__), "golden", name + ".gz")
+    dst = os.path.join(str(tmp_path), name)
+    with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+        fo.write(fi.read())
+    return dst

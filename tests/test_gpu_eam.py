@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import fcc, make_eam, oracle_eam_eval
+from tests.helpers import fcc, golden_setfl, make_eam, oracle_eam_eval
 from tests.test_gpu_sf import _alloy, E_TOL, F_TOL, W_TOL
 
 pytestmark = pytest.mark.gpu
@@ -109,6 +109,43 @@ def test_nn_eam_model_file_and_tables(lib, tmp_path):
     back = read_setfl(path)
     assert np.abs(back["rho"]["Mo"] - nn_function(r, nn.weights["Mo"]["rho"])[0]).max() < 1e-12
     assert np.abs(back["rphi"]["MoNi"] - r * nn_function(r, nn.weights["MoNi"]["phi"])[0]).max() < 1e-11
+
+
+def test_setfl_tables_run_as_splines(lib, tmp_path):
+    """A LAMMPS setfl file evaluated as natural cubic splines (`spline@` potentials; the
+    reference's `CubicInterpolator`, potentials/tests/test_mishin.py:36-160). Two checks: against
+    the oracle's SciPy splines of the same tables, and -- since `Zhou_AlCu.alloy.eam` IS the Zjw04
+    potential tabulated at dr = 0.003 (the reference asserts table == graph to 1e-12,
+    test_eam_alloy_nn.py:139-164) -- against the analytic Zjw04 model, where only the
+    interpolation error of the table remains."""
+    from tensoralloy_amd import Engine, TensorAlloyCalculator, UniversalTransformer
+    from tensoralloy_amd.eam import EamAlloyNN
+    path = golden_setfl("Zhou_AlCu.alloy.eam", tmp_path)
+    nn = EamAlloyNN.from_setfl(path)
+    nn.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=5.99))
+    frames = [_alloy(["Al", "Cu"], rep=(2, 2, 2), a=3.9), _alloy(["Al", "Al", "Cu"], rep=(2, 2, 3), a=4.05)]
+    _compare(nn, frames)
+    analytic = make_eam(["Al", "Cu"], 5.99)
+    with Engine(nn) as e1, Engine(analytic) as e2:
+        for a, b in zip(e1.evaluate(frames), e2.evaluate(frames)):
+            assert abs(a["energy"] - b["energy"]) < 2e-6 * len(a["forces"])
+            assert np.abs(a["forces"] - b["forces"]).max() < 2e-4
+    # one tabulated function inside an otherwise analytic model, and the model file round trip
+    pots = {"Al": {"rho": "spline@" + path, "embed": "zjw04"}, "Cu": {"rho": "zjw04", "embed": "spline@" + path},
+            "AlAl": {"phi": "zjw04"}, "AlCu": {"phi": "spline@" + path}, "CuCu": {"phi": "zjw04"}}
+    mixed = make_eam(["Al", "Cu"], 5.99, potential=pots)
+    _compare(mixed, frames[:1])
+    mixed.export(str(tmp_path / "mixed.pb"))
+    calc = TensorAlloyCalculator(str(tmp_path / "mixed.pb"))
+    assert abs(calc.get_potential_energy(frames[0]) - oracle_eam_eval(mixed, frames[0])["energy"]) < E_TOL
+
+
+def test_adp_tables_run_as_splines(lib, tmp_path):
+    from tensoralloy_amd import UniversalTransformer
+    from tensoralloy_amd.eam import AdpNN
+    nn = AdpNN.from_setfl(golden_setfl("AlCu_thinned.adp", tmp_path))
+    nn.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=6.2))
+    _compare(nn, [_alloy(["Al", "Al", "Cu"], rep=(2, 2, 2), a=4.0)])
 
 
 def test_device_softplus_accuracy(lib):

@@ -336,3 +336,73 @@ def test_lammps_native_npz_roundtrip(tmp_path):
     assert d1.kind == d2.kind == 4 and d1.n_grap_params == d2.n_grap_params
     with pytest.raises(ValueError):
         make_nn(["Ni"], 6.0, False, [8]).export_to_lammps_native(str(tmp_path / "sf.npz"))
+
+
+def test_setfl_readers_against_the_reference_literals(tmp_path):
+    """io/tests/test_lammps.py:25-71: values the reference's own reader test asserts for
+    `Zhou_AlCu.alloy.eam`; the thinned Al-Cu ADP file keeps every 10th knot of `AlCu.adp`
+    (w_AlCu[0] = 0.26740386..., u / w identically zero for Al-Al and Cu-Cu)."""
+    import gzip
+    from tests.helpers import golden_setfl
+    from tensoralloy_amd.io import read_adp_setfl, read_eam_alloy_setfl, natural_spline_coefficients
+    fl = read_eam_alloy_setfl(golden_setfl("Zhou_AlCu.alloy.eam", tmp_path))
+    assert fl.elements == ["Al", "Cu"] and fl.nr == 2000 and fl.nrho == 2000
+    assert fl.dr == 0.003 and fl.drho == 0.05 and fl.rcut == 6.0
+    assert fl.embed["Al"].y[10] == -1.8490865619220642e-01
+    assert abs(fl.phi["CuCu"].y[1] * fl.phi["CuCu"].x[1] - 3.8671050028993639) < 1e-15
+    assert sorted(fl.phi) == ["AlAl", "AlCu", "CuCu"] and fl.pair("phi", "Cu", "Al") is fl.phi["AlCu"]
+    assert fl.atomic_masses[0] == 26.98 and fl.lattice_types == ["fcc", "fcc"]
+    # the .gz is read directly as well
+    import os
+    gz = os.path.join(os.path.dirname(__file__), "golden", "Zhou_AlCu.alloy.eam.gz")
+    assert np.array_equal(read_eam_alloy_setfl(gz).rho["Cu"].y, fl.rho["Cu"].y)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "eam_tables.json")) as fp:
+        lit = json.load(fp)["AlCu_adp"]
+    adp = read_adp_setfl(golden_setfl("AlCu_thinned.adp", tmp_path))
+    assert adp.nr == lit["nr"] // 10 and adp.nrho == lit["nrho"] // 10
+    assert abs(adp.dr - 10 * lit["dr"]) < 1e-18 and abs(adp.drho - 10 * lit["drho"]) < 1e-18
+    assert abs(adp.quadrupole["AlCu"].y[0] - lit["w_AlCu_0_6"][0]) < 1e-15
+    assert np.abs(adp.dipole["AlAl"].y).max() == 0.0 and np.abs(adp.quadrupole["CuCu"].y).max() == 0.0
+    # natural cubic spline: interpolates the knots, second derivative zero at both ends,
+    # agrees with SciPy's natural spline between the knots
+    from scipy.interpolate import CubicSpline
+    sp = fl.rho["Al"]
+    c = natural_spline_coefficients(sp.x, sp.y)
+    assert np.array_equal(c[:, 0], sp.y[:-1]) and c[0, 2] == 0.0
+    h = sp.x[1] - sp.x[0]
+    assert abs(2 * c[-1, 2] + 6 * c[-1, 3] * h) < 1e-9
+    xx = np.random.RandomState(0).rand(500) * sp.x[-1]
+    k = np.minimum((xx / h).astype(int), len(sp.x) - 2)
+    t = xx - sp.x[k]
+    v = c[k, 0] + t * (c[k, 1] + t * (c[k, 2] + t * c[k, 3]))
+    assert np.abs(v - CubicSpline(sp.x, sp.y, bc_type="natural")(xx)).max() < 1e-13
+
+
+def test_spline_potentials_in_the_model_description(tmp_path):
+    from tests.helpers import golden_setfl
+    from tensoralloy_amd import UniversalTransformer
+    from tensoralloy_amd.eam import AdpNN, EamAlloyNN
+    path = golden_setfl("Zhou_AlCu.alloy.eam", tmp_path)
+    nn = EamAlloyNN.from_setfl(path)
+    assert nn.elements == ["Al", "Cu"] and nn.potentials["AlCu"] == {"phi": "spline@" + path}
+    nn.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=6.0))
+    desc, keep = nn.to_desc()
+    assert desc.n_eam_nets == 7 and [desc.eam_table_n[k] for k in range(7)] == [2000] * 7
+    assert abs(desc.eam_table_dx[0] - 0.003) < 1e-15 and abs(desc.eam_table_dx[2] - 0.05) < 1e-15
+    assert nn.nn_functions() == [None] * 7
+    mixed = EamAlloyNN(["Al", "Cu"], custom_potentials={
+        "Al": {"rho": "spline@" + path, "embed": "zjw04"}, "Cu": {"rho": "zjw04", "embed": "zjw04"},
+        "AlAl": {"phi": "zjw04"}, "AlCu": {"phi": "spline@" + path}, "CuCu": {"phi": "zjw04"}})
+    mixed.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=6.0))
+    desc, keep = mixed.to_desc()
+    assert [desc.eam_table_n[k] for k in range(7)] == [2000, 0, 0, 0, 0, 2000, 0]
+    with pytest.raises(ValueError, match="no rho table"):
+        bad = EamAlloyNN(["Al", "Ni"], custom_potentials={
+            "Ni": {"rho": "spline@" + path, "embed": "zjw04"}, "Al": {"rho": "zjw04", "embed": "zjw04"},
+            "AlAl": {"phi": "zjw04"}, "AlNi": {"phi": "zjw04"}, "NiNi": {"phi": "zjw04"}})
+        bad.attach_transformer(UniversalTransformer(["Al", "Ni"], rcut=6.0))
+        bad.to_desc()
+    adp = AdpNN.from_setfl(golden_setfl("AlCu_thinned.adp", tmp_path))
+    adp.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=6.0))
+    desc, keep = adp.to_desc()
+    assert desc.n_eam_nets == 13 and all(desc.eam_table_n[k] == 1000 for k in range(13))
