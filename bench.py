@@ -192,7 +192,7 @@ def main():
             dom_name, dom_key, passes = "sf_fused_kernel<1,2,2,16,true>", "sf_fused_kernel", 2.0
             bwd_ms = slots["fused"]
         else:
-            dom_name, dom_key, passes = "backward_v2_kernel<1,2,2,16,true>", "backward_v2_kernel", 1.0
+            dom_name, dom_key, passes = "backward_v2_kernel<1,2,2,12,true>", "backward_v2_kernel", 1.0
             bwd_ms = slots["backward"]
         bwd_bytes = passes * (32.0 * P + 60.0 * T)
         achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
