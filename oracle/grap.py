@@ -64,6 +64,29 @@ def radial_filter(algorithm, row, r, rc):
     raise ValueError(f"GRAP: algorithm '{algorithm}' is not implemented")
 
 
+def nn_filters(r, net):
+    """The `nn` algorithm (grap.py:220-270, :620-643): ONE shared 1x1 CNN `Filters` maps r to all
+    K = num_filters filter values, `convolution1x1(r, hidden_sizes, num_out=K, output_bias=False,
+    use_resnet_dt=...)` (convolutional.py:257-290). Returns v [P, K] and dv/dr [P, K]
+    (forward-mode). `net` = dict(layers=[(W, b), ..., (W_out, None)], activation, use_resnet_dt).
+    Only `h_abck_modifier = 0` (the input is r itself) is restated."""
+    from .sf import activation
+    h = np.asarray(r, dtype=np.float64)[:, None]
+    dh = np.ones_like(h)
+    layers = net["layers"]
+    for l, (W, b) in enumerate(layers):
+        W = np.asarray(W, dtype=np.float64)
+        z = h @ W + (0.0 if b is None else np.asarray(b, dtype=np.float64))
+        dz = dh @ W
+        if l == len(layers) - 1:
+            return z, dz
+        a, da = activation(net.get("activation", "softplus"), z)
+        da = da * dz
+        if net.get("use_resnet_dt", True) and l > 0 and W.shape[0] == W.shape[1]:
+            a, da = a + h, da + dh
+        h, dh = a, da
+
+
 # packed moment components: exponents (nx, ny, nz) of the unit vector, in the reference's order
 # (grap.py:501-511): 1 | x y z | xx xy xz yy yz zz | xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
 COMPONENTS = [(0, 0, 0),
@@ -101,11 +124,16 @@ def moment_coefficients(u, max_moment):
 class GrapModel:
     def __init__(self, elements, rcut, algorithm="sf", parameters=None, param_space_method="pair",
                  moment_tensors=0, cutoff_function="cosine", symmetric=False, legacy_mode=True,
-                 weights=None, activation="softplus", use_resnet_dt=False, minmax=None):
+                 weights=None, activation="softplus", use_resnet_dt=False, minmax=None,
+                 filter_net=None):
         self.elements = sorted(set(elements))
         self.rcut = float(rcut)
         self.algorithm = algorithm
-        self.grid = parameter_grid(algorithm, parameters, param_space_method)
+        self.filter_net = filter_net  # algorithm "nn": see nn_filters
+        if algorithm == "nn":
+            self.grid = [None] * int(np.shape(filter_net["layers"][-1][0])[1])
+        else:
+            self.grid = parameter_grid(algorithm, parameters, param_space_method)
         if isinstance(moment_tensors, int):
             moment_tensors = [moment_tensors]
         self.moment_tensors = list(set(moment_tensors))  # grap.py:295
@@ -187,7 +215,11 @@ def _moments(model, symbols, positions, cell, pbc, eps):
     M = moment_coefficients(u, mm)
     H = np.zeros((len(r), K))
     dH = np.zeros((len(r), K))
-    for k, row in enumerate(model.grid):
+    if model.algorithm == "nn":
+        v, dv = nn_filters(r, model.filter_net)
+        H = v * fc[:, None]
+        dH = dv * fc[:, None] + v * dfc[:, None]
+    for k, row in enumerate(model.grid if model.algorithm != "nn" else []):
         v, dv = radial_filter(model.algorithm, row, r, model.rcut)
         H[:, k] = v * fc
         dH[:, k] = dv * fc + v * dfc

@@ -84,10 +84,31 @@ def bench_nn_eam(steps=50):
     return out
 
 
+def bench_grap_nn(steps=50):
+    """GRAP with the `nn` filter network of defaults.toml `[nn.atomic.grap.nn]` (softplus, hidden
+    32-32-32 with ResNet skips, 16 filters), moments 0..3, rc 6.0, MLP 2 x 64."""
+    from tests.helpers import make_grap_nn, oracle_grap_eval
+    atoms = ni_frame(611)
+    nn = make_grap_nn(["Ni"], 6.0, [64, 64], "nn", moment_tensors=[0, 1, 2, 3])
+    with Engine(nn) as eng:
+        r = eng.evaluate([atoms])[0]
+        ms, slots = timeit(eng, WANT, steps=steps)
+        o = oracle_grap_eval(nn, atoms)
+        return {"N1_grap_nn_Ni": {
+            "atoms": len(atoms), "pairs": int(eng.info.n_pairs), "D": nn.ndim(), "ms_per_eval": ms,
+            "atom_steps_per_s": len(atoms) / ms * 1e3, "kernel_ms": slots,
+            "parity": {"dE_eV": abs(o["energy"] - r["energy"]),
+                       "dF_max": float(np.abs(o["forces"] - r["forces"]).max()),
+                       "dW_max": float(np.abs(o["virial"] - r["virial"]).max())}}}
+
+
 def main():
     _lib.build()
     if "--nn-eam" in sys.argv:
         print(json.dumps(bench_nn_eam(), indent=1))
+        return
+    if "--grap-nn" in sys.argv:
+        print(json.dumps(bench_grap_nn(), indent=1))
         return
     out = {}
 
@@ -163,6 +184,7 @@ def main():
     # nn-EAM: the reference's default potentials (rho, phi, embed = 1 -> 64 -> 32 -> 1 networks,
     # alloy.py:110-112, Defaults.hidden_sizes)
     out.update(bench_nn_eam())
+    out.update(bench_grap_nn())
     # ---- N1: the reference's default production descriptor (io/input/defaults.toml:131-155):
     # GRAP, pexp, 16 filters, moments 0..3, new mode, cosine cutoff, rc = 6.0; MLP 2 x 64
     from oracle import grap as ograp

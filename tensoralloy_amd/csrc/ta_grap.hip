@@ -22,9 +22,12 @@
 // Forces / virial / energy then use force_gather and frame_reduce like every other model.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "ta_device.h"
 #include "ta_math.h"
@@ -37,8 +40,10 @@ constexpr int kBlock = 256;
 constexpr int kMaxFilters = 32;
 constexpr int kMaxComp = 20;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double mlp_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kMlpTileRows = 16;
 
-enum { GRAP_SF = 0, GRAP_MORSE = 1, GRAP_DENSITY = 2, GRAP_PEXP = 3 };
+enum { GRAP_SF = 0, GRAP_MORSE = 1, GRAP_DENSITY = 2, GRAP_PEXP = 3, GRAP_NN = 4 };
 
 struct GrapParams {
   int nel, K, max_moment, nd;  // nd = 1, 4, 10, 20 packed components
@@ -48,6 +53,10 @@ struct GrapParams {
   double rcut, inv_rc2;
   double T[kMaxComp][4];       // multiplicity tensor (grap.py:470-492)
   const double *fp;            // device [K][4] filter constants
+  // algorithm `nn`: per pair the K filter values and their r-derivatives, written by
+  // grap_nn_filter_kernel: Hbuf[p][0 .. Ks) = v_k(r_p), Hbuf[p][Ks .. 2 Ks) = dv_k/dr
+  const double *Hbuf;
+  int Ks;                      // K rounded up to 16
 };
 
 // exponents (nx, ny, nz) packed 2 bits each, in the reference's component order (grap.py:501-511)
@@ -241,7 +250,10 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
         for (int base = 0; base < n; base += 4) {
           const int t = base + q4;  // < round_up(n, 16): staged (zero beyond n)
           double v, dv;
-          filter_fn(g.algo, fp0, fp1, fp2, L.r[t], L.logr[t], L.inv_r[t], v, dv);
+          if (g.algo == GRAP_NN)  // rows beyond n belong to later pairs (or the padding): f = 0 there
+            v = g.Hbuf[(size_t)(first + t) * (2 * g.Ks) + (k_ok ? k : 0)];
+          else
+            filter_fn(g.algo, fp0, fp1, fp2, L.r[t], L.logr[t], L.inv_r[t], v, dv);
           const double h = k_ok ? v * L.f[t] : 0.0;
           acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d0_ok ? L.M[t][m16] : 0.0, acc0, 0, 0, 0);
           if (nd > 16)
@@ -378,7 +390,13 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
           double H = 0.0, dH = 0.0;
           if (k < K) {
             double v, dv;
-            filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_r, v, dv);
+            if (g.algo == GRAP_NN) {
+              const double *hp = g.Hbuf + (size_t)(first + ta) * (2 * g.Ks);
+              v = hp[k];
+              dv = hp[g.Ks + k];
+            } else {
+              filter_fn(g.algo, FP[4 * k], FP[4 * k + 1], FP[4 * k + 2], r, logr, inv_r, v, dv);
+            }
             H = v * f;
             dH = dv * f + v * df;
           }
@@ -426,6 +444,131 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   }
 }
 
+// ---- the `nn` algorithm: one shared filter network r -> K filter values (grap.py:220-270, :632-643) --
+constexpr int kNetMaxLayers = 8;   // dense layers incl. the linear output layer
+constexpr int kNetMaxWidth = 64;   // padded layer width (4 column tiles)
+
+struct GrapNet {
+  int L, act, resnet;
+  int np[kNetMaxLayers];      // padded output width of every layer (multiple of 16)
+  int res[kNetMaxLayers];     // skip connection on this layer (convolutional.py:272-273)
+  const double *w[kNetMaxLayers];  // layer 0: [np0] (K = 1); else [kp = np[l-1]][np[l]] row-major, zero padded
+  const double *b[kNetMaxLayers];  // [np[l]], zeros where the layer has no bias
+  int xs;                     // row stride of the activation buffers (2 or 18 mod 32: conflict-free A reads)
+};
+
+__host__ __device__ inline int net_wstride(int np) { return (np % 32 == 0) ? np + 16 : np; }
+
+// Value and r-derivative of all K filters for every pair, forward mode: a wavefront owns 16 pairs;
+// the activations h and dh/dr of the current layer sit in the wavefront's LDS rows as [pair][unit]
+// (the A operand of v_mfma_f64_16x16x4_f64), [h; h'] . W shares the B operand read from the
+// workgroup's LDS image of the weights; the accumulator layout puts a pair's value and derivative of
+// one unit in the same lane, so the activation is applied in registers. Layer 0 has K = 1 and needs
+// no GEMM. Pair geometry: r = sqrt(r^2) of the pair records (pair_geometry_kernel ran before).
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, DeviceBatch b, double *Hbuf,
+                                                               int Ks) {
+  extern __shared__ double lds[];
+  const int act = ACT >= 0 ? ACT : net.act;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+  // LDS: w0, b0, then per GEMM layer W (padded stride) and bias, then the wavefronts' X buffers
+  double *w0 = lds, *b0 = w0 + net.np[0];
+  double *Wl[kNetMaxLayers], *Bl[kNetMaxLayers];
+  double *cur = b0 + net.np[0];
+  for (int l = 1; l < net.L; ++l) {
+    Wl[l] = cur;
+    cur += (size_t)net.np[l - 1] * net_wstride(net.np[l]);
+    Bl[l] = cur;
+    cur += net.np[l];
+  }
+  double *Xv = cur + (size_t)wave * 2 * kMlpTileRows * net.xs, *Xd = Xv + (size_t)kMlpTileRows * net.xs;
+  for (int idx = tid; idx < net.np[0]; idx += kBlock) {
+    w0[idx] = net.w[0][idx];
+    b0[idx] = net.b[0][idx];
+  }
+  for (int l = 1; l < net.L; ++l) {
+    const int kp = net.np[l - 1], np = net.np[l], ws = net_wstride(np);
+    for (int idx = tid; idx < kp * np; idx += kBlock) {
+      const int row = idx / np, col = idx - row * np;
+      Wl[l][row * ws + col] = net.w[l][idx];
+    }
+    for (int idx = tid; idx < np; idx += kBlock) Bl[l][idx] = net.b[l][idx];
+  }
+  __syncthreads();
+  const int64_t ntiles = (b.n_pairs + kMlpTileRows - 1) / kMlpTileRows;
+  // every wavefront of the workgroup makes the same number of trips (block-level barriers inside)
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < ntiles; base += (int64_t)gridDim.x * 4) {
+    const int64_t t = base + wave;
+    const int64_t p = t * kMlpTileRows + m;
+    const bool valid = t < ntiles && p < b.n_pairs;
+    const double x = valid ? sqrt(b.rec[kRecDoubles * (size_t)p + 3]) : 0.0;
+    for (int c = kq; c < net.np[0]; c += 4) {
+      const double wk = w0[c];
+      double h, dh;
+      activation_fn(act, fma(wk, x, b0[c]), h, dh);
+      Xv[m * net.xs + c] = h;
+      Xd[m * net.xs + c] = dh * wk;
+    }
+    __syncthreads();
+    for (int l = 1; l < net.L; ++l) {
+      const int kp = net.np[l - 1], NT = net.np[l] / 16, ws = net_wstride(net.np[l]);
+      mlp_f64x4 accv[4], accd[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const double bb = nt < NT ? Bl[l][16 * nt + m] : 0.0;
+        accv[nt] = {bb, bb, bb, bb};
+        accd[nt] = {0.0, 0.0, 0.0, 0.0};
+      }
+      for (int kk = 0; kk < kp / 4; ++kk) {
+        const int ki = 4 * kk + kq;
+        const double av = Xv[m * net.xs + ki], ad = Xd[m * net.xs + ki];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NT) {
+            const double B = Wl[l][ki * ws + 16 * nt + m];
+            accv[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B, accv[nt], 0, 0, 0);
+            accd[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, B, accd[nt], 0, 0, 0);
+          }
+      }
+      __syncthreads();  // every read of this layer's input is done
+      if (l < net.L - 1) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = kq + 4 * q, col = 16 * nt + m;
+              double h, dh;
+              activation_fn(act, accv[nt][q], h, dh);
+              double hd = dh * accd[nt][q];
+              if (net.res[l]) {  // x = act(w x + b) + x
+                h += Xv[row * net.xs + col];
+                hd += Xd[row * net.xs + col];
+              }
+              Xv[row * net.xs + col] = h;
+              Xd[row * net.xs + col] = hd;
+            }
+          }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int64_t pp = t * kMlpTileRows + kq + 4 * q;
+              const int col = 16 * nt + m;
+              if (t < ntiles && pp < b.n_pairs && col < Ks) {
+                Hbuf[(size_t)pp * (2 * Ks) + col] = accv[nt][q];
+                Hbuf[(size_t)pp * (2 * Ks) + Ks + col] = accd[nt][q];
+              }
+            }
+          }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 struct GrapModel {
@@ -434,7 +577,76 @@ struct GrapModel {
   double *Pbuf = nullptr;
   size_t cap_atoms = 0;
   int ndim = 0;
+  // algorithm `nn`
+  GrapNet net;
+  std::vector<double *> owned;           // device copies of the network's weights
+  double *Hbuf = nullptr;
+  size_t cap_pairs = 0;
+  size_t net_lds = 0;
 };
+
+void grap_destroy(GrapModel *g);
+
+namespace {
+
+// [L, activation, use_resnet_dt, h_abck_modifier, sizes 1, h1, ..., K, then per layer W [in][out], b [out]]
+void build_filter_net(GrapModel *g, const double *q, int n, int K, std::string &err) {
+  auto fail = [&](const char *msg) { throw std::invalid_argument(msg); };
+  if (n < 4) fail("grap_params: the filter network description is missing");
+  const int L = (int)q[0], act = (int)q[1], resnet = (int)q[2], modifier = (int)q[3];
+  if (L < 2 || L > kNetMaxLayers) fail("GRAP/nn: 2..8 dense layers (incl. the output layer)");
+  if (act < 0 || act > TA_ACT_ELU) fail("GRAP/nn: unknown activation");
+  if (modifier != 0) fail("GRAP/nn: h_abck_modifier 1 / 2 are not implemented");
+  if (n < 4 + L + 1) fail("grap_params: the filter network's layer sizes are missing");
+  int sizes[kNetMaxLayers + 1];
+  size_t need = 4 + L + 1;
+  for (int l = 0; l <= L; ++l) {
+    sizes[l] = (int)q[4 + l];
+    if (sizes[l] < 1 || sizes[l] > kNetMaxWidth) fail("GRAP/nn: layer widths 1..64");
+    if (l > 0) need += (size_t)sizes[l - 1] * sizes[l] + sizes[l];
+  }
+  if (sizes[0] != 1 || sizes[L] != K) fail("GRAP/nn: the network maps 1 input to K filters");
+  if ((size_t)n != need) fail("grap_params: wrong length for the filter network");
+  GrapNet &net = g->net;
+  std::memset(&net, 0, sizeof(net));
+  net.L = L;
+  net.act = act;
+  net.resnet = resnet ? 1 : 0;
+  const double *src = q + 4 + L + 1;
+  int maxw = 16;
+  for (int l = 0; l < L; ++l) {
+    const int k = sizes[l], nn = sizes[l + 1];
+    const int kp = l == 0 ? 1 : (k + 15) / 16 * 16, np = (nn + 15) / 16 * 16;
+    net.np[l] = np;
+    net.res[l] = (resnet && l > 0 && l < L - 1 && k == nn) ? 1 : 0;
+    maxw = std::max(maxw, np);
+    std::vector<double> w((size_t)kp * np, 0.0), bb(np, 0.0);
+    for (int a = 0; a < k; ++a)
+      for (int c = 0; c < nn; ++c) w[(size_t)a * np + c] = src[(size_t)a * nn + c];
+    src += (size_t)k * nn;
+    for (int c = 0; c < nn; ++c) bb[c] = src[c];
+    src += nn;
+    double *dw = nullptr, *db = nullptr;
+    if (hipMalloc((void **)&dw, w.size() * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+    g->owned.push_back(dw);
+    if (hipMalloc((void **)&db, bb.size() * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+    g->owned.push_back(db);
+    if (hipMemcpy(dw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db, bb.data(), bb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      throw std::runtime_error("hipMemcpy of the GRAP filter network failed");
+    net.w[l] = dw;
+    net.b[l] = db;
+  }
+  net.xs = maxw + 2;
+  size_t doubles = 2 * (size_t)net.np[0];
+  for (int l = 1; l < L; ++l) doubles += (size_t)net.np[l - 1] * net_wstride(net.np[l]) + net.np[l];
+  doubles += 4 * 2 * (size_t)kMlpTileRows * net.xs;
+  g->net_lds = doubles * sizeof(double);
+  if (g->net_lds > 150 * 1024) fail("GRAP/nn: the filter network does not fit the LDS image");
+  (void)err;
+}
+
+}  // namespace
 
 // grap_desc: [algorithm, K, max_moment, legacy, symmetric, moment mask (bit m = emitted),
 //             then K x 3 filter constants]
@@ -446,8 +658,12 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
   const double *q = m->grap_params;
   const int algo = (int)q[0], K = (int)q[1], mm = (int)q[2], legacy = (int)q[3], symmetric = (int)q[4];
   const int mask = (int)q[5];
-  if (algo < 0 || algo > 3) {
+  if (algo < 0 || algo > GRAP_NN) {
     err = "unknown GRAP algorithm";
+    return nullptr;
+  }
+  if (algo == GRAP_NN && legacy) {
+    err = "GRAP/nn exists only in the non-legacy formulation (grap.py:620-643)";
     return nullptr;
   }
   if (K < 1 || K > kMaxFilters) {
@@ -462,7 +678,7 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
     err = "GRAP legacy mode has moments 0, 1, 2 only (grap.py:423-460)";
     return nullptr;
   }
-  if (m->n_grap_params != 6 + 3 * K) {
+  if (algo != GRAP_NN && m->n_grap_params != 6 + 3 * K) {
     err = "grap_params must hold 6 + 3 K doubles";
     return nullptr;
   }
@@ -509,8 +725,18 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
     if (sym)
       for (int d = 1; d < 4; ++d) p.T[d][3] = -3.0 / 5.0;
   }
+  p.Ks = (K + 15) / 16 * 16;
+  if (algo == GRAP_NN) {
+    try {
+      build_filter_net(g, q + 6, m->n_grap_params - 6, K, err);
+    } catch (const std::exception &ex) {
+      err = ex.what();
+      grap_destroy(g);
+      return nullptr;
+    }
+  }
   double host[kMaxFilters * 4] = {0};
-  for (int k = 0; k < K; ++k)
+  for (int k = 0; k < K && algo != GRAP_NN; ++k)
     for (int c = 0; c < 3; ++c) host[4 * k + c] = q[6 + 3 * k + c];
   for (int k = 0; k < K; ++k) {
     const double *f = &host[4 * k];
@@ -555,11 +781,25 @@ void grap_destroy(GrapModel *g) {
   if (!g) return;
   if (g->fp) (void)hipFree(g->fp);
   if (g->Pbuf) (void)hipFree(g->Pbuf);
+  if (g->Hbuf) (void)hipFree(g->Hbuf);
+  for (double *d : g->owned) (void)hipFree(d);
   delete g;
 }
 
 void grap_ensure(GrapModel *g, const DeviceBatch &b) {
   const size_t n = (size_t)b.n_atoms;
+  if (g->p.algo == GRAP_NN && (size_t)b.n_pairs > g->cap_pairs) {
+    if (g->Hbuf) (void)hipFree(g->Hbuf);
+    g->Hbuf = nullptr;
+    g->cap_pairs = 0;
+    // the forward kernel's zero-weighted padding rows read up to one chunk past the last pair
+    const size_t cap = (size_t)b.n_pairs + (size_t)b.n_pairs / 8 + 2 * kFwdChunk;
+    if (hipMalloc((void **)&g->Hbuf, cap * 2 * g->p.Ks * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+    if (hipMemset(g->Hbuf, 0, cap * 2 * g->p.Ks * sizeof(double)) != hipSuccess)
+      throw std::runtime_error("hipMemset failed");
+    g->cap_pairs = cap - 2 * kFwdChunk;
+    g->p.Hbuf = g->Hbuf;
+  }
   if (n <= g->cap_atoms) return;
   if (g->Pbuf) (void)hipFree(g->Pbuf);
   g->Pbuf = nullptr;
@@ -571,6 +811,22 @@ void grap_ensure(GrapModel *g, const DeviceBatch &b) {
 
 void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStream_t s) {
   if (b.n_atoms == 0) return;
+  if (g->p.algo == GRAP_NN && b.n_pairs > 0) {
+    // geometry first (the filter network needs r), then the K filters of every pair
+    SFParams sf;
+    std::memset(&sf, 0, sizeof(sf));
+    sf.n_elements = g->p.nel;
+    sf.eps = eps;
+    launch_pair_geometry(sf, b, s);
+    const unsigned tiles = (unsigned)((b.n_pairs + kMlpTileRows - 1) / kMlpTileRows);
+    const dim3 grid(std::min((tiles + 3) / 4, 2048u));
+    if (g->net.act == TA_ACT_SOFTPLUS)
+      hipLaunchKernelGGL(grap_nn_filter_kernel<TA_ACT_SOFTPLUS>, grid, dim3(kBlock), g->net_lds, s, g->net, b,
+                         g->Hbuf, g->p.Ks);
+    else
+      hipLaunchKernelGGL(grap_nn_filter_kernel<-1>, grid, dim3(kBlock), g->net_lds, s, g->net, b, g->Hbuf,
+                         g->p.Ks);
+  }
   hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
                      g->ndim, eps);
 }

@@ -293,6 +293,10 @@ class AtomicNN:
                 xlo, xhi = self.minmax[el]
                 data[f"xlo_{i}"] = np.asarray(xlo, dtype=np.float64)
                 data[f"xhi_{i}"] = np.asarray(xhi, dtype=np.float64)
+        for j, (w, b) in enumerate(getattr(self._descriptor, "filter_weights", None) or []):
+            data[f"fnn::weights_0_{j}"] = np.asarray(w, dtype=np.float64)   # GRAP `nn` filter network
+            if b is not None:
+                data[f"fnn::biases_0_{j}"] = np.asarray(b, dtype=np.float64)
         np.savez(stem + ".npz", **data)
         with open(stem + ".json", "w") as fp:
             json.dump(meta, fp, indent=1)
@@ -329,10 +333,29 @@ class AtomicNN:
                 "numbers": np.array(chars, dtype=np.int32), "tdnp": np.int32(0),
                 "precision": np.int32(64 if dtype == np.float64 else 32), "use_fnn": np.int32(0)}
         algo = gd.algorithm.as_dict(convert_to_pairs=True)
-        method = {"pexp": 0, "morse": 1, "density": 2, "sf": 3}[gd.algorithm.name]
-        data["descriptor::method"] = np.int32(method)
-        for key, values in algo["parameters"].items():
-            data[f"descriptor::{key}"] = np.array(values, dtype=dtype)
+        if gd.algorithm.name == "nn":  # atomic.py:408-438
+            if not gd.filter_weights:
+                raise ValueError("GRAP/nn: the descriptor has no filter weights")
+            if algo["activation"].lower() not in actfn_map:
+                raise ValueError(f"activation '{algo['activation']}' has no code in the native format")
+            data["use_fnn"] = np.int32(1)
+            data["fnn::nlayers"] = np.int32(len(algo["hidden_sizes"]) + 1)
+            data["fnn::layer_sizes"] = np.array(list(algo["hidden_sizes"]) + [algo["num_filters"]], dtype=np.int32)
+            data["fnn::num_filters"] = np.int32(algo["num_filters"])
+            data["fnn::actfn"] = np.int32(actfn_map[algo["activation"].lower()])
+            data["fnn::use_resnet_dt"] = np.int32(algo["use_resnet_dt"])
+            data["fnn::apply_output_bias"] = np.int32(0)
+            data["fnn::h_abck_modifier"] = np.int32(algo["h_abck_modifier"])
+            for j, (w, b) in enumerate(gd.filter_weights):
+                data[f"fnn::weights_0_{j}"] = np.squeeze(np.asarray(w, dtype=dtype))
+                if j < len(gd.filter_weights) - 1:
+                    data[f"fnn::biases_0_{j}"] = (np.zeros(np.shape(w)[1], dtype=dtype) if b is None
+                                                  else np.asarray(b, dtype=dtype))
+        else:
+            method = {"pexp": 0, "morse": 1, "density": 2, "sf": 3}[gd.algorithm.name]
+            data["descriptor::method"] = np.int32(method)
+            for key, values in algo["parameters"].items():
+                data[f"descriptor::{key}"] = np.array(values, dtype=dtype)
         data["nlayers"] = np.int32(len(layer_sizes))
         data["max_moment"] = np.int32(gd.max_moment)
         data["actfn"] = np.int32(actfn_map[self._activation.lower()])
@@ -466,16 +489,19 @@ def load_lammps_native(path: str):
     from .grap import GenericRadialAtomicPotential
     from .transformer import UniversalTransformer
     npz = np.load(path)
-    if int(npz["use_fnn"]) != 0:
-        raise ValueError(f"{path}: the 'nn' filter network of GRAP is not implemented by tensoralloy_amd")
     if int(npz["tdnp"]) != 0:
         raise ValueError(f"{path}: temperature-dependent models are not implemented by tensoralloy_amd")
     chars = np.asarray(npz["numbers"], dtype=int).reshape(-1, 2)
     elements = ["".join(chr(c) for c in row if c) for row in chars]
-    method = {0: "pexp", 1: "morse", 2: "density", 3: "sf"}[int(npz["descriptor::method"])]
-    keys = {"pexp": ["rl", "pl"], "morse": ["D", "gamma", "r0"], "density": ["A", "beta", "re"],
-            "sf": ["eta", "omega"]}[method]
-    parameters = {k: np.atleast_1d(npz[f"descriptor::{k}"]).astype(float).tolist() for k in keys}
+    if int(npz["use_fnn"]) != 0:   # the `nn` filter network: hyper-parameters and weights from fnn::*
+        method = "nn"
+        parameters = {"h_abck_modifier": int(npz["fnn::h_abck_modifier"]) if "fnn::h_abck_modifier" in npz.files else 0,
+                      "ckpt": str(path)}
+    else:
+        method = {0: "pexp", 1: "morse", 2: "density", 3: "sf"}[int(npz["descriptor::method"])]
+        keys = {"pexp": ["rl", "pl"], "morse": ["D", "gamma", "r0"], "density": ["A", "beta", "re"],
+                "sf": ["eta", "omega"]}[method]
+        parameters = {k: np.atleast_1d(npz[f"descriptor::{k}"]).astype(float).tolist() for k in keys}
     max_moment = int(npz["max_moment"])
     gd = GenericRadialAtomicPotential(
         elements, method, parameters, param_space_method="pair",
@@ -565,6 +591,16 @@ def load_model(graph_model_path: str):
             nn.weights[el] = layers
             if nn._minmax_scale:
                 nn.minmax[el] = (np.array(npz[f"xlo_{i}"]), np.array(npz[f"xhi_{i}"]))
+        if getattr(getattr(nn.descriptor, "algorithm", None), "name", "") == "nn":
+            layers, j = [], 0
+            while f"fnn::weights_0_{j}" in npz:
+                b = np.array(npz[f"fnn::biases_0_{j}"], dtype=np.float64).ravel() \
+                    if f"fnn::biases_0_{j}" in npz else None
+                layers.append((np.array(npz[f"fnn::weights_0_{j}"], dtype=np.float64), b))
+                j += 1
+            if not layers:
+                raise ValueError(f"{stem}.npz holds no weights of the GRAP filter network")
+            nn.descriptor.filter_weights = layers
     elif nn_cls in ("EamAlloyNN", "AdpNN"):
         from .eam import nn_from_dict
         npz = None

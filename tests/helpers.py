@@ -145,7 +145,9 @@ def make_grap_nn(elements, rcut, hidden, algorithm="pexp", parameters=None, mome
                  minmax=False, seed=611, precision="high"):
     from tensoralloy_amd.grap import GenericRadialAtomicPotential
     clf = UniversalTransformer(elements, rcut=rcut, angular=False)
-    grap = GenericRadialAtomicPotential(elements, algorithm, parameters=parameters or PEXP,
+    if algorithm == "nn" and parameters is None:
+        parameters = {}
+    grap = GenericRadialAtomicPotential(elements, algorithm, parameters=PEXP if parameters is None else parameters,
                                         param_space_method=param_space_method,
                                         moment_tensors=list(moment_tensors), cutoff_function=cutoff,
                                         symmetric=symmetric, legacy_mode=legacy_mode)
@@ -154,6 +156,10 @@ def make_grap_nn(elements, rcut, hidden, algorithm="pexp", parameters=None, mome
     nn.attach_transformer(clf)
     nn.precision = precision
     nn.initialize(seed=seed, bias_scale=0.1)
+    if algorithm == "nn":
+        grap.initialize_filters(seed=seed + 7, bias_scale=0.1)
+        w, b = grap.filter_weights[-1]
+        grap.filter_weights[-1] = (w * 0.2, b)   # filter values of order 1, like the analytic ones
     if minmax:
         rng = np.random.RandomState(seed + 1)
         D = nn.ndim()
@@ -165,7 +171,13 @@ def make_grap_nn(elements, rcut, hidden, algorithm="pexp", parameters=None, mome
 def oracle_grap_model(nn):
     from oracle.grap import GrapModel
     d = nn.descriptor.as_dict()
+    filter_net = None
+    if d["algorithm"] == "nn":
+        a = nn.descriptor.algorithm
+        filter_net = dict(layers=nn.descriptor.filter_weights, activation=a.activation,
+                          use_resnet_dt=a.use_resnet_dt)
     return GrapModel(nn.elements, nn.transformer.rcut, algorithm=d["algorithm"], parameters=d["parameters"],
+                     filter_net=filter_net,
                      param_space_method=d["param_space_method"], moment_tensors=d["moment_tensors"],
                      cutoff_function=d["cutoff_function"], symmetric=d["symmetric"],
                      legacy_mode=d["legacy_mode"], weights=nn.weights, activation=nn._activation,

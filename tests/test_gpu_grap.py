@@ -92,3 +92,25 @@ def test_native_npz_model_runs_in_the_calculator(lib, tmp_path):
     assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
     assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
     assert np.abs(calc.get_stress(atoms) - o["stress_voigt"]).max() < 1e-8
+
+
+def test_nn_filter_network(lib, tmp_path):
+    """The `nn` algorithm (grap.py:220-270, :632-643; defaults.toml `[nn.atomic.grap.nn]`: softplus,
+    hidden 32-32-32 with ResNet skips, 16 filters): one shared filter network instead of analytic
+    filters. Default shape, a second shape / activation, the model file and the native `.npz`."""
+    from tensoralloy_amd import TensorAlloyCalculator
+    nn = make_grap_nn(["Ni"], 6.0, [64, 64], "nn", moment_tensors=[0, 1, 2, 3])
+    assert nn.descriptor.algorithm.hidden_sizes == [32, 32, 32] and len(nn.descriptor.algorithm) == 16
+    assert nn.ndim() == 4 * 16
+    _compare(nn, [fcc(rep=(3, 3, 3)), fcc(rep=(1, 1, 1))])
+    par = {"hidden_sizes": [24, 40], "num_filters": 10, "activation": "tanh", "use_resnet_dt": False}
+    nn2 = make_grap_nn(["Mo", "Ni"], 5.5, [16], "nn", par, moment_tensors=[0, 1, 2], symmetric=True)
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    _compare(nn2, [atoms])
+    o = oracle_grap_eval(nn2, atoms)
+    for path in (nn2.export(str(tmp_path / "fnn")), nn2.export_to_lammps_native(str(tmp_path / "fnn_native.npz"))):
+        calc = TensorAlloyCalculator(path)
+        assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
+        assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
+    with pytest.raises(ValueError, match="legacy_mode=False"):
+        make_grap_nn(["Ni"], 6.0, [16], "nn", legacy_mode=True)

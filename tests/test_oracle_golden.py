@@ -350,3 +350,30 @@ def test_grap_oracle_finite_differences():
         Ep = grap.evaluate(m, sym, atoms.positions @ (np.eye(3) + e), cell @ (np.eye(3) + e), atoms.pbc)["energy"]
         Em = grap.evaluate(m, sym, atoms.positions @ (np.eye(3) - e), cell @ (np.eye(3) - e), atoms.pbc)["energy"]
         assert abs(o["virial"][1, 2] - (Ep - Em) / 2e-6) < 1e-6
+
+
+def test_grap_nn_filters_oracle_finite_differences():
+    """`nn` filters (grap.py:632-643): Jacobian of the shared filter network and the forces built on
+    it, against central differences."""
+    from oracle.grap import nn_filters
+    from tests.helpers import make_grap_nn, oracle_grap_eval
+    nn = make_grap_nn(["Ni"], 5.0, [16], "nn", {"hidden_sizes": [8, 8], "num_filters": 5},
+                      moment_tensors=[0, 1, 2])
+    a = nn.descriptor.algorithm
+    net = dict(layers=nn.descriptor.filter_weights, activation=a.activation, use_resnet_dt=a.use_resnet_dt)
+    r = np.linspace(1.0, 5.0, 17)
+    v, dv = nn_filters(r, net)
+    assert v.shape == (17, 5)
+    d = 1e-6
+    num = (nn_filters(r + d, net)[0] - nn_filters(r - d, net)[0]) / (2 * d)
+    assert np.abs(dv - num).max() < 1e-8
+    atoms = fcc(rep=(2, 2, 2), a=3.6)
+    o = oracle_grap_eval(nn, atoms)
+    for (i, k) in [(0, 0), (5, 1), (17, 2)]:
+        e = []
+        for sgn in (1, -1):
+            a2 = atoms.copy()
+            p = a2.positions.copy(); p[i, k] += sgn * 1e-5
+            a2.positions = p
+            e.append(oracle_grap_eval(nn, a2)["energy"])
+        assert abs(o["forces"][i, k] + (e[0] - e[1]) / 2e-5) < 1e-6
