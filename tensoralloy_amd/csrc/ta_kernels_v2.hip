@@ -30,6 +30,9 @@
 // exact exp + cutoff evaluation, used for the polynomial cutoff or large beta).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "ta_device.h"
 #include "ta_math.h"
 #include "ta_reduce.h"
@@ -313,6 +316,16 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
   }
 }
 
+// Phase stagger (flags bits 8..15 = sleep count, bits 16..20 = shift): a launch whose workgroups
+// are all resident at once runs its memory-bound staging and its VALU-bound triple loop in lock
+// step; holding back every other group of workgroups for a few microseconds lets the two phases of
+// different workgroups overlap on a CU, as they do by themselves in many-frame batches.
+__device__ __forceinline__ void stagger(int flags) {
+  const int n = (flags >> 8) & 0xff;
+  if (n && ((blockIdx.x >> ((flags >> 16) & 31)) & 1))
+    for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);
+}
+
 // DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
@@ -320,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
                                                                DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int geom = flags & 1;
+  stagger(flags);
   extern __shared__ double lds[];
   const Fields f = carve(lds, b.cap);
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
@@ -492,8 +506,10 @@ template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
 // are constrained; the generic ones keep the compiler's choice.
 __global__ __launch_bounds__(kBlock)
     __attribute__((amdgpu_waves_per_eu(DEFZ ? (NSPEC == 1 ? 5 : 4) : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
-                                                             DeviceBatch b, int first) {
+                                                             DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
+  const int first = flags & 1;
+  stagger(flags);
   extern __shared__ double lds[];
   const int kCap = b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
@@ -743,6 +759,16 @@ size_t v2_lds_bytes(bool backward, int cap) {
     }                                                             \
   } while (0)
 
+// stagger flags for a launch: "<count>[,<shift>]" from the environment (experiment switch)
+static int stagger_bits(const DeviceBatch &b, const char *var) {
+  const char *e = getenv(var);
+  if (!e) return 0;
+  int n = 0, shift = 3;
+  if (sscanf(e, "%d,%d", &n, &shift) < 1) return 0;
+  (void)b;
+  return ((n & 0xff) << 8) | ((shift & 31) << 16);
+}
+
 // `ch` must describe ONE beta (nb == 1).
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           bool reduce, const DeviceBatch &b, hipStream_t s) {
@@ -750,7 +776,8 @@ void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz
   const int nspec = sf.n_elements;
   // bit 0: compute the pair geometry; bit 1: assemble the descriptors at the end; bit 2: this is
   // the only forward launch (all angular channels are here)
-  const int geom = (geometry ? 1 : 0) | (reduce ? 2 : 0) | ((geometry && reduce) ? 4 : 0);
+  const int geom = (geometry ? 1 : 0) | (reduce ? 2 : 0) | ((geometry && reduce) ? 4 : 0) |
+                   stagger_bits(b, "TA_STAGGER_FWD");
   TA_DISPATCH_V2(fwd_t, sf, ch, b, geom, s);
 }
 
@@ -758,7 +785,7 @@ void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, 
                         const DeviceBatch &b, hipStream_t s) {
   if (b.n_blk == 0) return;
   const int nspec = sf.n_elements;
-  const int f = first ? 1 : 0;
+  const int f = (first ? 1 : 0) | stagger_bits(b, "TA_STAGGER_BWD");
   TA_DISPATCH_V2(bwd_t, sf, ch, b, f, s);
 }
 
