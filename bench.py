@@ -107,8 +107,16 @@ def main():
         # torch first: its bundled HIP runtime must be the one the process shares
         import torch
         import torch.distributed as dist
+        # TA_BENCH_BACKEND=gloo rehearses several ranks on a box with fewer GPUs than ranks (ranks
+        # share devices; the all-reduce then goes through gloo): the driver's runs use nccl = RCCL
+        backend = os.environ.get("TA_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from tensoralloy_amd import Engine, _lib
     _lib.build()
