@@ -427,17 +427,26 @@ __global__ __launch_bounds__(kBlock) void eam_nn_pair_fast_kernel(EamParams P, c
       accv[nt] = {bb, bb, bb, bb};
       accd[nt] = {0.0, 0.0, 0.0, 0.0};
     }
-    for (int kk = 0; kk < H1 / 4; ++kk) {
-      const int ki = 4 * kk + kq;
-      const double wk = w1[ki];
-      double h, dh;
-      activation_fn(act, fma(wk, r, b1[ki]), h, dh);
-      dh *= wk;
+    // four k-steps per trip (H1 is a multiple of 16): four independent activation chains for the
+    // scheduler to interleave, then the MFMAs
+    for (int kk = 0; kk < H1 / 4; kk += 4) {
+      double h[4], dh[4];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const double B = W2[ki * s2 + 16 * nt + m];
-        accv[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, B, accv[nt], 0, 0, 0);
-        accd[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dh, B, accd[nt], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const int ki = 4 * (kk + j) + kq;
+        const double wk = w1[ki];
+        activation_fn(act, fma(wk, r, b1[ki]), h[j], dh[j]);
+        dh[j] *= wk;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ki = 4 * (kk + j) + kq;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const double B = W2[ki * s2 + 16 * nt + m];
+          accv[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(h[j], B, accv[nt], 0, 0, 0);
+          accd[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dh[j], B, accd[nt], 0, 0, 0);
+        }
       }
     }
     // accv[nt][q] = z2[pair kq + 4 q][unit 16 nt + m]

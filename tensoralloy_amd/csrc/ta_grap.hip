@@ -502,12 +502,21 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
     const int64_t p = t * kMlpTileRows + m;
     const bool valid = t < ntiles && p < b.n_pairs;
     const double x = valid ? sqrt(b.rec[kRecDoubles * (size_t)p + 3]) : 0.0;
-    for (int c = kq; c < net.np[0]; c += 4) {
-      const double wk = w0[c];
-      double h, dh;
-      activation_fn(act, fma(wk, x, b0[c]), h, dh);
-      Xv[m * net.xs + c] = h;
-      Xd[m * net.xs + c] = dh * wk;
+    // np[0] is a multiple of 16: four independent activation chains per trip
+    for (int c0 = kq; c0 < net.np[0]; c0 += 16) {
+      double h[4], dh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 4 * j;
+        const double wk = w0[c];
+        activation_fn(act, fma(wk, x, b0[c]), h[j], dh[j]);
+        dh[j] *= wk;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Xv[m * net.xs + c0 + 4 * j] = h[j];
+        Xd[m * net.xs + c0 + 4 * j] = dh[j];
+      }
     }
     __syncthreads();
     for (int l = 1; l < net.L; ++l) {
