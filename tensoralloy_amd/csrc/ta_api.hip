@@ -47,6 +47,10 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
                   hipStream_t s);
 void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
                  hipEvent_t *ev /* 2 events or null */);
+int64_t eam_param_count(const EamModel *);
+void eam_update_weights(EamModel *, const double *flat, int64_t n);
+void eam_energy_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, double *grad,
+                         hipStream_t s);
 }  // namespace ta
 
 namespace {
@@ -1129,6 +1133,10 @@ int ta_copy_batch_energy(ta_handle h, void *dst_device) {
 
 int ta_param_count(ta_handle h, int64_t *n_params) {
   if (!h || !n_params) return TA_ERR_INVALID;
+  if (h->eam) {  // the nn functions of an EAM / ADP model, slot after slot
+    *n_params = ta::eam_param_count(h->eam);
+    return TA_OK;
+  }
   if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
     return fail(h, TA_ERR_INVALID, "the model has no MLP");
   int64_t n = 0;
@@ -1139,6 +1147,11 @@ int ta_param_count(ta_handle h, int64_t *n_params) {
 
 int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights) {
   if (!h || !weights) return TA_ERR_INVALID;
+  if (h->eam)
+    return guarded(h, [&]() {
+      HIP_CHECK(hipStreamSynchronize(h->stream));  // nothing may still read the old weights
+      ta::eam_update_weights(h->eam, weights, n_weights);
+    });
   if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
     return fail(h, TA_ERR_INVALID, "the model has no MLP");
   return guarded(h, [&]() {
@@ -1173,6 +1186,24 @@ int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights) {
 int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int64_t n_grad) {
   if (!h || !frame_coeff || !grad) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (h->eam)
+    return guarded(h, [&]() {
+      const int64_t total = ta::eam_param_count(h->eam);
+      if (n_grad != total)
+        throw std::invalid_argument("ta_energy_gradient: expected room for " + std::to_string(total) + " values");
+      if (total == 0) return;
+      // every function depends on the weights: the forward pass runs again (rho, F', moments)
+      compute_impl(h, TA_WANT_ENERGY, false, nullptr);
+      hipStream_t s = h->stream;
+      const size_t F = (size_t)h->db.n_frames;
+      h->train_grad.ensure((size_t)total + 8);
+      h->train_coeff.ensure(F + 8);
+      if (F) HIP_CHECK(hipMemcpyAsync(h->train_coeff.ptr, frame_coeff, F * sizeof(double), hipMemcpyHostToDevice, s));
+      ta::eam_energy_gradient(h->eam, h->db, h->train_coeff.ptr, h->train_grad.ptr, s);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    });
   if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
     return fail(h, TA_ERR_INVALID, "the model has no MLP");
   return guarded(h, [&]() {

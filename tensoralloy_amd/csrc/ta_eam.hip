@@ -50,6 +50,14 @@ namespace ta {
 
 struct EamModel;
 void eam_destroy(EamModel *);
+// weight gradients (ta_train.hip)
+int mlp_param_count(const MlpDev &mlp);
+size_t mlp_grad_scratch_doubles(const MlpDev &mlp, int n_atoms);
+size_t mlp_grad_partial_doubles(const MlpDev &mlp, int n_atoms);
+void launch_mlp_grad_rows(const MlpDev &mlp, int activation, const int32_t *atoms, int n_rows,
+                          const double *x, const double *row_coeff, const int32_t *frame_of_atom,
+                          const double *frame_coeff, double *scratch, double *partial, double *grad,
+                          hipStream_t s);
 
 namespace {
 
@@ -670,6 +678,49 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
   }
 }
 
+// ---- weight gradients of the nn functions (training) ------------------------------
+// dL/dtheta = sum_f c_f dE_f/dtheta. For a per-pair network f of class rho / phi / u / w the energy
+// depends on theta only through f(r_p) of the pairs p it serves, so
+//   dL/dtheta = sum_p w_p df(r_p)/dtheta,  w_p = c[frame] dE/df_p:
+//   rho: F'(rho_i)   phi: 1/2   u: mu_i . D   w: D . Lambda_i . D     (i = centre of p; eam.py:353-355,
+//   adp.py:371-392, :458-492 differentiated). This kernel writes w_p for the pairs of one function
+//   (class, k) and 0 for all others; the MLP gradient kernel then runs over all pairs with these
+//   weights. Embedding networks: rows = atoms of the element, weight c[frame].
+__global__ __launch_bounds__(kBlock) void eam_grad_coeff_kernel(EamParams P, DeviceBatch b, int cls, int k,
+                                                                const double *__restrict__ frame_coeff,
+                                                                const double *__restrict__ dF,
+                                                                const double *__restrict__ mom,
+                                                                double *coeff) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= b.n_pairs) return;
+  const int nel = P.nel;
+  const int i = b.pair_i[p];
+  const int sA = b.species[i], sb = b.species[b.pair_j[p]];
+  const int key = cls == 0 ? sb : pair_type(sA, sb, nel);
+  double w = 0.0;
+  if (key == k) {
+    const double c = frame_coeff[b.frame_of_atom[i]];
+    if (cls == 0) {
+      w = c * dF[i];
+    } else if (cls == 1) {
+      w = 0.5 * c;
+    } else {
+      const double *rec = b.rec + kRecDoubles * (size_t)p;
+      const double dx = rec[0], dy = rec[1], dz = rec[2];
+      const double *m = mom + ((size_t)i * nel + sb) * 9;
+      if (cls == 2) {
+        w = c * (m[0] * dx + m[1] * dy + m[2] * dz);
+      } else {
+        const double lx = m[3] * dx + m[8] * dy + m[7] * dz;
+        const double ly = m[8] * dx + m[4] * dy + m[6] * dz;
+        const double lz = m[7] * dx + m[6] * dy + m[5] * dz;
+        w = c * (dx * lx + dy * ly + dz * lz);
+      }
+    }
+  }
+  coeff[p] = w;
+}
+
 // table of one nn function on caller-supplied abscissae (setfl export)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void eam_nn_table_kernel(const MlpDev *__restrict__ nets, int slot,
@@ -706,6 +757,9 @@ struct EamModel {
   double *pf = nullptr;           // [8 or 4][cap_pairs] value / derivative columns, then r [cap_pairs]
   size_t cap_pairs = 0;
   TabDev *tabs_dev = nullptr;     // [n_slots] tabulated functions (n == 0: none)
+  // training: per-pair weights, scratch and partial sums of the gradient kernels
+  double *gcoeff = nullptr, *gscratch = nullptr, *gpartial = nullptr;
+  size_t cap_gcoeff = 0, cap_gscratch = 0, cap_gpartial = 0;
   int fast_nt = 0;                // > 0: every pair function is 1 -> H1 -> 16 fast_nt -> 1 (fast kernel)
   size_t fast_lds = 0;
   NnFnList fns;                   // the pair functions that are nn functions
@@ -937,6 +991,9 @@ void eam_destroy(EamModel *m) {
   if (m->mom) (void)hipFree(m->mom);
   if (m->pf) (void)hipFree(m->pf);
   if (m->rho_buf) (void)hipFree(m->rho_buf);
+  if (m->gcoeff) (void)hipFree(m->gcoeff);
+  if (m->gscratch) (void)hipFree(m->gscratch);
+  if (m->gpartial) (void)hipFree(m->gpartial);
   for (double *d : m->owned) (void)hipFree(d);
   delete m;
 }
@@ -995,6 +1052,97 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
       table(slot_pair(nel, 2, pt), r, n_r, u_of_r + (size_t)pt * n_r);
       table(slot_pair(nel, 3, pt), r, n_r, w_of_r + (size_t)pt * n_r);
     }
+  }
+}
+
+// ---- training support: parameter vector = the nn slots in order, per layer W [in][out] then b [out] --
+int64_t eam_param_count(const EamModel *m) {
+  int64_t n = 0;
+  for (const MlpDev &net : m->nets)
+    if (net.n_layers) n += mlp_param_count(net);
+  return n;
+}
+
+void eam_update_weights(EamModel *m, const double *flat, int64_t n) {
+  if (n != eam_param_count(m)) throw std::invalid_argument("ta_update_weights: wrong number of values");
+  const double *src = flat;
+  for (MlpDev &md : m->nets) {
+    for (int l = 0; l < md.n_layers; ++l) {
+      MlpLayerDev &ly = md.layer[l];
+      std::vector<double> w((size_t)ly.kp * ly.np, 0.0), wt((size_t)ly.np * ly.kp, 0.0), bb(ly.np, 0.0);
+      for (int k = 0; k < ly.k; ++k)
+        for (int c = 0; c < ly.n; ++c) {
+          const double v = src[(size_t)k * ly.n + c];
+          w[(size_t)k * ly.np + c] = v;
+          wt[(size_t)c * ly.kp + k] = v;
+        }
+      src += (size_t)ly.k * ly.n;
+      for (int c = 0; c < ly.n; ++c) bb[c] = src[c];
+      src += ly.n;
+      if (hipMemcpy(ly.w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(ly.wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(ly.b, bb.data(), bb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("hipMemcpy of the EAM function networks failed");
+    }
+  }
+}
+
+namespace {
+void grow(double *&ptr, size_t &cap, size_t need) {
+  if (need <= cap) return;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  if (hipMalloc((void **)&ptr, need * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+  cap = need;
+}
+}  // namespace
+
+// grad (device, eam_param_count values) = sum_f frame_coeff[f] dE_f/dtheta; needs the forward pass of
+// eam_compute on this batch (dF, moments, rho, pair records) to have run with the current weights
+void eam_energy_gradient(EamModel *m, const DeviceBatch &b, const double *frame_coeff, double *grad,
+                         hipStream_t s) {
+  const int nel = m->p.nel, npair = nel * (nel + 1) / 2;
+  const int n_pairs = (int)b.n_pairs;
+  size_t scratch = 1, partial = 1;
+  for (int sl = 0; sl < m->n_slots; ++sl) {
+    const MlpDev &net = m->nets[sl];
+    if (!net.n_layers) continue;
+    const bool embed = sl >= nel && sl < 2 * nel;
+    const int rows = embed ? (int)b.n_atoms : n_pairs;
+    scratch = std::max(scratch, mlp_grad_scratch_doubles(net, rows));
+    partial = std::max(partial, mlp_grad_partial_doubles(net, rows));
+  }
+  grow(m->gscratch, m->cap_gscratch, scratch + 8);
+  grow(m->gpartial, m->cap_gpartial, partial + 8);
+  grow(m->gcoeff, m->cap_gcoeff, (size_t)n_pairs + 8);
+  const double *rbuf = m->pf ? m->pf + (size_t)(m->p.adp ? 8 : 4) * m->cap_pairs : nullptr;
+  size_t off = 0;
+  for (int sl = 0; sl < m->n_slots; ++sl) {
+    const MlpDev &net = m->nets[sl];
+    if (!net.n_layers) continue;
+    double *g = grad + off;
+    off += (size_t)mlp_param_count(net);
+    if (sl >= nel && sl < 2 * nel) {  // embedding network of element e: rows = its atoms, x = rho_i
+      const int e = sl - nel;
+      launch_mlp_grad_rows(net, m->activation, b.elem_atoms + b.elem_start[e],
+                           b.elem_start[e + 1] - b.elem_start[e], m->rho_buf, nullptr, b.frame_of_atom,
+                           frame_coeff, m->gscratch, m->gpartial, g, s);
+      continue;
+    }
+    int cls, k;
+    if (sl < nel) {
+      cls = 0;
+      k = sl;
+    } else {
+      cls = 1 + (sl - 2 * nel) / npair;
+      k = (sl - 2 * nel) % npair;
+    }
+    if (n_pairs > 0)
+      hipLaunchKernelGGL(eam_grad_coeff_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock),
+                         0, s, m->p, b, cls, k, frame_coeff, m->dF, m->mom, m->gcoeff);
+    launch_mlp_grad_rows(net, m->activation, nullptr, n_pairs, rbuf, m->gcoeff, nullptr, nullptr, m->gscratch,
+                         m->gpartial, g, s);
   }
 }
 

@@ -36,8 +36,11 @@ struct GradLayout {
 __global__ __launch_bounds__(kThreads) void mlp_grad_kernel(MlpDev mlp, GradLayout lay, int act, int ndim,
                                                             const int32_t *atoms, int n_atoms,
                                                             const double *G, const int32_t *frame_of_atom,
-                                                            const double *frame_coeff, double *scratch,
+                                                            const double *frame_coeff,
+                                                            const double *row_coeff, double *scratch,
                                                             double *partial, int stride) {
+  // rows: `atoms[.]` (null: the rows themselves); weight of a row: `row_coeff[row]` when given
+  // (per-pair networks of nn-EAM), else c[frame of the atom]
   extern __shared__ double lds[];
   double *buf0 = lds, *buf1 = lds + kMlpRows * stride;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void mlp_grad_kernel(MlpDev mlp, GradLayo
     const int row = idx / kp0, k = idx - row * kp0;
     double x = 0.0;
     if (row < nrows && k < ndim) {
-      x = G[(size_t)atoms[a0 + row] * ndim + k];
+      x = G[(size_t)(atoms ? atoms[a0 + row] : a0 + row) * ndim + k];
       if (mlp.xlo) {
         const double den = mlp.xhi[k] - mlp.xlo[k];
         x = (den != 0.0) ? (mlp.xhi[k] - x) / den : 0.0;
@@ -103,7 +106,10 @@ __global__ __launch_bounds__(kThreads) void mlp_grad_kernel(MlpDev mlp, GradLayo
   for (int idx = tid; idx < kMlpRows * npL; idx += kThreads) {
     const int row = idx / npL, col = idx - row * npL;
     double c = 0.0;
-    if (col == 0 && row < nrows) c = frame_coeff[frame_of_atom[atoms[a0 + row]]];
+    if (col == 0 && row < nrows) {
+      const int id = atoms ? atoms[a0 + row] : a0 + row;
+      c = row_coeff ? row_coeff[id] : frame_coeff[frame_of_atom[id]];
+    }
     cur[row * stride + col] = c;
   }
   __syncthreads();
@@ -211,7 +217,28 @@ void launch_mlp_grad(const MlpDev &mlp, int activation, int ndim, const int32_t 
   const size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
   const int blocks = std::min((n_atoms + kMlpRows - 1) / kMlpRows, kMaxBlocks);
   hipLaunchKernelGGL(mlp_grad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation,
-                     ndim, atoms, n_atoms, b.G, b.frame_of_atom, frame_coeff, scratch, partial, stride);
+                     ndim, atoms, n_atoms, b.G, b.frame_of_atom, frame_coeff, nullptr, scratch, partial, stride);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
+}
+
+// The same for a scalar-input network evaluated on rows x[0 .. n_rows) with one weight per row
+// (nn-EAM: rho / phi / u / w networks over the pairs); or, with `atoms`, on x[atoms[.]] weighted
+// by c[frame of the atom] (the embedding networks over the atoms of one element).
+void launch_mlp_grad_rows(const MlpDev &mlp, int activation, const int32_t *atoms, int n_rows,
+                          const double *x, const double *row_coeff, const int32_t *frame_of_atom,
+                          const double *frame_coeff, double *scratch, double *partial, double *grad,
+                          hipStream_t s) {
+  const GradLayout lay = make_layout(mlp);
+  if (n_rows == 0) {
+    (void)hipMemsetAsync(grad, 0, (size_t)lay.n_params * sizeof(double), s);
+    return;
+  }
+  const int stride = mlp_stride(mlp);
+  const size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
+  const int blocks = std::min((n_rows + kMlpRows - 1) / kMlpRows, kMaxBlocks);
+  hipLaunchKernelGGL(mlp_grad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation, 1,
+                     atoms, n_rows, x, frame_of_atom, frame_coeff, row_coeff, scratch, partial, stride);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
 }

@@ -21,12 +21,21 @@ import numpy as np
 from .parallel import shard_range, world_from_env
 
 
+def _networks(nn):
+    """The model's networks in the order of the C ABI's parameter vector, as (container, key):
+    per element for an `AtomicNN`; per nn-function slot (rho[element], embed[element], phi[pair],
+    dipole[pair], quadrupole[pair]) for an `EamAlloyNN` / `AdpNN`."""
+    if hasattr(nn, "nn_functions"):
+        return [(nn.weights[sec], fn) for sec, fn in (s for s in nn.nn_functions() if s is not None)]
+    return [(nn.weights, el) for el in nn.elements]
+
+
 def flatten_weights(nn) -> np.ndarray:
-    """Flat parameter vector in the C ABI's layout: per element (sorted), per layer W[in][out]
-    row-major then b[out] (zeros where the layer has no bias)."""
+    """Flat parameter vector in the C ABI's layout: per network (see `_networks`), per layer
+    W[in][out] row-major then b[out] (zeros where the layer has no bias)."""
     out = []
-    for el in nn.elements:
-        for w, b in nn.weights[el]:
+    for box, key in _networks(nn):
+        for w, b in box[key]:
             w = np.asarray(w, dtype=np.float64)
             out.append(w.ravel())
             out.append(np.zeros(w.shape[1]) if b is None else np.asarray(b, dtype=np.float64).ravel())
@@ -37,9 +46,11 @@ def unflatten_weights(nn, flat: np.ndarray) -> Dict[str, List]:
     """Inverse of `flatten_weights`; layers without a bias keep `None`."""
     flat = np.asarray(flat, dtype=np.float64)
     out, k = {}, 0
-    for el in nn.elements:
+    eam = hasattr(nn, "nn_functions")
+    names = [s for s in nn.nn_functions() if s is not None] if eam else [(None, el) for el in nn.elements]
+    for (box, key), (sec, _) in zip(_networks(nn), names):
         layers = []
-        for w, b in nn.weights[el]:
+        for w, b in box[key]:
             shape = np.shape(w)
             n = shape[0] * shape[1]
             w2 = flat[k:k + n].reshape(shape).copy()
@@ -47,15 +58,18 @@ def unflatten_weights(nn, flat: np.ndarray) -> Dict[str, List]:
             b2 = None if b is None else flat[k:k + shape[1]].copy()
             k += shape[1]
             layers.append((w2, b2))
-        out[el] = layers
+        if eam:
+            out.setdefault(sec, {})[key] = layers
+        else:
+            out[key] = layers
     return out
 
 
 def trainable_mask(nn) -> np.ndarray:
     """1 for real parameters, 0 for the bias slots of layers that have no bias."""
     out = []
-    for el in nn.elements:
-        for w, b in nn.weights[el]:
+    for box, key in _networks(nn):
+        for w, b in box[key]:
             shape = np.shape(w)
             out.append(np.ones(shape[0] * shape[1]))
             out.append(np.zeros(shape[1]) if b is None else np.ones(shape[1]))

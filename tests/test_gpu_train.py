@@ -139,3 +139,75 @@ def test_fit_with_forces_lowers_force_error(lib):
     tr.close()
     assert hist[-1]["forces"] < 0.5 * hist[0]["forces"]
     assert hist[-1]["total"] < 0.5 * hist[0]["total"]
+
+
+@pytest.mark.parametrize("kind", ["eam_ni", "eam_binary_mixed", "adp"])
+def test_nn_eam_weight_gradient(lib, kind):
+    """Gradient of sum_f c_f E_f with respect to the weights of the nn functions of an EAM / ADP
+    model (rho, phi, embed, dipole, quadrupole networks): against central differences of the ORACLE's
+    energies in single weights of every network, and `ta_update_weights` on the live handle."""
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import flatten_weights, trainable_mask, unflatten_weights
+    from tests.helpers import make_eam, oracle_eam_eval
+    if kind == "eam_ni":
+        nn = make_eam(["Ni"], 6.0, potential=None, hidden_sizes=[16, 8])
+        frames = [fcc(rep=(2, 2, 2)), fcc(rep=(2, 2, 3), a=3.4, seed=3)]
+    elif kind == "eam_binary_mixed":
+        pots = {"Ni": {"rho": "nn", "embed": "zjw04"}, "Mo": {"rho": "zjw04", "embed": "nn"},
+                "NiNi": {"phi": "zjw04"}, "MoNi": {"phi": "nn"}, "MoMo": {"phi": "nn"}}
+        nn = make_eam(["Mo", "Ni"], 6.0, potential=pots, hidden_sizes=[12])
+        frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))]
+    else:
+        nn = make_eam(["Mo", "Ni"], 5.5, adp=True, potential=None, hidden_sizes=[8, 8])
+        frames = [_alloy(["Ni", "Mo"], rep=(2, 2, 2))]
+    coeff = np.random.RandomState(2).randn(len(frames))
+    theta = flatten_weights(nn)
+    mask = trainable_mask(nn)
+    with Engine(nn) as eng:
+        eng.set_frames(frames)
+        assert eng.param_count() == len(theta)
+        g = eng.energy_gradient(coeff) * mask
+        # a second model's weights on the live handle
+        eng.update_weights(theta * 0.5)
+        e_half = eng.energies(reuse_descriptors=True)
+    half = unflatten_weights(nn, theta * 0.5)
+    saved = nn.weights
+    nn.weights = half
+    ref_half = np.array([oracle_eam_eval(nn, a)["energy"] for a in frames])
+    nn.weights = saved
+    assert np.abs(e_half - ref_half).max() < 1e-8 * max(1.0, np.abs(ref_half).max())
+
+    def oracle_loss(vec):
+        nn.weights = unflatten_weights(nn, vec)
+        try:
+            return sum(c * oracle_eam_eval(nn, a)["energy"] for a, c in zip(frames, coeff))
+        finally:
+            nn.weights = saved
+
+    rng = np.random.RandomState(5)
+    live = np.flatnonzero(mask)
+    picks = list(rng.choice(live, size=10, replace=False)) + [live[0], live[-1]]
+    scale = max(1.0, np.abs(g).max())
+    for k in picks:
+        d = 1e-5
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += d
+        tm[k] -= d
+        num = (oracle_loss(tp) - oracle_loss(tm)) / (2 * d)
+        assert abs(g[k] - num) < 2e-6 * scale, (k, g[k], num)
+
+
+def test_nn_eam_fit_recovers_teacher_energies(lib):
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import EnergyTrainer
+    from tests.helpers import make_eam
+    teacher = make_eam(["Ni"], 5.0, potential=None, hidden_sizes=[8], seed=1)
+    frames = [fcc(rep=(2, 2, 2), a=a, seed=k) for k, a in enumerate((3.4, 3.5, 3.6, 3.7))]
+    with Engine(teacher) as eng:
+        labels = [r["energy"] for r in eng.evaluate(frames)]
+    student = make_eam(["Ni"], 5.0, potential=None, hidden_sizes=[8], seed=2)
+    tr = EnergyTrainer(student, frames, labels, device=0, learning_rate=0.001)
+    hist = tr.fit(120)
+    tr.close()
+    # the RMSE loss has gradients of constant size near its minimum: Adam hovers around it
+    assert min(hist) < 0.15 * hist[0] and np.mean(hist[-20:]) < 0.4 * hist[0]
