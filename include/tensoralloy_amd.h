@@ -255,9 +255,10 @@ int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64
                      int32_t **i, int32_t **j, int32_t **shift /*[n][3]*/, int32_t **rev);
 void ta_free(void *p);
 
-/* --- training support: gradients with respect to the MLP weights ---------------
- * Parameter vector layout = `ta_model_desc.weights`: per element (sorted), per layer W[in][out]
- * row-major then b[out]. */
+/* --- training support: gradients with respect to the network weights -----------
+ * Parameter vector layout = `ta_model_desc.weights`: per element (sorted) -- for EAM / ADP models
+ * per nn-function slot (rho[element], embed[element], phi / dipole / quadrupole[pair]; analytic and
+ * tabulated slots hold nothing) --, per layer W[in][out] row-major then b[out]. */
 
 /* length of that vector */
 int ta_param_count(ta_handle h, int64_t *n_params);
