@@ -189,6 +189,56 @@ def nn_function(x, layers, act="softplus", resnet=False):
     return h[:, 0], dh[:, 0]
 
 
+def sutton90_rho(r, p):
+    """AgSutton90 (potentials/sutton90.py:47-100): rho = (a / r)^6, phi = (b / r)^12, F = -sqrt(rho)."""
+    f = (p["a"] / r) ** 6
+    return f, -6.0 * f / r
+
+
+def sutton90_phi(r, p):
+    f = (p["b"] / r) ** 12
+    return f, -12.0 * f / r
+
+
+def sutton90_embed(rho, p):
+    s = np.sqrt(rho)
+    return -s, -0.5 / s
+
+
+def _morse(r, d, g, r0):
+    e1 = np.exp(-g * (r - r0))
+    return d * (e1 * e1 - 2.0 * e1), 2.0 * d * g * (e1 - e1 * e1)   # generic.py:15-30, agrawal.py:20-32
+
+
+def agrawal_rho(r, p):
+    """AgrawalBe "Be/1" (potentials/agrawal.py:57-79)."""
+    e = p["A"] * np.exp(-p["B"] * (r - p["re"]))
+    ec = p["A"] * np.exp(-p["B"] * (p["rc"] - p["re"]))
+    x = r / p["rc"]
+    f = e - ec + p["rc"] / p["m"] * (1.0 - x ** p["m"]) * (-p["B"] * ec)
+    return f, -p["B"] * e + x ** (p["m"] - 1.0) * p["B"] * ec
+
+
+def agrawal_phi(r, p):
+    """agrawal.py:124-152."""
+    m0, dm0 = _morse(r, p["D"], p["alpha"], p["re"])
+    mc, dmc = _morse(p["rc"], p["D"], p["alpha"], p["re"])
+    x = r / p["rc"]
+    return m0 - mc + p["rc"] / p["m"] * (1.0 - x ** p["m"]) * dmc, dm0 - x ** (p["m"] - 1.0) * dmc
+
+
+def agrawal_embed(rho, p):
+    """agrawal.py:81-122."""
+    L = np.log(np.maximum(rho, 1e-12))
+    F = p["F0"] * (1.0 - p["beta"] * L) * rho ** p["beta"] + p["F1"] * rho ** p["gamma"]
+    dF = -p["F0"] * p["beta"] ** 2 * L * rho ** (p["beta"] - 1.0) + p["F1"] * p["gamma"] * rho ** (p["gamma"] - 1.0)
+    return F, dF
+
+
+OTHER = {"sutton90": (sutton90_rho, sutton90_phi, sutton90_embed),
+         "be/1": (agrawal_rho, agrawal_phi, agrawal_embed)}
+
+
 def spline_function(x, table):
     """Tabulated function (knots, values) as the natural cubic spline the reference builds with
     `CubicInterpolator(x, y, natural_boundary=True)` (potentials/tests/test_mishin.py:60-70), here
@@ -207,7 +257,7 @@ class EamModel:
     keyed by the sorted pair 'AB' (dict with d1..q3, h, rc)."""
 
     def __init__(self, elements, rcut, params=None, adp=None, blended_embed=False, phi_pairs=None,
-                 nets=None, activation="softplus", tables=None):
+                 nets=None, activation="softplus", tables=None, other=None):
         self.elements = sorted(set(elements))
         self.rcut = float(rcut)
         # "nn" functions: {'rho': {el: layers}, 'embed': {el: layers}, 'phi': {'AB': layers},
@@ -217,6 +267,8 @@ class EamModel:
         self.activation = activation
         # tabulated functions, same nesting: {'rho': {el: (x, y)}, 'phi': {'AB': (x, y)}, ...}
         self.tables = tables or {}
+        # elements whose analytic functions are sutton90 / Be/1: {el: (kind, constants dict)}
+        self.other = other or {}
         self.params = params if params is not None else {
             e: dict(ZJW04[e]) for e in self.elements if e in ZJW04}
         self.adp = adp  # {'NiNi': {...}} or None
@@ -247,6 +299,8 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
             rho_pair[m], drho_pair[m] = spline_function(r[m], model.tables["rho"][eb])
         elif eb in model.nets.get("rho", {}):
             rho_pair[m], drho_pair[m] = nn_function(r[m], model.nets["rho"][eb], model.activation)
+        elif eb in model.other:
+            rho_pair[m], drho_pair[m] = OTHER[model.other[eb][0]][0](r[m], model.other[eb][1])
         else:
             rho_pair[m], drho_pair[m] = zjw04_rho(r[m], model.params[eb])  # neighbour's element, alloy.py:176
         for a, ea in enumerate(els):
@@ -256,6 +310,8 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
                 phi_pair[mm], dphi_pair[mm] = spline_function(r[mm], model.tables["phi"][key])
             elif key in model.nets.get("phi", {}):
                 phi_pair[mm], dphi_pair[mm] = nn_function(r[mm], model.nets["phi"][key], model.activation)
+            elif a == b and ea in model.other:
+                phi_pair[mm], dphi_pair[mm] = OTHER[model.other[ea][0]][1](r[mm], model.other[ea][1])
             elif a != b and key in model.phi_pairs:
                 phi_pair[mm], dphi_pair[mm] = zjw04xcp_phi_ab(r[mm], model.phi_pairs[key])
             else:
@@ -273,6 +329,9 @@ def evaluate(model: EamModel, symbols, positions, cell, pbc, eps=EPS64):
             continue
         if ea in model.nets.get("embed", {}):
             F[m], dF[m] = nn_function(rho[m], model.nets["embed"][ea], model.activation)
+            continue
+        if ea in model.other:
+            F[m], dF[m] = OTHER[model.other[ea][0]][2](rho[m], model.other[ea][1])
             continue
         embed = zjw04xc_embed if model.blended_embed else zjw04_embed
         F[m], dF[m] = embed(rho[m], model.params[ea])

@@ -69,6 +69,9 @@ struct EamParams {
   int nel;
   int adp;
   int embed_kind[kMaxEamElements];  // 0: piecewise (Zjw04), 1: sigmoid-blended (Zjw04xc)
+  int el_kind[kMaxEamElements];     // potential of the element's analytic rho / embed / phi_AA:
+                                    // 0 Zjw04 family, 1 AgSutton90 (el = {a, b}), 2 AgrawalBe "Be/1"
+                                    // (el = {A, B, D, alpha, re, F0, F1, beta, gamma, m, rc})
   int phi_kind[kMaxPairTypes];      // 0: Zjw04 (AA, or AB by density mixing), 1: own constants (Zjw04xcp)
   double el[kMaxEamElements][20];   // ZJW04_KEYS order (tensoralloy_amd/eam.py)
   double phi[kMaxPairTypes][7];     // r_eq A B alpha beta kappa lamda of a Zjw04xcp cross term
@@ -209,6 +212,73 @@ __device__ __forceinline__ void zjw_embed(const double *p, int kind, double rho,
   }
 }
 
+// ---- the other empirical potentials of the reference's `available_potentials` ---------------------
+// AgSutton90 (potentials/sutton90.py:47-100): rho = (a / r)^6, phi = (b / r)^12, F = -sqrt(rho).
+// AgrawalBe "Be/1" (potentials/agrawal.py:57-152): with s(r) = (rc / m) (1 - (r / rc)^m),
+//   rho = A e^{-B (r - re)} - A e^{-B (rc - re)} - s(r) A B e^{-B (rc - re)},
+//   phi = M(r) - M(rc) + s(r) M'(rc),  M = Morse(D, alpha, re) (generic.py:15-30, agrawal.py:20-32),
+//   F = F0 (1 - beta ln max(rho, 1e-12)) rho^beta + F1 rho^gamma.
+enum { AG_A = 0, AG_B, AG_D, AG_ALPHA, AG_RE, AG_F0, AG_F1, AG_BETA, AG_GAMMA, AG_M, AG_RC };
+
+__device__ __forceinline__ void morse_fn(double r, double d, double g, double r0, double &f, double &df) {
+  const double e1 = exp(-g * (r - r0)), e2 = e1 * e1;
+  f = d * (e2 - 2.0 * e1);
+  df = 2.0 * d * g * (e1 - e2);
+}
+
+__device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, double &f, double &df) {
+  const double *p = P.el[e];
+  if (P.el_kind[e] == 1) {
+    const double t = p[0] / r, t2 = t * t;
+    f = t2 * t2 * t2;
+    df = -6.0 * f / r;
+  } else if (P.el_kind[e] == 2) {
+    const double ev = p[AG_A] * exp(-p[AG_B] * (r - p[AG_RE]));
+    const double ec = p[AG_A] * exp(-p[AG_B] * (p[AG_RC] - p[AG_RE]));
+    const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
+    f = ev - ec - p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * p[AG_B] * ec;
+    df = -p[AG_B] * ev + xm1 * p[AG_B] * ec;
+  } else {
+    zjw_rho(p, r, f, df);
+  }
+}
+
+__device__ __forceinline__ void pair_phi(const EamParams &P, int sa, int sb, double r, double &f, double &df) {
+  const int kind = sa == sb ? P.el_kind[sa] : 0;
+  if (kind == 1) {
+    const double t = P.el[sa][1] / r, t2 = t * t, t4 = t2 * t2;
+    f = t4 * t4 * t4;
+    df = -12.0 * f / r;
+  } else if (kind == 2) {
+    const double *p = P.el[sa];
+    double m0, dm0, mc, dmc;
+    morse_fn(r, p[AG_D], p[AG_ALPHA], p[AG_RE], m0, dm0);
+    morse_fn(p[AG_RC], p[AG_D], p[AG_ALPHA], p[AG_RE], mc, dmc);
+    const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
+    f = m0 - mc + p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * dmc;
+    df = dm0 - xm1 * dmc;
+  } else {
+    zjw_phi(P, sa, sb, r, f, df);
+  }
+}
+
+__device__ __forceinline__ void el_embed(const EamParams &P, int e, double rho, double &F, double &dF) {
+  const double *p = P.el[e];
+  if (P.el_kind[e] == 1) {
+    const double s = sqrt(rho);
+    F = -s;
+    dF = -0.5 / s;
+  } else if (P.el_kind[e] == 2) {
+    const double L = log(fmax(rho, 1e-12));
+    const double xb = pow(rho, p[AG_BETA] - 1.0), yg = pow(rho, p[AG_GAMMA] - 1.0);
+    F = p[AG_F0] * (1.0 - p[AG_BETA] * L) * xb * rho + p[AG_F1] * yg * rho;
+    dF = -p[AG_F0] * p[AG_BETA] * p[AG_BETA] * L * xb + p[AG_F1] * p[AG_GAMMA] * yg;
+  } else {
+    zjw_embed(p, P.embed_kind[e], rho, F, dF);
+  }
+}
+
+
 // (p1 exp(-p2 r) + p3) psi((r - rc)/h), psi(x) = x^4/(1+x^4) for x < 0  (generic.py:52-84)
 __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, double p3, double rc,
                                              double h, double &f, double &df) {
@@ -282,11 +352,11 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // density function of the NEIGHBOUR's element (alloy.py:176)
       if (rho_nn) f = pf[PF_RHO * ps + q];
       else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
-      else zjw_rho(P.el[sb], r, f, df);
+      else el_rho(P, sb, r, f, df);
       rho += f;
       if (phi_nn) f = pf[PF_PHI * ps + q];
       else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, df);
-      else zjw_phi(P, sA, sb, r, f, df);
+      else pair_phi(P, sA, sb, r, f, df);
       phis += f;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
@@ -340,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     } else {
       double F, d;
       if ((P.tab_embed >> sA) & 1u) spline_eval(tabs[slot_embed(nel, sA)], rho, F, d);
-      else zjw_embed(P.el[sA], P.embed_kind[sA], rho, F, d);
+      else el_embed(P, sA, rho, F, d);
       b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
       dF[i] = d;
     }
@@ -581,10 +651,10 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const int pt = pair_type(sA, sa, nel);
   if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
   else if ((P.tab_rho >> sa) & 1u) spline_eval(tabs[slot_rho(sa)], r, f, drho);
-  else zjw_rho(P.el[sa], r, f, drho);
+  else el_rho(P, sa, r, f, drho);
   if ((P.nn_phi >> pt) & 1u) dphi = pf[PF_DPHI * ps + p];
   else if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, dphi);
-  else zjw_phi(P, sA, sa, r, f, dphi);
+  else pair_phi(P, sA, sa, r, f, dphi);
   // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
   double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
   double gx = c * dx, gy = c * dy, gz = c * dz;
@@ -642,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     double f, df;
     if (row < nel) {
       if ((P.tab_rho >> row) & 1u) spline_eval(tabs[slot_rho(row)], x, f, df);
-      else zjw_rho(P.el[row], x, f, df);
+      else el_rho(P, row, x, f, df);
       rho_of_r[(size_t)row * n_r + k] = f;
     } else {
       const int pt = row - nel;
@@ -653,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
       }
       const int b2 = a + rem;
       if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], x, f, df);
-      else zjw_phi(P, a, b2, x, f, df);
+      else pair_phi(P, a, b2, x, f, df);
       phi_of_r[(size_t)pt * n_r + k] = f;
       if (P.adp && u_of_r && w_of_r) {
         const double *pp = P.pair[pt];
@@ -673,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     const int row = (int)(j / n_rho), k = (int)(j % n_rho);
     double F, dF;
     if ((P.tab_embed >> row) & 1u) spline_eval(tabs[slot_embed(nel, row)], rho[k], F, dF);
-    else zjw_embed(P.el[row], P.embed_kind[row], rho[k], F, dF);
+    else el_embed(P, row, rho[k], F, dF);
     embed_of_rho[(size_t)row * n_rho + k] = F;
   }
 }
@@ -844,8 +914,8 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   const int nel = m->n_elements;
   const bool adp = m->kind == TA_MODEL_EAM_ADP;
   const int npair = nel * (nel + 1) / 2;
-  // per element 20 Zjw04 constants + embed kind; per pair phi kind + 7 constants; ADP: + 8 per pair
-  const int need = nel * 21 + npair * 8 + (adp ? npair * 8 : 0);
+  // per element 20 constants + embed kind + potential kind; per pair phi kind + 7 constants; ADP: + 8 per pair
+  const int need = nel * 22 + npair * 8 + (adp ? npair * 8 : 0);
   if (!m->eam_params || m->n_eam_params != need) {
     err = "eam_params must hold " + std::to_string(need) + " doubles for this model";
     return nullptr;
@@ -957,10 +1027,17 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     }
   }
   for (int k = 0; k < nel; ++k) {
-    for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 21 + c];
-    e->p.embed_kind[k] = m->eam_params[k * 21 + 20] != 0.0 ? 1 : 0;
+    for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 22 + c];
+    e->p.embed_kind[k] = m->eam_params[k * 22 + 20] != 0.0 ? 1 : 0;
+    const int kind = (int)m->eam_params[k * 22 + 21];
+    if (kind < 0 || kind > 2) {
+      eam_destroy(e);
+      err = "unknown empirical potential kind";
+      return nullptr;
+    }
+    e->p.el_kind[k] = kind;
   }
-  const double *pp = m->eam_params + nel * 21;
+  const double *pp = m->eam_params + nel * 22;
   for (int k = 0; k < npair; ++k) {
     e->p.phi_kind[k] = pp[k * 8] != 0.0 ? 1 : 0;
     for (int c = 0; c < 7; ++c) e->p.phi[k][c] = pp[k * 8 + 1 + c];
@@ -977,7 +1054,8 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     if (!adp || e->p.pair[k][6] == 0.0) e->p.pair[k][6] = 1.0;  // h: avoid 0/0 for absent terms
   }
   for (int k = 0; k < nel; ++k)
-    if (!(e->p.el[k][R_EQ] > 0.0) || !(e->p.el[k][RHO_E] > 0.0) || !(e->p.el[k][RHO_S] > 0.0)) {
+    if (e->p.el_kind[k] == 0 &&
+        (!(e->p.el[k][R_EQ] > 0.0) || !(e->p.el[k][RHO_E] > 0.0) || !(e->p.el[k][RHO_S] > 0.0))) {
       eam_destroy(e);
       err = "r_eq, rho_e and rho_s must be positive";
       return nullptr;

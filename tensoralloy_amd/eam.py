@@ -5,7 +5,8 @@ analytic-potential hot path:
   EamAlloyNN  <- reference tensoralloy/nn/eam/alloy.py:24-127 (+ EamNN, eam.py:78-130)
   AdpNN       <- reference tensoralloy/nn/eam/adp.py (dipole / quadrupole terms)
 
-Supported potentials: the Zhou-Johnson-Wadley family for rho / embed / phi --
+Supported potentials: `sutton90` (AgSutton90) and `Be/1` (AgrawalBe) for single-element rho / embed /
+phi, and the Zhou-Johnson-Wadley family for rho / embed / phi --
 `zjw04` (nn/eam/potentials/zjw04.py:155-412), `zjw04xc` / `zjw04uxc` (sigmoid-
 blended embedding, :415-568; the two differ only in which constants are
 trainable) and `zjw04xcp` (own constants for cross-element phi, :571-696) -- and
@@ -22,7 +23,8 @@ symbol or sorted pair key, and are written to / read from `<stem>.npz` under
 `<section>/<function>/weights_<j>`, `.../biases_<j>`.
 
 Flat parameter block handed to the C ABI (`ta_model_desc.eam_params`):
-  per element (sorted): 20 doubles in `ZJW04_KEYS` order + embed kind (0 / 1);
+  per element (sorted): 20 doubles in `ZJW04_KEYS` order (sutton90: a, b; Be/1: `AGRAWAL_KEYS`) +
+  embed kind (0 / 1) + potential kind (0 Zjw04 family, 1 sutton90, 2 Be/1);
   per unordered element pair (a <= b, row-major upper triangle): phi kind
   (0 = Zjw04, 1 = Zjw04xcp constants) + [r_eq, A, B, alpha, beta, kappa, lamda];
   for ADP, per pair: 8 doubles [d1, d2, d3, q1, q2, q3, h, rc] (all zero = none).
@@ -70,6 +72,14 @@ ZJW04_DEFAULTS = {
 }
 
 ZJW04_FAMILY = ("zjw04", "zjw04xc", "zjw04uxc", "zjw04xcp")
+# the other eam/alloy members of the reference's `available_potentials` (potentials/__init__.py:20-30):
+# AgSutton90 (sutton90.py:37-44) and AgrawalBe "Be/1" (agrawal.py:49-55); constants as published there
+OTHER_POTENTIALS = ("sutton90", "be/1")
+SUTTON90_DEFAULTS = {"Ag": {"a": 2.928323832, "b": 2.485883762}}   # 'Ag': a, 'AgAg': b
+AGRAWAL_KEYS = ["A", "B", "D", "alpha", "re", "F0", "F1", "beta", "gamma", "m", "rc"]
+AGRAWAL_DEFAULTS = {"Be": dict(A=1.597, B=9.49713, D=0.41246, alpha=0.36324, re=2.29, F0=-2.0393,
+                               F1=12.6178, beta=0.18752, gamma=-2.28827, m=10.0, rc=5.0)}
+EL_KIND = {"zjw": 0, "sutton90": 1, "be/1": 2}
 PHI_KEYS = ["r_eq", "A", "B", "alpha", "beta", "kappa", "lamda"]
 # Zjw04xcp refits (reference nn/eam/potentials/zjw04.py:608-633; the later assignment wins)
 _XCP_KEYS = ["A", "B", "F0", "F1", "F2", "F3", "Fe", "Fn0", "Fn1", "Fn2", "Fn3", "alpha", "beta",
@@ -179,20 +189,39 @@ class EamAlloyNN:
         family = set()
         for key, sec in pots.items():
             for fn, name in sec.items():
-                ok = {"rho": ZJW04_FAMILY, "embed": ZJW04_FAMILY, "phi": ZJW04_FAMILY,
+                eam_ok = ZJW04_FAMILY + OTHER_POTENTIALS
+                ok = {"rho": eam_ok, "embed": eam_ok, "phi": eam_ok,
                       "dipole": ("mishinh",), "quadrupole": ("mishinh",)}[fn]
                 if str(name).lower() == "nn" or str(name).startswith("spline@"):
                     continue
                 if str(name).lower() not in ok:
                     raise ValueError(f"potential '{name}' for {key}/{fn} is not implemented by "
                                      f"tensoralloy_amd (available: {ok})")
-                if fn in ("rho", "embed", "phi"):
+                if fn in ("rho", "embed", "phi") and str(name).lower() in ZJW04_FAMILY:
                     family.add(str(name).lower())
         if len(family) > 1:
             # every reference potential object carries its own constants per element; mixing
             # them inside one model needs per-function parameter sets, which the kernels lack
             raise ValueError(f"one Zjw04 variant per model, got {sorted(family)}")
         self._family = family.pop() if family else "zjw04"
+        # the analytic rho, embed and same-element phi of one element share one constant block in
+        # the kernels: they must come from one potential (Zjw04 family, sutton90 or Be/1); a
+        # cross-element analytic phi exists only in the Zjw04 family (mixing rule / xcp constants)
+        self._el_kind = {}
+        for el in self._elements:
+            names = {str(pots[el][fn]).lower() for fn in ("rho", "embed")} | {str(pots[el + el]["phi"]).lower()}
+            kinds = {("zjw" if n in ZJW04_FAMILY else n) for n in names if n != "nn" and not n.startswith("spline@")}
+            if len(kinds) > 1:
+                raise ValueError(f"the analytic functions of {el} mix potentials {sorted(kinds)}; use one")
+            self._el_kind[el] = kinds.pop() if kinds else "zjw"
+        for term in self._unique_kbody_terms:
+            a, b = get_elements_from_kbody_term(term)
+            name = str(pots[term]["phi"]).lower()
+            if a != b and name in OTHER_POTENTIALS:
+                raise ValueError(f"{name} has no cross-element pair potential ({term})")
+            if a != b and name in ZJW04_FAMILY and name != "zjw04xcp" and \
+                    (self._el_kind[a] != "zjw" or self._el_kind[b] != "zjw"):
+                raise ValueError(f"the Zjw04 mixing rule for {term} needs Zjw04 constants of both elements")
         return pots
 
     # -- reference-compatible surface ----------------------------------------------
@@ -329,6 +358,18 @@ class EamAlloyNN:
         """'zjw04', 'zjw04xc', 'zjw04uxc' or 'zjw04xcp'."""
         return self._family
 
+    def other_parameters(self, el: str) -> Dict[str, float]:
+        """Constants of an element whose analytic functions are sutton90 or Be/1."""
+        kind = self._el_kind[el]
+        table, keys = (SUTTON90_DEFAULTS, ["a", "b"]) if kind == "sutton90" else (AGRAWAL_DEFAULTS, AGRAWAL_KEYS)
+        p = dict(table.get(el, {}))
+        p.update({k: v for k, v in self._parameters.get(el, {}).items() if k in keys})
+        p.update({k: v for k, v in self._parameters.get(el + el, {}).items() if k in keys})
+        missing = [k for k in keys if k not in p]
+        if missing:
+            raise ValueError(f"{kind} has no constants for {el} (missing {missing}); pass parameters=")
+        return p
+
     def element_parameters(self, el: str) -> Dict[str, float]:
         # defaults per variant: zjw04.py:19-152; Zjw04xc adds Be := Mo (:436-438);
         # Zjw04xcp refits Ni and Mo (:608-633)
@@ -380,9 +421,16 @@ class EamAlloyNN:
         out = []
         embed_kind = 0.0 if self._family == "zjw04" else 1.0
         for el in self._elements:
-            p = self.element_parameters(el)
-            out.extend(p[k] for k in ZJW04_KEYS)
+            kind = self._el_kind[el]
+            if kind == "zjw":
+                p = self.element_parameters(el)
+                out.extend(p[k] for k in ZJW04_KEYS)
+            else:
+                q = self.other_parameters(el)
+                vals = [q[k] for k in (["a", "b"] if kind == "sutton90" else AGRAWAL_KEYS)]
+                out.extend(vals + [0.0] * (20 - len(vals)))
             out.append(embed_kind)
+            out.append(float(EL_KIND[kind]))
         n = len(self._elements)
         for i in range(n):
             for j in range(i, n):

@@ -112,8 +112,9 @@ class SetFL:
 
 def _read_setfl(filename: str, is_adp: bool) -> SetFL:
     opener = gzip.open if str(filename).endswith(".gz") else open
-    with opener(filename, "rt") as fp:
-        lines = fp.read().split("\n")
+    with opener(filename, "rb") as fp:
+        # some published tables have "\r\r\n" line ends (Be_Agrawal.eam.alloy): drop every \r
+        lines = fp.read().decode("utf-8", "replace").replace("\r", "").split("\n")
     head = lines[3].split()
     n_el = int(head[0])
     elements = head[1:1 + n_el]

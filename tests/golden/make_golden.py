@@ -193,6 +193,28 @@ def main():
     with gzip.GzipFile(os.path.join(HERE, "AlCu_thinned.adp.gz"), "wb", mtime=0) as fo:
         fo.write("".join(adp_lines).encode())
 
+    # Agrawal's Be table (the LAMMPS side of potentials/tests/test_agrawal.py:52-58): rho(r) and
+    # r phi(r) at every 5th knot; F(rho) in full (it is singular at rho = 0, and the ringing of
+    # a natural spline around that knot dies out by a factor 0.27 per interval: with fewer knots it
+    # would reach the densities that occur)
+    with open(f"{REF}/test_files/lammps/Be_Agrawal.eam.alloy", "rb") as fp:
+        raw = fp.read().decode().replace("\r", "").split("\n")
+    nrho_b, drho_b, nr_b, dr_b, rc_b = raw[4].split()[:5]
+    nrho_b, nr_b, drho_b, dr_b = int(nrho_b), int(nr_b), float(drho_b), float(dr_b)
+    tok = " ".join(raw[6:]).split()
+    F_b = np.array(tok[:nrho_b], dtype=float)
+    rho_b = np.array(tok[nrho_b:nrho_b + nr_b], dtype=float)
+    rphi_b = np.array(tok[nrho_b + nr_b:nrho_b + 2 * nr_b], dtype=float)
+    k = 5
+    be_lines = ["Be, Agrawal et al., Modelling Simul. Mater. Sci. Eng. 2013 (Be_Agrawal.eam.alloy)\n",
+                "thinned by tests/golden/make_golden.py (r tables: every 5th knot)\n", "\n", "1 Be\n",
+                f"{nrho_b} {drho_b!r} {nr_b // k} {dr_b * k!r} {float(rc_b)!r}\n", raw[5].strip() + "\n"]
+    be_lines += ["%.10e\n" % v for v in F_b]
+    for arr in (rho_b, rphi_b):
+        be_lines += ["%.16e\n" % v for v in arr[::k]]
+    with gzip.GzipFile(os.path.join(HERE, "Be_Agrawal_thinned.eam.alloy.gz"), "wb", mtime=0) as fo:
+        fo.write("".join(be_lines).encode())
+
     # ---- 7. Reference-generated Hessian of Zjw04 Ni (nn/constraint/tests/test_fc2.py:29-54)
     #         with the structure it was computed for (test_files/crystals/Ni_sc.cif, P1)
     fc2 = np.load(f"{REF}/test_files/crystals/Ni_fc2.npy")

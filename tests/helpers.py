@@ -14,6 +14,15 @@ def fcc(symbol="Ni", a=3.524, rep=(2, 2, 2), jitter=0.05, seed=611):
                  cell=np.diag([a * rep[0], a * rep[1], a * rep[2]]), pbc=True)
 
 
+def hcp(symbol="Be", a=2.29, c=3.58, rep=(3, 3, 2), jitter=0.1, seed=0):
+    cell = np.array([[a, 0, 0], [-a / 2, a * np.sqrt(3) / 2, 0], [0, 0, c]])
+    basis = np.array([[0, 0, 0], [1 / 3, 2 / 3, 0.5]])
+    pts = np.array([(b + np.array([i, j, k])) @ cell for i in range(rep[0]) for j in range(rep[1])
+                    for k in range(rep[2]) for b in basis])
+    pts = pts + np.random.RandomState(seed).randn(*pts.shape) * jitter
+    return Atoms(symbols=[symbol] * len(pts), positions=pts, cell=cell * np.array(rep)[:, None], pbc=True)
+
+
 def pd3o2():
     return Atoms(symbols="Pd3O2", pbc=[True, True, False],
                  cell=np.array([[7.78, 0., 0.], [0., 5.50129076, 0.], [0., 0., 15.37532269]]),
@@ -127,8 +136,9 @@ def oracle_eam_eval(nn, atoms):
                 phi_pairs[a + b] = q
     if isinstance(nn, AdpNN) and not adp:
         adp = {}
-    m = EamModel(nn.elements, nn.transformer.rcut,
-                 params={el: nn.element_parameters(el) for el in nn.elements}, adp=adp,
+    other = {el: (nn._el_kind[el], nn.other_parameters(el)) for el in nn.elements if nn._el_kind[el] != "zjw"}
+    m = EamModel(nn.elements, nn.transformer.rcut, other=other,
+                 params={el: nn.element_parameters(el) for el in nn.elements if el not in other}, adp=adp,
                  blended_embed=nn.family != "zjw04", phi_pairs=phi_pairs, nets=nets,
                  activation=nn._activation, tables=tables)
     eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14

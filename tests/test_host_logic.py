@@ -207,7 +207,7 @@ def test_model_file_roundtrip(tmp_path):
     p = e.export(str(tmp_path / "adp"))
     e2, _, _ = load_model(p)
     assert e2.as_dict() == e.as_dict()
-    assert np.array_equal(e2.flat_parameters(), e.flat_parameters()) and len(e.flat_parameters()) == 2 * 21 + 3 * 8 + 3 * 8
+    assert np.array_equal(e2.flat_parameters(), e.flat_parameters()) and len(e.flat_parameters()) == 2 * 22 + 3 * 8 + 3 * 8
     with pytest.raises(ValueError):
         load_model(str(tmp_path / "missing.pb"))
     (tmp_path / "bad.json").write_text(json.dumps({"format": "other"}))
@@ -223,7 +223,13 @@ def test_model_argument_checks():
     with pytest.raises(ValueError):
         SymmetryFunction(["Ni"], cutoff_function="tanh")
     with pytest.raises(ValueError):
-        EamAlloyNN(["Ni"], custom_potentials="sutton90")
+        EamAlloyNN(["Ni"], custom_potentials="msah11")                     # an eam/fs potential
+    with pytest.raises(ValueError, match="no constants"):
+        EamAlloyNN(["Ni"], custom_potentials="sutton90").flat_parameters() # AgSutton90 knows Ag only
+    ag = EamAlloyNN(["Ag"], custom_potentials="sutton90")
+    assert list(ag.flat_parameters()[:2]) == [2.928323832, 2.485883762] and ag.flat_parameters()[21] == 1.0
+    with pytest.raises(ValueError, match="mix potentials"):
+        EamAlloyNN(["Ag"], custom_potentials={"Ag": {"rho": "sutton90", "embed": "zjw04"}, "AgAg": {"phi": "sutton90"}})
     d = EamAlloyNN(["Mo", "Ni"])                                          # default: all "nn" (alloy.py:110-112)
     assert d.potentials == {"Mo": {"rho": "nn", "embed": "nn"}, "Ni": {"rho": "nn", "embed": "nn"},
                             "MoMo": {"phi": "nn"}, "MoNi": {"phi": "nn"}, "NiNi": {"phi": "nn"}}
@@ -250,8 +256,8 @@ def test_model_argument_checks():
     xcp = EamAlloyNN(["Mo", "Ni"], custom_potentials="zjw04xcp")
     assert xcp.element_parameters("Ni")["rho_e"] == 25.423122           # the refit, zjw04.py:621-626
     flat = xcp.flat_parameters()
-    assert len(flat) == 2 * 21 + 3 * 8 and flat[20] == 1.0 and flat[41] == 1.0
-    assert list(flat[42:50]) == [0.0] * 8 and flat[50] == 1.0 and flat[51] == 2.235219
+    assert len(flat) == 2 * 22 + 3 * 8 and flat[20] == 1.0 and flat[42] == 1.0 and flat[21] == 0.0
+    assert list(flat[44:52]) == [0.0] * 8 and flat[52] == 1.0 and flat[53] == 2.235219
     nn = AtomicNN(["Ni"], SymmetryFunction(["Ni"]), hidden_sizes=[4])
     with pytest.raises(ValueError):
         nn.ndim()                                                         # no transformer attached
