@@ -101,3 +101,35 @@ def test_grap_models(lib, seed):
     with Engine(nn) as eng:
         res = eng.evaluate(frames)
     _check(res, [oracle_grap_eval(nn, a) for a in frames])
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_nn_functions_and_tables(lib, seed, tmp_path):
+    """nn-EAM / nn-ADP with random shapes and activations, mixed with analytic and tabulated
+    functions, and the GRAP filter network: random triclinic frames, uneven batches."""
+    from tensoralloy_amd import Engine
+    from tests.helpers import golden_setfl
+    rng = np.random.RandomState(4000 + seed)
+    if seed == 4:
+        elements = ["Mo", "Ni"]
+        par = {"hidden_sizes": [int(rng.randint(8, 40)) for _ in range(rng.randint(1, 4))],
+               "num_filters": int(rng.randint(3, 20)), "activation": "softplus", "use_resnet_dt": True}
+        nn = make_grap_nn(elements, rng.uniform(4.0, 5.5), [16], "nn", par, moment_tensors=[0, 1, 2, 3])
+        frames = [_random_frame(rng, elements) for _ in range(3)]
+        with Engine(nn) as eng:
+            res = eng.evaluate(frames)
+        _check(res, [oracle_grap_eval(nn, a) for a in frames])
+        return
+    elements = [["Ni"], ["Mo", "Ni"], ["Al", "Cu"], ["Al", "Cu", "Ni"]][seed]
+    hs = [int(rng.randint(4, 70)) for _ in range(rng.randint(1, 4))]
+    pots = None
+    if seed == 2:   # tabulated + nn + analytic in one model
+        path = golden_setfl("Zhou_AlCu.alloy.eam", tmp_path)
+        pots = {"Al": {"rho": "spline@" + path, "embed": "nn"}, "Cu": {"rho": "nn", "embed": "zjw04"},
+                "AlAl": {"phi": "nn"}, "AlCu": {"phi": "spline@" + path}, "CuCu": {"phi": "zjw04"}}
+    nn = make_eam(elements, rng.uniform(4.5, 5.9), adp=seed == 1, potential=pots, hidden_sizes=hs,
+                  activation=["softplus", "tanh", "softplus", "squareplus"][seed], seed=seed)
+    frames = [_random_frame(rng, elements, min_dist=2.0) for _ in range(3)]
+    with Engine(nn) as eng:
+        res = eng.evaluate(frames)
+    _check(res, [oracle_eam_eval(nn, a) for a in frames])
