@@ -27,6 +27,11 @@ def main():
         ("grap 4000-atom Ni", make_grap_nn(["Ni"], 6.0, [64, 64], moment_tensors=[0, 1]), ni_frame(7), None, 200),
         ("eam/adp Ni-Mo small", make_eam(["Mo", "Ni"], 6.0, adp=True), _alloy(["Ni", "Mo"], rep=(2, 2, 2), a=3.7),
          oracle_eam_eval, 200),
+        ("nn-eam Ni-Mo small", make_eam(["Mo", "Ni"], 6.0, potential=None), _alloy(["Ni", "Mo"], rep=(2, 2, 2), a=3.7),
+         oracle_eam_eval, 200),
+        ("nn-eam 4000-atom Ni", make_eam(["Ni"], 6.5, potential=None), ni_frame(9), None, 200),
+        ("grap nn-filter Ni small", make_grap_nn(["Ni"], 6.0, [16, 16], "nn", moment_tensors=[0, 1, 2, 3]),
+         fcc(rep=(2, 2, 2)), oracle_grap_eval, 200),
     ]
     for name, nn, atoms, oracle, n_calls in families:
         worst_f, worst_e, checks = 0.0, 0.0, 0
