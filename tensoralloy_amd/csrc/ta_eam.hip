@@ -226,9 +226,14 @@ __device__ __forceinline__ void morse_fn(double r, double d, double g, double r0
   df = 2.0 * d * g * (e1 - e2);
 }
 
+// OTHER = false: every analytic function of the model is of the Zjw04 family (the kind tests and the
+// pow calls of the other potentials stay out of the kernels: -9 % on the plain Zjw04 path otherwise)
+template <bool OTHER>
 __device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, double &f, double &df) {
   const double *p = P.el[e];
-  if (P.el_kind[e] == 1) {
+  if (!OTHER) {
+    zjw_rho(p, r, f, df);
+  } else if (P.el_kind[e] == 1) {
     const double t = p[0] / r, t2 = t * t;
     f = t2 * t2 * t2;
     df = -6.0 * f / r;
@@ -243,9 +248,12 @@ __device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, doub
   }
 }
 
+template <bool OTHER>
 __device__ __forceinline__ void pair_phi(const EamParams &P, int sa, int sb, double r, double &f, double &df) {
-  const int kind = sa == sb ? P.el_kind[sa] : 0;
-  if (kind == 1) {
+  const int kind = (OTHER && sa == sb) ? P.el_kind[sa] : 0;
+  if (!OTHER) {
+    zjw_phi(P, sa, sb, r, f, df);
+  } else if (kind == 1) {
     const double t = P.el[sa][1] / r, t2 = t * t, t4 = t2 * t2;
     f = t4 * t4 * t4;
     df = -12.0 * f / r;
@@ -262,9 +270,12 @@ __device__ __forceinline__ void pair_phi(const EamParams &P, int sa, int sb, dou
   }
 }
 
+template <bool OTHER>
 __device__ __forceinline__ void el_embed(const EamParams &P, int e, double rho, double &F, double &dF) {
   const double *p = P.el[e];
-  if (P.el_kind[e] == 1) {
+  if (!OTHER) {
+    zjw_embed(p, P.embed_kind[e], rho, F, dF);
+  } else if (P.el_kind[e] == 1) {
     const double s = sqrt(rho);
     F = -s;
     dF = -0.5 / s;
@@ -300,6 +311,7 @@ __device__ __forceinline__ void mishin_polar(double r, double p1, double p2, dou
 
 // moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
 // in the order xx yy zz yz xz xy
+template <bool OTHER>
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
                                                           double *mom, double eps,
                                                           const double *__restrict__ pf, size_t ps,
@@ -352,11 +364,11 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // density function of the NEIGHBOUR's element (alloy.py:176)
       if (rho_nn) f = pf[PF_RHO * ps + q];
       else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
-      else el_rho(P, sb, r, f, df);
+      else el_rho<OTHER>(P, sb, r, f, df);
       rho += f;
       if (phi_nn) f = pf[PF_PHI * ps + q];
       else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, df);
-      else pair_phi(P, sA, sb, r, f, df);
+      else pair_phi<OTHER>(P, sA, sb, r, f, df);
       phis += f;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     } else {
       double F, d;
       if ((P.tab_embed >> sA) & 1u) spline_eval(tabs[slot_embed(nel, sA)], rho, F, d);
-      else el_embed(P, sA, rho, F, d);
+      else el_embed<OTHER>(P, sA, rho, F, d);
       b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
       dF[i] = d;
     }
@@ -635,6 +647,7 @@ __global__ __launch_bounds__(THREADS) void eam_nn_embed_kernel(const MlpDev *__r
       [&](int row, int, double d) { dF[atoms[a0 + row]] = d; });
 }
 
+template <bool OTHER>
 __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBatch b,
                                                           const double *dF, const double *mom,
                                                           const double *__restrict__ pf, size_t ps,
@@ -651,10 +664,10 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const int pt = pair_type(sA, sa, nel);
   if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
   else if ((P.tab_rho >> sa) & 1u) spline_eval(tabs[slot_rho(sa)], r, f, drho);
-  else el_rho(P, sa, r, f, drho);
+  else el_rho<OTHER>(P, sa, r, f, drho);
   if ((P.nn_phi >> pt) & 1u) dphi = pf[PF_DPHI * ps + p];
   else if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, dphi);
-  else pair_phi(P, sA, sa, r, f, dphi);
+  else pair_phi<OTHER>(P, sA, sa, r, f, dphi);
   // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
   double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
   double gx = c * dx, gy = c * dy, gz = c * dz;
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     double f, df;
     if (row < nel) {
       if ((P.tab_rho >> row) & 1u) spline_eval(tabs[slot_rho(row)], x, f, df);
-      else el_rho(P, row, x, f, df);
+      else el_rho<true>(P, row, x, f, df);
       rho_of_r[(size_t)row * n_r + k] = f;
     } else {
       const int pt = row - nel;
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
       }
       const int b2 = a + rem;
       if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], x, f, df);
-      else pair_phi(P, a, b2, x, f, df);
+      else pair_phi<true>(P, a, b2, x, f, df);
       phi_of_r[(size_t)pt * n_r + k] = f;
       if (P.adp && u_of_r && w_of_r) {
         const double *pp = P.pair[pt];
@@ -743,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     const int row = (int)(j / n_rho), k = (int)(j % n_rho);
     double F, dF;
     if ((P.tab_embed >> row) & 1u) spline_eval(tabs[slot_embed(nel, row)], rho[k], F, dF);
-    else el_embed(P, row, rho[k], F, dF);
+    else el_embed<true>(P, row, rho[k], F, dF);
     embed_of_rho[(size_t)row * n_rho + k] = F;
   }
 }
@@ -1263,9 +1276,15 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
                          m->p, m->nets_dev, m->activation, b, rbuf, m->pf, ps, m->stride);
     }
   }
-  hipLaunchKernelGGL(eam_atom_kernel, dim3((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf, ps, m->rho_buf,
-                     pair_nets ? 1 : 0, m->tabs_dev);
+  bool other = false;
+  for (int e = 0; e < m->p.nel; ++e) other = other || m->p.el_kind[e] != 0;
+  const dim3 agrid((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock));
+  if (other)
+    hipLaunchKernelGGL(eam_atom_kernel<true>, agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf,
+                       ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev);
+  else
+    hipLaunchKernelGGL(eam_atom_kernel<false>, agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf,
+                       ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev);
   if (m->embed_nets) {
     EmbedTiles t;
     std::memset(&t, 0, sizeof(t));
@@ -1284,8 +1303,13 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
                          m->stride);
   }
   if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
-    hipLaunchKernelGGL(eam_pair_kernel, dim3((unsigned)((b.n_pairs + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps, m->tabs_dev);
+    const dim3 pgrid((unsigned)((b.n_pairs + kBlock - 1) / kBlock));
+    if (other)
+      hipLaunchKernelGGL(eam_pair_kernel<true>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
+                         m->tabs_dev);
+    else
+      hipLaunchKernelGGL(eam_pair_kernel<false>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
+                         m->tabs_dev);
     launch_force_gather(sf, b, s);
   } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
     launch_force_gather(sf, b, s);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ta_device.h"
 #include "ta_mlp_tile.h"
@@ -24,7 +25,10 @@ __global__ __launch_bounds__(THREADS) void mlp_kernel(MlpDev mlp, int act, int n
   double *buf0 = lds, *buf1 = lds + kMlpRows * stride;
   const int a0 = blockIdx.x * kMlpRows;
   const int nrows = min(kMlpRows, n_atoms - a0);
-  double *da = scratch + (size_t)blockIdx.x * mlp.n_layers * kMlpRows * stride;
+  // activation derivatives of the forward sweep: behind the two activation buffers in LDS when the
+  // launch reserved room for them (scratch == nullptr), else in the global scratch slab
+  double *da = scratch ? scratch + (size_t)blockIdx.x * mlp.n_layers * kMlpRows * stride
+                       : lds + 2 * kMlpRows * stride;
   for (int idx = threadIdx.x; idx < kMlpRows * ndim; idx += THREADS) {
     const int row = idx / ndim, k = idx - row * ndim;
     buf0[row * stride + k] = row < nrows ? G[(size_t)atoms[a0 + row] * ndim + k] : 0.0;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(THREADS) void mlp_all_kernel(const MlpDev *__restri
   const int n_atoms = tiles.elem_start[e + 1] - tiles.elem_start[e];
   const int a0 = ((int)blockIdx.x - tiles.tile_start[e]) * kMlpRows;
   const int nrows = min(kMlpRows, n_atoms - a0);
-  double *da = scratch + (size_t)blockIdx.x * tile_doubles;
+  double *da = scratch ? scratch + (size_t)blockIdx.x * tile_doubles : lds + 2 * kMlpRows * stride;
   for (int idx = threadIdx.x; idx < kMlpRows * ndim; idx += THREADS) {
     const int row = idx / ndim, k = idx - row * ndim;
     buf0[row * stride + k] = row < nrows ? G[(size_t)el_atoms[a0 + row] * ndim + k] : 0.0;
@@ -82,8 +86,13 @@ void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t 
                      const DeviceBatch &b, double *scratch, hipStream_t s) {
   if (n_atoms == 0) return;
   const int stride = mlp_stride(mlp);
-  const size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
+  size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
   const unsigned blocks = (unsigned)((n_atoms + kMlpRows - 1) / kMlpRows);
+  const size_t lds_da = (size_t)mlp.n_layers * kMlpRows * stride * sizeof(double);
+  if (lds + lds_da <= 64 * 1024 && !getenv("TA_MLP_DA_GLOBAL")) {
+    lds += lds_da;
+    scratch = nullptr;
+  }
   // one wavefront per 16-column tile of the widest layer, at most 8
   if (mlp.max_np >= 128)
     hipLaunchKernelGGL(mlp_kernel<512>, dim3(blocks), dim3(512), lds, s, mlp, activation, ndim, atoms,
@@ -127,7 +136,12 @@ void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, in
   t.elem_start[nel] = b.elem_start[nel];
   for (int e = nel + 1; e <= kMaxElements; ++e) t.tile_start[e] = t.elem_start[e] = 0;
   if (blocks == 0) return;
-  const size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
+  size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
+  const size_t lds_da = (size_t)layers * kMlpRows * stride * sizeof(double);
+  if (lds + lds_da <= 64 * 1024 && !getenv("TA_MLP_DA_GLOBAL")) {  // act' slab in LDS, see mlp_kernel
+    lds += lds_da;
+    scratch = nullptr;
+  }
   if (width >= 128)
     hipLaunchKernelGGL(mlp_all_kernel<512>, dim3((unsigned)blocks), dim3(512), lds, s, mlps_dev, t,
                        activation, ndim, b.elem_atoms, b.G, b.dEdG, b.eatom, scratch, stride,
