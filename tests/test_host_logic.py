@@ -412,3 +412,72 @@ def test_spline_potentials_in_the_model_description(tmp_path):
     adp.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=6.0))
     desc, keep = adp.to_desc()
     assert desc.n_eam_nets == 13 and all(desc.eam_table_n[k] == 1000 for k in range(13))
+
+
+def test_batch_universal_transformer_records():
+    """`BatchUniversalTransformer` (universal.py:921-1388): padded records with the reference's
+    keys and shapes; decoded and scattered they give, structure by structure, the dense arrays of
+    the single-structure transformer (whose layout the oracle tests pin), padded to the data set's
+    `nnl_max` / `ij2k_max`."""
+    from collections import Counter
+    from tensoralloy_amd import UniversalTransformer
+    from tensoralloy_amd.transformer import BatchUniversalTransformer
+    from tests.test_gpu_sf import _alloy
+    frames = [_alloy(["Ni", "Ni", "Mo"], rep=(1, 1, 2), a=3.6), _alloy(["Ni", "Mo"], rep=(1, 1, 1), a=3.7, seed=5)]
+    frames[0].info["energy"] = -12.5
+    frames[0].info["forces"] = np.arange(3 * len(frames[0]), dtype=float).reshape(-1, 3)
+    max_occurs = Counter()
+    for a in frames:
+        for el, n in Counter(a.get_chemical_symbols()).items():
+            max_occurs[el] = max(max_occurs[el], n)
+    single = UniversalTransformer(["Mo", "Ni"], rcut=4.0, angular=True)
+    feeds = [single.get_np_feed_dict(a) for a in frames]
+    nij = max(len(f["g2.ilist"]) for f in feeds)
+    nijk = max(len(f["g4.ilist"]) for f in feeds)
+    nnl = max(int(f["nnl_max"]) for f in feeds)
+    ij2k = max(int(f["ij2k_max"]) for f in feeds)
+    clf = BatchUniversalTransformer(max_occurs, rcut=4.0, angular=True, nij_max=nij + 3, nijk_max=nijk + 5,
+                                    nnl_max=nnl, ij2k_max=ij2k, batch_size=2, use_forces=True, use_stress=True)
+    d = clf.as_dict()
+    assert d["class"] == "BatchUniversalTransformer" and d["nij_max"] == nij + 3 and d["use_stress"] is True
+    assert clf.as_descriptor_transformer().as_dict() == single.as_dict()
+    recs = [clf.encode(a) for a in frames]
+    n_vap = sum(max_occurs.values()) + 1
+    for a, r in zip(frames, recs):
+        assert r["positions"].shape == (n_vap, 3) and r["atom_masks"].shape == (n_vap,)
+        assert int(r["n_atoms_vap"]) == len(a)                                  # base.py:411
+        assert r["g2.indices"].shape == (nij + 3, 7) and r["g2.indices"].dtype == np.int32
+        assert r["g4.indices"].shape == (nijk + 5, 8) and r["g4.shifts"].shape == (nijk + 5, 9)
+        assert r["forces"].shape == (n_vap, 3) and r["stress"].shape == (6,)
+        assert r["atom_masks"].sum() == len(a)
+    assert recs[0]["energy"][0] == -12.5 and recs[1]["energy"][0] == 0.0
+    vap0 = clf.get_vap_transformer(frames[0])
+    assert np.array_equal(vap0.map_forces(recs[0]["forces"], reverse=True), frames[0].info["forces"])
+    batch = clf.batch(recs)
+    assert batch["g2.v2g_map"].shape == (2, nij + 3, 5) and batch["g4.klist"].shape == (2, nijk + 5)
+    dense = clf.get_descriptors(batch)
+    for b, a in enumerate(frames):
+        # the same structure through the single-structure transformer, with ITS vap (own counts)
+        ref = single.get_descriptors(feeds[b])
+        vap_b, vap_s = clf.get_vap_transformer(a), single.get_vap_transformer(a)
+        for el in ("Mo", "Ni"):
+            n_own = vap_s.max_occurs[el]
+            got = dense["radial"][el][0][:, b]                                   # [4, nr, n_el, nnl, 1]
+            own = ref["radial"][el][0]
+            real = np.flatnonzero(dense["atom_masks"][el][b])
+            assert len(real) == Counter(a.get_chemical_symbols())[el]
+            k = own.shape[3]
+            # atoms of one element keep their relative order in both maps
+            assert np.allclose(got[:, :, real, :k], own[:, :, :len(real)], atol=1e-12)
+            assert np.abs(got[:, :, :, k:]).max() < 1e-6 if got.shape[3] > k else True
+            ga = dense["angular"][el][0][:, b]
+            oa = ref["angular"][el][0]
+            assert np.allclose(ga[:, :, real, :oa.shape[3], :oa.shape[4]], oa[:, :, :len(real)], atol=1e-12)
+            assert n_own >= 1
+    back = clf.frames(batch, [a.get_chemical_symbols() for a in frames])
+    for a, c in zip(frames, back):
+        assert np.allclose(a.positions, c.positions) and np.allclose(np.asarray(a.get_cell()), np.asarray(c.get_cell()))
+    with pytest.raises(ValueError, match="more than the declared maximum"):
+        BatchUniversalTransformer(max_occurs, rcut=4.0, nij_max=5).encode(frames[0])
+    with pytest.raises(ValueError, match="exceed max_occurs"):
+        BatchUniversalTransformer(Counter({"Ni": 1, "Mo": 1}), rcut=4.0).encode(frames[0])
