@@ -569,6 +569,49 @@ __global__ __launch_bounds__(kBlock) void eam_nn_pair_fast_kernel(EamParams P, c
   }
 }
 
+// One hidden layer, 1 -> H1 -> 1: no GEMM at all. One lane per pair, the weights are LDS broadcasts,
+// four independent activation chains per trip.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void eam_nn_pair_1h_kernel(EamParams P, const MlpDev *__restrict__ nets,
+                                                                int act_rt, NnFnList fl, DeviceBatch b,
+                                                                const double *__restrict__ rbuf, double *pf,
+                                                                size_t ps) {
+  extern __shared__ double lds[];
+  const int act = ACT >= 0 ? ACT : act_rt;
+  const int cls = fl.cls[blockIdx.y], k = fl.k[blockIdx.y];
+  const int nel = P.nel;
+  const MlpDev &net = nets[cls == 0 ? slot_rho(k) : slot_pair(nel, cls, k)];
+  const int H1 = net.layer[0].np;  // multiple of 16; padded units have zero output weight
+  double *w1 = lds, *b1 = w1 + H1, *w2 = b1 + H1;
+  for (int idx = threadIdx.x; idx < H1; idx += kBlock) {
+    w1[idx] = net.layer[0].w[idx];
+    b1[idx] = net.layer[0].b[idx];
+    w2[idx] = net.layer[1].w[(size_t)idx * net.layer[1].np];  // column 0 of [H1][16]
+  }
+  const double b2 = net.layer[1].b[0];
+  __syncthreads();
+  double *val = pf + (size_t)(2 * cls) * ps, *der = pf + (size_t)(2 * cls + 1) * ps;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < b.n_pairs; p += (int64_t)gridDim.x * kBlock) {
+    const int sb = b.species[b.pair_j[p]];
+    const int key = cls == 0 ? sb : pair_type(b.species[b.pair_i[p]], sb, nel);
+    if (key != k) continue;
+    const double r = rbuf[p];
+    double fv = b2, fd = 0.0;
+    for (int k0 = 0; k0 < H1; k0 += 4) {
+      double h[4], dh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) activation_fn(act, fma(w1[k0 + j], r, b1[k0 + j]), h[j], dh[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fv = fma(h[j], w2[k0 + j], fv);
+        fd = fma(dh[j] * w1[k0 + j], w2[k0 + j], fd);
+      }
+    }
+    val[p] = fv;
+    der[p] = fd;
+  }
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void eam_nn_pair_kernel(EamParams P, const MlpDev *__restrict__ nets,
                                                               int act, DeviceBatch b,
@@ -843,6 +886,7 @@ struct EamModel {
   // training: per-pair weights, scratch and partial sums of the gradient kernels
   double *gcoeff = nullptr, *gscratch = nullptr, *gpartial = nullptr;
   size_t cap_gcoeff = 0, cap_gscratch = 0, cap_gpartial = 0;
+  bool fast_1h = false;           // every pair function is 1 -> H1 -> 1 (no-GEMM kernel)
   int fast_nt = 0;                // > 0: every pair function is 1 -> H1 -> 16 fast_nt -> 1 (fast kernel)
   size_t fast_lds = 0;
   NnFnList fns;                   // the pair functions that are nn functions
@@ -1014,15 +1058,17 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     // list of the pair functions; the fast kernel applies when all of them are 1 -> H1 -> H2 -> 1
     // with the same padded H2 <= 64 and the LDS image of one function stays below 64 KB
     std::memset(&e->fns, 0, sizeof(e->fns));
-    bool fast = true;
+    bool fast = true, all_1h = true;
     int h2 = 0;
-    size_t lds = 0;
+    size_t lds = 0, lds_1h = 0;
     auto add = [&](int cls, int k) {
       const MlpDev &n = e->nets[cls == 0 ? slot_rho(k) : slot_pair(nel, cls, k)];
       if (!n.n_layers) return;
       e->fns.cls[e->fns.n] = (int8_t)cls;
       e->fns.k[e->fns.n] = (int8_t)k;
       ++e->fns.n;
+      all_1h = all_1h && n.n_layers == 2;
+      lds_1h = std::max(lds_1h, (size_t)3 * n.layer[0].np * sizeof(double));
       if (n.n_layers != 3 || n.layer[1].res || n.layer[1].np > 64 || (h2 && n.layer[1].np != h2)) {
         fast = false;
         return;
@@ -1037,6 +1083,9 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     if (fast && e->fns.n && lds <= 64 * 1024 && !getenv("TA_EAM_NN_GENERIC")) {
       e->fast_nt = h2 / 16;
       e->fast_lds = lds;
+    } else if (all_1h && e->fns.n && !getenv("TA_EAM_NN_GENERIC")) {
+      e->fast_1h = true;
+      e->fast_lds = lds_1h;
     }
   }
   for (int k = 0; k < nel; ++k) {
@@ -1271,6 +1320,14 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
       }
 #undef TA_NN_FAST_NT
 #undef TA_NN_FAST
+    } else if (m->fast_1h) {
+      const dim3 grid(std::min((unsigned)((b.n_pairs + kBlock - 1) / kBlock), 4096u), (unsigned)m->fns.n);
+      if (m->activation == TA_ACT_SOFTPLUS)
+        hipLaunchKernelGGL(eam_nn_pair_1h_kernel<TA_ACT_SOFTPLUS>, grid, dim3(kBlock), m->fast_lds, s, m->p,
+                           m->nets_dev, m->activation, m->fns, b, rbuf, m->pf, ps);
+      else
+        hipLaunchKernelGGL(eam_nn_pair_1h_kernel<-1>, grid, dim3(kBlock), m->fast_lds, s, m->p, m->nets_dev,
+                           m->activation, m->fns, b, rbuf, m->pf, ps);
     } else {
       hipLaunchKernelGGL(eam_nn_pair_kernel<kNetThreads>, dim3(tiles), dim3(kNetThreads), net_lds_bytes(m), s,
                          m->p, m->nets_dev, m->activation, b, rbuf, m->pf, ps, m->stride);

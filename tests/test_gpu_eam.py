@@ -58,6 +58,16 @@ def test_nn_eam_default_potentials(lib, monkeypatch, generic):
     _compare(nn, [fcc(rep=(3, 3, 3)), fcc(rep=(2, 2, 2), a=3.3, seed=5), fcc(rep=(1, 1, 1))])
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_nn_eam_one_hidden_layer(lib, monkeypatch, generic):
+    """1 -> H -> 1 functions: the no-GEMM kernel and the generic tile."""
+    if generic:
+        monkeypatch.setenv("TA_EAM_NN_GENERIC", "1")
+    frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2)), fcc(rep=(1, 1, 1))]
+    _compare(make_eam(["Mo", "Ni"], 6.0, potential=None, hidden_sizes=[40]), frames[:1])
+    _compare(make_eam(["Ni"], 6.0, adp=True, potential=None, hidden_sizes=[7], activation="tanh"), frames[1:])
+
+
 def test_nn_eam_binary_and_other_shapes(lib):
     frames = [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 3)), _alloy(["Mo", "Ni"], rep=(2, 2, 2), a=3.3)]
     _compare(make_eam(["Ni", "Mo"], 6.5, potential=None), frames)
