@@ -267,11 +267,19 @@ def main():
             for _ in range(args.cpu_evals if time_cpu else 0):
                 csf.run(m, prep, True, cores, cm)
             tc = (time.perf_counter() - t0) / max(1, args.cpu_evals)
+            # the same port on ONE thread (the reference's `serial_mode=True` analogue)
+            serial = None
+            if time_cpu:
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    csf.run(m, prep, True, 1, cm)
+                ts = (time.perf_counter() - t1) / 2
+                serial = {"value": n0 / ts, "cores": 1, "sample": "2 evaluations of the same frame", "ms_per_eval": ts * 1e3}
             cpu = None if not time_cpu else {"value": n0 / tc, "unit": "atom-steps/s", "cores": cores, "kind": "port",
                    "sample": f"{args.cpu_evals} evaluations of frame 0 ({n0} atoms, {len(prep['i'])} "
                              f"pairs) by oracle/c/sf_oracle.c (OpenMP, {cores} threads), same "
                              f"model; neighbour list excluded as for the GPU",
-                   "ms_per_eval": tc * 1e3,
+                   "ms_per_eval": tc * 1e3, "serial": serial,
                    "parity": {"dE_eV": dE, "dF_max_eV_per_A": dF, "dW_max_eV": dW}}
         out = {
             "metric": "atom-steps/sec (energy+forces), 4000-atom Ni rcut=6.5 A",
