@@ -273,7 +273,7 @@ int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights);
  * energy term of nn/losses.py:204-285. The batch's descriptors are computed once and reused. */
 int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int64_t n_grad);
 
-/* Tables of an EAM / ADP model's analytic functions on caller-supplied abscissae: what
+/* Tables of an EAM / ADP model's functions (analytic, nn or tabulated) on caller-supplied abscissae: what
  * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it
  * writes a LAMMPS setfl file. Rows: elements (sorted) for rho(r) [n_elements][n_r] and F(rho)
  * [n_elements][n_rho]; element pairs a <= b (upper triangle, row-major) for phi(r), and for an
