@@ -96,6 +96,13 @@ def main():
     ap.add_argument("--cpu-evals", type=int, default=40)  # ~10 s of 16-thread CPU work
     args = ap.parse_args()
 
+    # the driver reads ONE JSON line from stdout: native libraries print there too (RCCL writes a
+    # version banner on initialisation, gloo its connection report), so everything else that lands
+    # on fd 1 during the run is sent to stderr and the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from tensoralloy_amd.parallel import world_from_env
     rank, local_rank, world = world_from_env()
     if world != args.gpus and world != 1:
@@ -305,8 +312,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    sys.stdout.flush()
     if out is not None:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
