@@ -148,6 +148,11 @@ def main():
         ebuf = torch.zeros(2, dtype=torch.float64, device=f"cuda:{local_rank}")
         # kernels go onto torch's current stream so the collective is ordered
         # behind them by stream semantics: no host synchronisation per step
+        # a dedicated non-blocking stream (not the legacy default stream, whose launches carry the
+        # implicit synchronisation with every blocking stream); TA_BENCH_DEFAULT_STREAM=1: the old way
+        if os.environ.get("TA_BENCH_DEFAULT_STREAM") != "1":
+            side = torch.cuda.Stream(device=local_rank)
+            torch.cuda.set_stream(side)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         slots_ = [ebuf[0:1], ebuf[1:2]]
         slot_ptrs = [s_.data_ptr() for s_ in slots_]
