@@ -465,7 +465,8 @@ __host__ __device__ inline int net_wstride(int np) { return (np % 32 == 0) ? np 
 // workgroup's LDS image of the weights; the accumulator layout puts a pair's value and derivative of
 // one unit in the same lane, so the activation is applied in registers. Layer 0 has K = 1 and needs
 // no GEMM. Pair geometry: r = sqrt(r^2) of the pair records (pair_geometry_kernel ran before).
-template <int ACT>
+// NTMAX = column tiles of the widest layer (1..4): sizes the accumulator arrays
+template <int ACT, int NTMAX>
 __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, DeviceBatch b, double *Hbuf,
                                                                int Ks) {
   extern __shared__ double lds[];
@@ -521,9 +522,9 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
     __syncthreads();
     for (int l = 1; l < net.L; ++l) {
       const int kp = net.np[l - 1], NT = net.np[l] / 16, ws = net_wstride(net.np[l]);
-      mlp_f64x4 accv[4], accd[4];
+      mlp_f64x4 accv[NTMAX], accd[NTMAX];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < NTMAX; ++nt) {
         const double bb = nt < NT ? Bl[l][16 * nt + m] : 0.0;
         accv[nt] = {bb, bb, bb, bb};
         accd[nt] = {0.0, 0.0, 0.0, 0.0};
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
         const int ki = 4 * kk + kq;
         const double av = Xv[m * net.xs + ki], ad = Xd[m * net.xs + ki];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTMAX; ++nt)
           if (nt < NT) {
             const double B = Wl[l][ki * ws + 16 * nt + m];
             accv[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B, accv[nt], 0, 0, 0);
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
       __syncthreads();  // every read of this layer's input is done
       if (l < net.L - 1) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTMAX; ++nt)
           if (nt < NT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
         __syncthreads();
       } else {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTMAX; ++nt)
           if (nt < NT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -829,12 +830,19 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStre
     launch_pair_geometry(sf, b, s);
     const unsigned tiles = (unsigned)((b.n_pairs + kMlpTileRows - 1) / kMlpTileRows);
     const dim3 grid(std::min((tiles + 3) / 4, 2048u));
-    if (g->net.act == TA_ACT_SOFTPLUS)
-      hipLaunchKernelGGL(grap_nn_filter_kernel<TA_ACT_SOFTPLUS>, grid, dim3(kBlock), g->net_lds, s, g->net, b,
-                         g->Hbuf, g->p.Ks);
-    else
-      hipLaunchKernelGGL(grap_nn_filter_kernel<-1>, grid, dim3(kBlock), g->net_lds, s, g->net, b, g->Hbuf,
-                         g->p.Ks);
+    int ntmax = 1;
+    for (int l = 1; l < g->net.L; ++l) ntmax = std::max(ntmax, g->net.np[l] / 16);
+#define TA_GRAP_NET(ACT, NT)                                                                                \
+  hipLaunchKernelGGL((grap_nn_filter_kernel<ACT, NT>), grid, dim3(kBlock), g->net_lds, s, g->net, b, g->Hbuf, \
+                     g->p.Ks)
+    if (g->net.act == TA_ACT_SOFTPLUS) {
+      if (ntmax <= 2) TA_GRAP_NET(TA_ACT_SOFTPLUS, 2);
+      else TA_GRAP_NET(TA_ACT_SOFTPLUS, 4);
+    } else {
+      if (ntmax <= 2) TA_GRAP_NET(-1, 2);
+      else TA_GRAP_NET(-1, 4);
+    }
+#undef TA_GRAP_NET
   }
   hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
                      g->ndim, eps);
