@@ -95,8 +95,9 @@ typedef struct {
   /* EAM / ADP analytic potentials (nn/eam/potentials/zjw04.py, mishin.py), one flat block:
    *   per element (sorted): 20 constants -- Zjw04 [r_eq f_eq rho_e rho_s alpha beta A B kappa lamda
    *     Fn0 Fn1 Fn2 Fn3 F0 F1 F2 F3 eta Fe], AgSutton90 [a b] (sutton90.py:37-44) or AgrawalBe "Be/1"
-   *     [A B D alpha re F0 F1 beta gamma m rc] (agrawal.py:49-55), zero padded -- + embed kind
-   *     (0 Zjw04 piecewise, 1 Zjw04xc blended) + potential kind (0 Zjw04 family, 1 sutton90, 2 Be/1);
+   *     [A B D alpha re F0 F1 beta gamma m rc] (agrawal.py:49-55) or RWGrimes "grimes" [G n A rho C D
+   *     gamma r0] (grimmes.py:33-37), zero padded -- + embed kind (0 Zjw04 piecewise, 1 Zjw04xc
+   *     blended) + potential kind (0 Zjw04 family, 1 sutton90, 2 Be/1, 3 grimes);
    *   per element pair a <= b (upper triangle, row-major): phi kind (0 Zjw04, 1 Zjw04xcp own
    *     constants) + [r_eq A B alpha beta kappa lamda];
    *   ADP only, per pair: [d1 d2 d3 q1 q2 q3 h rc] (all zero = no angular term).           */

@@ -235,7 +235,30 @@ def agrawal_embed(rho, p):
     return F, dF
 
 
-OTHER = {"sutton90": (sutton90_rho, sutton90_phi, sutton90_embed),
+def grimes_rho(r, p):
+    """RWGrimes (potentials/grimmes.py:67-86): n / r^8 (1/2 + 1/2 erf(20 (r - 3/2)))."""
+    from scipy.special import erf
+    t = 20.0 * (r - 1.5)
+    sw = 0.5 + 0.5 * erf(t)
+    dsw = 20.0 / np.sqrt(np.pi) * np.exp(-t * t)
+    return p["n"] / r ** 8 * sw, p["n"] / r ** 8 * (dsw - 8.0 * sw / r)
+
+
+def grimes_phi(r, p):
+    """grimmes.py:40-65: Morse + Buckingham (generic.py:15-49)."""
+    m0, dm0 = _morse(r, p["D"], p["gamma"], p["r0"])
+    eb = p["A"] * np.exp(-r / p["rho"])
+    return m0 + eb - p["C"] / r ** 6, dm0 - eb / p["rho"] + 6.0 * p["C"] / r ** 7
+
+
+def grimes_embed(rho, p):
+    """grimmes.py:88-100: -G sqrt(rho)."""
+    s = np.sqrt(rho)
+    return -p["G"] * s, -0.5 * p["G"] / s
+
+
+OTHER = {"grimes": (grimes_rho, grimes_phi, grimes_embed),
+         "sutton90": (sutton90_rho, sutton90_phi, sutton90_embed),
          "be/1": (agrawal_rho, agrawal_phi, agrawal_embed)}
 
 

@@ -71,7 +71,8 @@ struct EamParams {
   int embed_kind[kMaxEamElements];  // 0: piecewise (Zjw04), 1: sigmoid-blended (Zjw04xc)
   int el_kind[kMaxEamElements];     // potential of the element's analytic rho / embed / phi_AA:
                                     // 0 Zjw04 family, 1 AgSutton90 (el = {a, b}), 2 AgrawalBe "Be/1"
-                                    // (el = {A, B, D, alpha, re, F0, F1, beta, gamma, m, rc})
+                                    // (el = {A, B, D, alpha, re, F0, F1, beta, gamma, m, rc}),
+                                    // 3 RWGrimes (el = {G, n, A, rho, C, D, gamma, r0})
   int phi_kind[kMaxPairTypes];      // 0: Zjw04 (AA, or AB by density mixing), 1: own constants (Zjw04xcp)
   double el[kMaxEamElements][20];   // ZJW04_KEYS order (tensoralloy_amd/eam.py)
   double phi[kMaxPairTypes][7];     // r_eq A B alpha beta kappa lamda of a Zjw04xcp cross term
@@ -218,7 +219,11 @@ __device__ __forceinline__ void zjw_embed(const double *p, int kind, double rho,
 //   rho = A e^{-B (r - re)} - A e^{-B (rc - re)} - s(r) A B e^{-B (rc - re)},
 //   phi = M(r) - M(rc) + s(r) M'(rc),  M = Morse(D, alpha, re) (generic.py:15-30, agrawal.py:20-32),
 //   F = F0 (1 - beta ln max(rho, 1e-12)) rho^beta + F1 rho^gamma.
+// RWGrimes "grimes" (potentials/grimmes.py:33-100): rho = n / r^8 (1/2 + 1/2 erf(20 (r - 3/2))),
+//   phi = Morse(D, gamma, r0) + Buckingham(A, rho, C) = ... + A e^{-r / rho} - C / r^6 (generic.py:15-49),
+//   F = -G sqrt(rho).
 enum { AG_A = 0, AG_B, AG_D, AG_ALPHA, AG_RE, AG_F0, AG_F1, AG_BETA, AG_GAMMA, AG_M, AG_RC };
+enum { GR_G = 0, GR_N, GR_A, GR_RHO, GR_C, GR_D, GR_GAMMA, GR_R0 };
 
 __device__ __forceinline__ void morse_fn(double r, double d, double g, double r0, double &f, double &df) {
   const double e1 = exp(-g * (r - r0)), e2 = e1 * e1;
@@ -243,6 +248,13 @@ __device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, doub
     const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
     f = ev - ec - p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * p[AG_B] * ec;
     df = -p[AG_B] * ev + xm1 * p[AG_B] * ec;
+  } else if (P.el_kind[e] == 3) {
+    const double i2 = 1.0 / (r * r), i8 = i2 * i2 * i2 * i2;
+    const double t = 20.0 * (r - 1.5);
+    const double sw = 0.5 + 0.5 * erf(t);
+    const double dsw = 20.0 * 0.56418958354775628 * exp(-t * t);  // 10 * 2 / sqrt(pi) * e^{-t^2}
+    f = p[GR_N] * i8 * sw;
+    df = p[GR_N] * i8 * (dsw - 8.0 * sw / r);
   } else {
     zjw_rho(p, r, f, df);
   }
@@ -265,6 +277,14 @@ __device__ __forceinline__ void pair_phi(const EamParams &P, int sa, int sb, dou
     const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
     f = m0 - mc + p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * dmc;
     df = dm0 - xm1 * dmc;
+  } else if (kind == 3) {
+    const double *p = P.el[sa];
+    double m0, dm0;
+    morse_fn(r, p[GR_D], p[GR_GAMMA], p[GR_R0], m0, dm0);
+    const double eb = p[GR_A] * exp(-r / p[GR_RHO]);
+    const double i2 = 1.0 / (r * r), i6 = i2 * i2 * i2;
+    f = m0 + eb - p[GR_C] * i6;
+    df = dm0 - eb / p[GR_RHO] + 6.0 * p[GR_C] * i6 / r;
   } else {
     zjw_phi(P, sa, sb, r, f, df);
   }
@@ -284,6 +304,10 @@ __device__ __forceinline__ void el_embed(const EamParams &P, int e, double rho, 
     const double xb = pow(rho, p[AG_BETA] - 1.0), yg = pow(rho, p[AG_GAMMA] - 1.0);
     F = p[AG_F0] * (1.0 - p[AG_BETA] * L) * xb * rho + p[AG_F1] * yg * rho;
     dF = -p[AG_F0] * p[AG_BETA] * p[AG_BETA] * L * xb + p[AG_F1] * p[AG_GAMMA] * yg;
+  } else if (P.el_kind[e] == 3) {
+    const double s = sqrt(rho);
+    F = -p[GR_G] * s;
+    dF = -0.5 * p[GR_G] / s;
   } else {
     zjw_embed(p, P.embed_kind[e], rho, F, dF);
   }
@@ -1092,7 +1116,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
     for (int c = 0; c < 20; ++c) e->p.el[k][c] = m->eam_params[k * 22 + c];
     e->p.embed_kind[k] = m->eam_params[k * 22 + 20] != 0.0 ? 1 : 0;
     const int kind = (int)m->eam_params[k * 22 + 21];
-    if (kind < 0 || kind > 2) {
+    if (kind < 0 || kind > 3) {
       eam_destroy(e);
       err = "unknown empirical potential kind";
       return nullptr;

@@ -5,8 +5,8 @@ analytic-potential hot path:
   EamAlloyNN  <- reference tensoralloy/nn/eam/alloy.py:24-127 (+ EamNN, eam.py:78-130)
   AdpNN       <- reference tensoralloy/nn/eam/adp.py (dipole / quadrupole terms)
 
-Supported potentials: `sutton90` (AgSutton90) and `Be/1` (AgrawalBe) for single-element rho / embed /
-phi, and the Zhou-Johnson-Wadley family for rho / embed / phi --
+Supported potentials: `sutton90` (AgSutton90), `Be/1` (AgrawalBe) and `grimes` (RWGrimes) for
+single-element rho / embed / phi, and the Zhou-Johnson-Wadley family for rho / embed / phi --
 `zjw04` (nn/eam/potentials/zjw04.py:155-412), `zjw04xc` / `zjw04uxc` (sigmoid-
 blended embedding, :415-568; the two differ only in which constants are
 trainable) and `zjw04xcp` (own constants for cross-element phi, :571-696) -- and
@@ -74,12 +74,17 @@ ZJW04_DEFAULTS = {
 ZJW04_FAMILY = ("zjw04", "zjw04xc", "zjw04uxc", "zjw04xcp")
 # the other eam/alloy members of the reference's `available_potentials` (potentials/__init__.py:20-30):
 # AgSutton90 (sutton90.py:37-44) and AgrawalBe "Be/1" (agrawal.py:49-55); constants as published there
-OTHER_POTENTIALS = ("sutton90", "be/1")
+OTHER_POTENTIALS = ("sutton90", "be/1", "grimes")
+GRIMES_KEYS = ["G", "n", "A", "rho", "C", "D", "gamma", "r0"]       # 'Pu': G, n; 'PuPu': the rest
+GRIMES_DEFAULTS = {"Pu": dict(G=2.168, n=3980.058, A=18600.0, rho=0.2637, C=0.0, D=0.70185,
+                              gamma=1.98008, r0=2.34591)}             # grimmes.py:33-37
 SUTTON90_DEFAULTS = {"Ag": {"a": 2.928323832, "b": 2.485883762}}   # 'Ag': a, 'AgAg': b
 AGRAWAL_KEYS = ["A", "B", "D", "alpha", "re", "F0", "F1", "beta", "gamma", "m", "rc"]
 AGRAWAL_DEFAULTS = {"Be": dict(A=1.597, B=9.49713, D=0.41246, alpha=0.36324, re=2.29, F0=-2.0393,
                                F1=12.6178, beta=0.18752, gamma=-2.28827, m=10.0, rc=5.0)}
-EL_KIND = {"zjw": 0, "sutton90": 1, "be/1": 2}
+EL_KIND = {"zjw": 0, "sutton90": 1, "be/1": 2, "grimes": 3}
+_OTHER_TABLES = {"sutton90": (SUTTON90_DEFAULTS, ["a", "b"]), "be/1": (AGRAWAL_DEFAULTS, AGRAWAL_KEYS),
+                 "grimes": (GRIMES_DEFAULTS, GRIMES_KEYS)}
 PHI_KEYS = ["r_eq", "A", "B", "alpha", "beta", "kappa", "lamda"]
 # Zjw04xcp refits (reference nn/eam/potentials/zjw04.py:608-633; the later assignment wins)
 _XCP_KEYS = ["A", "B", "F0", "F1", "F2", "F3", "Fe", "Fn0", "Fn1", "Fn2", "Fn3", "alpha", "beta",
@@ -361,7 +366,7 @@ class EamAlloyNN:
     def other_parameters(self, el: str) -> Dict[str, float]:
         """Constants of an element whose analytic functions are sutton90 or Be/1."""
         kind = self._el_kind[el]
-        table, keys = (SUTTON90_DEFAULTS, ["a", "b"]) if kind == "sutton90" else (AGRAWAL_DEFAULTS, AGRAWAL_KEYS)
+        table, keys = _OTHER_TABLES[kind]
         p = dict(table.get(el, {}))
         p.update({k: v for k, v in self._parameters.get(el, {}).items() if k in keys})
         p.update({k: v for k, v in self._parameters.get(el + el, {}).items() if k in keys})
@@ -427,7 +432,7 @@ class EamAlloyNN:
                 out.extend(p[k] for k in ZJW04_KEYS)
             else:
                 q = self.other_parameters(el)
-                vals = [q[k] for k in (["a", "b"] if kind == "sutton90" else AGRAWAL_KEYS)]
+                vals = [q[k] for k in _OTHER_TABLES[kind][1]]
                 out.extend(vals + [0.0] * (20 - len(vals)))
             out.append(embed_kind)
             out.append(float(EL_KIND[kind]))

@@ -182,6 +182,7 @@ def test_sutton90_and_agrawal_potentials(lib, tmp_path):
         for a, b in zip(e1.evaluate(frames), e2.evaluate(frames)):
             assert abs(a["energy"] - b["energy"]) < 1.5e-3 * len(a["forces"])
             assert np.abs(a["forces"] - b["forces"]).max() < 1e-2
+    _compare(make_eam(["Pu"], 6.0, potential="grimes"), [fcc("Pu", a=4.6, rep=(2, 2, 2), jitter=0.08)])
     mixed = {"Be": {"rho": "Be/1", "embed": "nn"}, "BeBe": {"phi": "Be/1"}}
     _compare(make_eam(["Be"], 5.0, potential=mixed, hidden_sizes=[8]), frames[:1])
 
