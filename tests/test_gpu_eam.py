@@ -187,6 +187,36 @@ def test_sutton90_and_agrawal_potentials(lib, tmp_path):
     _compare(make_eam(["Be"], 5.0, potential=mixed, hidden_sizes=[8]), frames[:1])
 
 
+def test_nn_and_table_models_edge_cases(lib, tmp_path):
+    """Lone atoms (no pairs: rho = 0, F(0) of an nn embedding is not 0), an empty batch, uneven
+    batches, a molecule without periodicity, 'medium' precision, and a second evaluation with other
+    frames on the same handle (buffers grow)."""
+    from tensoralloy_amd import Atoms, Engine, UniversalTransformer
+    from tensoralloy_amd.eam import EamAlloyNN
+    nn = make_eam(["Mo", "Ni"], 5.5, potential=None, hidden_sizes=[16, 16])
+    lone = Atoms(symbols=["Ni"], positions=[[1.0, 2.0, 3.0]], cell=np.eye(3) * 25.0, pbc=True)
+    mol = Atoms(symbols=["Ni", "Mo", "Ni", "Mo", "Ni"], positions=np.random.RandomState(3).rand(5, 3) * 4.0,
+                cell=np.eye(3) * 20.0, pbc=False)
+    big = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 3))
+    with Engine(nn) as eng:
+        assert eng.evaluate([]) == []
+        for frames in ([lone], [lone, big, mol], [big], [mol, lone]):
+            res = eng.evaluate(frames)
+            for a, r in zip(frames, res):
+                o = oracle_eam_eval(nn, a)
+                assert abs(r["energy"] - o["energy"]) < E_TOL
+                assert np.abs(r["forces"] - o["forces"]).max() < F_TOL
+                assert np.abs(r["virial"] - o["virial"]).max() < W_TOL
+    assert abs(oracle_eam_eval(nn, lone)["energy"]) > 1e-3          # F(0) != 0 for an nn embedding
+    med = make_eam(["Ni"], 6.0, potential=None, hidden_sizes=[8])
+    med.precision = "medium"
+    _compare(med, [fcc(rep=(2, 2, 2))])
+    tab = EamAlloyNN.from_setfl(golden_setfl("Zhou_AlCu.alloy.eam", tmp_path))
+    tab.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=5.5))
+    lone_al = Atoms(symbols=["Al"], positions=[[0.0, 0.0, 0.0]], cell=np.eye(3) * 25.0, pbc=True)
+    _compare(tab, [lone_al, _alloy(["Al", "Cu"], rep=(2, 2, 2), a=3.9)])
+
+
 def test_device_softplus_accuracy(lib):
     """The device softplus (own exp / log1p / reciprocals, ta_math.h) against NumPy in extended
     precision, through the table of an nn function whose only live unit is softplus(x)."""
