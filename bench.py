@@ -30,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md §Chip-level parameters
+# dense fp64 matrix peak: AMD's MI355X figure, 78.6 TFLOP/s = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
+# (v_mfma_f64_16x16x4_f64 = 2048 flop in 64 cycles; the guide's table has no fp64 row)
+FP64_MFMA_PEAK_TFLOPS = 78.6
 E_TOL, F_TOL = 1e-6, 1e-5  # north_star parity tolerances (eV, eV/A)
 
 
@@ -241,6 +244,23 @@ def main():
                         "frac": valu / (bwd_ms * 1e-3) / peak_issue,
                         "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
         copy_gbs = eng.measure_hbm_copy(1 << 30, 10)  # achievable copy rate on this box, SURVEY 8(d)
+        # MFMA utilisation of the batched per-atom MLP (north_star): v_mfma_f64_16x16x4_f64 count of
+        # one launch (forward + backward-to-inputs, padded tiles; equals SQ_INSTS_VALU_MFMA_F64 in
+        # profiles/r01_rocprofv3_summary.txt) x 2048 flop, over the kernel's HIP-event duration,
+        # against the dense fp64 matrix peak of MI355X_MICROARCH.md
+        sizes = [D] + list(nn.hidden_sizes[nn.elements[0]]) + [1]
+        pad = lambda v: (v + 15) // 16 * 16
+        per_tile = 2 * sum((pad(sizes[l]) // 4) * (pad(sizes[l + 1]) // 16) for l in range(len(sizes) - 1))
+        n_mfma = per_tile * ((n_atoms // fpg + 15) // 16) * fpg
+        mlp_ms = slots.get("mlp", 0.0)
+        mlp_mfma = None
+        if mlp_ms > 0:
+            tf = n_mfma * 2048.0 / (mlp_ms * 1e-3) / 1e12
+            mlp_mfma = {"kernel": "mlp_kernel<256>", "mfma_insts_per_launch": n_mfma,
+                        "flop_per_launch": n_mfma * 2048.0, "kernel_ms": mlp_ms, "achieved": tf,
+                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                        "note": "16-row tiles: one frame is 250 workgroups on 256 CUs, the kernel is "
+                                "bound by the latency of its 6 dependent GEMM phases, not by the matrix pipe"}
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "peak_measured_copy": copy_gbs,
@@ -251,6 +271,7 @@ def main():
                     "whole_eval_bytes": eval_bytes,
                     "whole_eval_frac": eval_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                     "valu_issue": valu_obj,
+                    "mlp_mfma": mlp_mfma,
                     "note": "triples are generated on the fly from LDS-staged pair records, so "
                             "HBM traffic is far below the packed-record bytes the formula prices "
                             "(frac > 1); the kernel is bounded by FP64 VALU issue, see valu_issue"}
