@@ -529,6 +529,7 @@ void fill_pairs_on_device(ta_context *h) {
 
 void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   using namespace ta;
+  h->db.rec4 = nullptr;  // only the second-generation angular path below sets it
   const DeviceBatch &db = h->db;
   hipStream_t s = h->stream;
   const bool need_forces = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
@@ -561,6 +562,10 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       used[TA_K_FORCE_GATHER] = true;
     }
   } else if (h->kind == TA_MODEL_SF_MLP) {
+    // second-generation angular path: 32-byte pair records {D, r^2} in the same buffer
+    // (TA_FULL_RECORDS=1 keeps the 64-byte ones for A/B runs)
+    static const bool full_records = getenv("TA_FULL_RECORDS") != nullptr;
+    h->db.rec4 = (h->sf.angular && h->use_v2 && !h->use_v3 && !h->use_fused && !full_records) ? h->db.rec : nullptr;
     if (!h->use_v2) {
       // second-generation forward kernels compute the pair geometry while staging
       begin(TA_K_PAIR_GEOMETRY);

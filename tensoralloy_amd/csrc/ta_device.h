@@ -66,8 +66,12 @@ struct DeviceBatch {
   int cap = kCapMin;             // records per v2 workgroup (multiple of 64)
   int32_t *elem_atoms = nullptr; // atoms grouped by element
   int32_t elem_start[kMaxElements + 1] = {0};
+
   // work buffers
   double *rec = nullptr;    // [P][8]  {Dx,Dy,Dz,r2,1/r,H0,H1,H2}
+  double *rec4 = nullptr;   // [P][4]  {Dx,Dy,Dz,r2}: compact records of the second-generation angular
+                            // path (set instead of `rec`: half the record traffic of the forward,
+                            // backward and gather kernels; 1/r is recomputed where it is needed)
   double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
   unsigned long long *masks = nullptr;  // [ceil(nnl_max/128)][P] candidate masks, forward -> backward
   double *G = nullptr;      // [N][D]
@@ -80,6 +84,13 @@ struct DeviceBatch {
   double *virial = nullptr; // [F][9]
   double *batch_energy = nullptr;  // [1]
 };
+
+// {Dx, Dy}, {Dz, r^2} of pair q, from the compact or the full record
+#ifdef __HIPCC__
+__device__ __forceinline__ const double2 *pair_geom(const DeviceBatch &b, size_t q) {
+  return reinterpret_cast<const double2 *>(b.rec4 ? b.rec4 + 4 * q : b.rec + kRecDoubles * q);
+}
+#endif
 
 // Per-element MLP on the device: padded weights, both orientations.
 struct MlpLayerDev {

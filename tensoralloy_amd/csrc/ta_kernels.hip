@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int q = ok[k] ? qb + 16 * k : q0;
-      const double2 *rec = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)q);
+      const double2 *rec = pair_geom(b, (size_t)q);
       const double2 v0 = rec[0], v1 = rec[1];
       d[k][0] = v0.x;
       d[k][1] = v0.y;

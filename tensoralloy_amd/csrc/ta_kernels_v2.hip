@@ -134,11 +134,22 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       v0 = make_double2(dx, dy);
       v1 = make_double2(dz, r2);
       v2 = make_double2(1.0 / sqrt(r2), 0.0);
-      double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)p);
-      dst[0] = v0;
-      dst[1] = v1;
-      dst[2] = v2;
-      dst[3] = make_double2(0.0, 0.0);
+      if (b.rec4) {  // compact record: 1 / r is recomputed by the readers
+        double2 *dst = reinterpret_cast<double2 *>(b.rec4 + 4 * (size_t)p);
+        dst[0] = v0;
+        dst[1] = v1;
+      } else {
+        double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)p);
+        dst[0] = v0;
+        dst[1] = v1;
+        dst[2] = v2;
+        dst[3] = make_double2(0.0, 0.0);
+      }
+    } else if (b.rec4) {
+      const double2 *src = reinterpret_cast<const double2 *>(b.rec4 + 4 * (size_t)(s0 + item));
+      v0 = src[0];
+      v1 = src[1];
+      v2 = make_double2(1.0 / sqrt(v1.y), 0.0);  // the same expression the writer used
     } else {
       const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)(s0 + item));
       v0 = src[0];

@@ -44,7 +44,7 @@ __device__ __forceinline__ void atom_descriptors(const SFParams &sf, const Devic
     for (int c0 = 0; c0 < sf.n_rad; c0 += 4) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       for (int q = q0 + l; q < q1; q += W) {
-        const double r2 = b.rec[kRecDoubles * (size_t)q + 3];
+        const double r2 = pair_geom(b, (size_t)q)[1].y;
         const double u = r2 * sf.inv_rc2;
         const double r = sqrt(r2);
         const double f = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
