@@ -33,6 +33,7 @@ void launch_mlp_grad(const MlpDev &mlp, int activation, int ndim, const int32_t 
 struct GrapModel;
 GrapModel *grap_create(const ta_model_desc *m, std::string &err);
 int grap_ndim(const GrapModel *g);
+bool grap_uses_filter_net(const GrapModel *g);
 void grap_destroy(GrapModel *);
 void grap_ensure(GrapModel *, const DeviceBatch &b);
 void launch_grap_forward(GrapModel *, const DeviceBatch &b, double eps, hipStream_t s);
@@ -635,6 +636,9 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       used[TA_K_FORCE_GATHER] = true;
     }
   } else if (h->kind == TA_MODEL_GRAP_MLP) {
+    // 32-byte pair records, as on the second-generation angular path; the `nn` filter network
+    // takes r from the full records its geometry pre-pass writes
+    h->db.rec4 = (!ta::grap_uses_filter_net(h->grap) && !getenv("TA_FULL_RECORDS")) ? h->db.rec : nullptr;
     begin(TA_K_GRAP);
     launch_grap_forward(h->grap, db, h->sf.eps, s);  // computes the pair geometry while staging
     end(TA_K_GRAP);

@@ -157,17 +157,24 @@ __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBat
         dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
         r2 = dx * dx + dy * dy + dz * dz + eps;
         inv_r = 1.0 / sqrt(r2);
-        double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * q);
-        dst[0] = make_double2(dx, dy);
-        dst[1] = make_double2(dz, r2);
-        dst[2] = make_double2(inv_r, 0.0);
+        if (b.rec4) {  // compact 32-byte record {D, r^2}: the readers recompute 1 / r
+          double2 *dst = reinterpret_cast<double2 *>(b.rec4 + 4 * q);
+          dst[0] = make_double2(dx, dy);
+          dst[1] = make_double2(dz, r2);
+        } else {
+          double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * q);
+          dst[0] = make_double2(dx, dy);
+          dst[1] = make_double2(dz, r2);
+          dst[2] = make_double2(inv_r, 0.0);
+        }
       } else {
-        const double *rec = b.rec + kRecDoubles * (size_t)(first + t);
-        dx = rec[0];
-        dy = rec[1];
-        dz = rec[2];
-        r2 = rec[3];
-        inv_r = rec[4];
+        const double2 *rec = pair_geom(b, (size_t)(first + t));
+        const double2 v0 = rec[0], v1 = rec[1];
+        dx = v0.x;
+        dy = v0.y;
+        dz = v1.x;
+        r2 = v1.y;
+        inv_r = b.rec4 ? 1.0 / sqrt(r2) : b.rec[kRecDoubles * (size_t)(first + t) + 4];
       }
       r = r2 * inv_r;  // sqrt(r2)
       ux = dx * inv_r;
@@ -786,6 +793,7 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
 }
 
 int grap_ndim(const GrapModel *g) { return g->ndim; }
+bool grap_uses_filter_net(const GrapModel *g) { return g->p.algo == GRAP_NN; }
 
 void grap_destroy(GrapModel *g) {
   if (!g) return;
