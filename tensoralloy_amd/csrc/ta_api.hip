@@ -659,6 +659,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       used[TA_K_FORCE_GATHER] = true;
     }
   } else {
+    h->db.rec4 = getenv("TA_FULL_RECORDS") ? nullptr : h->db.rec;  // 32-byte pair records {D, r^2}
     begin(TA_K_EAM);
     eam_compute(h->eam, db, want, s, nullptr);
     end(TA_K_EAM);

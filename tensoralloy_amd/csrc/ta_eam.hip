@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // left in the pair record for the pair kernel and the force gather
       double rec[5];
       if (geom_done) {  // eam_geom_kernel has been here
-        const double2 *src = reinterpret_cast<const double2 *>(b.rec + kRecDoubles * (size_t)q);
+        const double2 *src = pair_geom(b, (size_t)q);
         const double2 a = src[0], c = src[1];
         rec[0] = a.x;
         rec[1] = a.y;
@@ -378,10 +378,16 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
         rec[2] = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
         rec[3] = rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2] + eps;
         rec[4] = 1.0 / sqrt(rec[3]);
-        double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
-        dst[0] = make_double2(rec[0], rec[1]);
-        dst[1] = make_double2(rec[2], rec[3]);
-        dst[2] = make_double2(rec[4], 0.0);
+        if (b.rec4) {  // compact 32-byte record {D, r^2}: the readers recompute 1 / r
+          double2 *dst = reinterpret_cast<double2 *>(b.rec4 + 4 * (size_t)q);
+          dst[0] = make_double2(rec[0], rec[1]);
+          dst[1] = make_double2(rec[2], rec[3]);
+        } else {
+          double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
+          dst[0] = make_double2(rec[0], rec[1]);
+          dst[1] = make_double2(rec[2], rec[3]);
+          dst[2] = make_double2(rec[4], 0.0);
+        }
       }
       const double r = sqrt(rec[3]);
       double f, df;
@@ -469,10 +475,16 @@ __global__ __launch_bounds__(kBlock) void eam_geom_kernel(DeviceBatch b, double 
   const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
   const double r2 = dx * dx + dy * dy + dz * dz + eps;
   const double r = sqrt(r2);
-  double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
-  dst[0] = make_double2(dx, dy);
-  dst[1] = make_double2(dz, r2);
-  dst[2] = make_double2(1.0 / r, 0.0);
+  if (b.rec4) {
+    double2 *dst = reinterpret_cast<double2 *>(b.rec4 + 4 * (size_t)q);
+    dst[0] = make_double2(dx, dy);
+    dst[1] = make_double2(dz, r2);
+  } else {
+    double2 *dst = reinterpret_cast<double2 *>(b.rec + kRecDoubles * (size_t)q);
+    dst[0] = make_double2(dx, dy);
+    dst[1] = make_double2(dz, r2);
+    dst[2] = make_double2(1.0 / r, 0.0);
+  }
   rbuf[q] = r;
 }
 
@@ -724,9 +736,11 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const int nel = P.nel;
   const int i = b.pair_i[p];
   const int sA = b.species[i], sa = b.species[b.pair_j[p]];
-  const double *rec = b.rec + kRecDoubles * (size_t)p;
-  const double dx = rec[0], dy = rec[1], dz = rec[2], inv_r = rec[4];
-  const double r = sqrt(rec[3]);
+  const double2 *rec = pair_geom(b, (size_t)p);
+  const double2 v0 = rec[0], v1 = rec[1];
+  const double dx = v0.x, dy = v0.y, dz = v1.x;
+  const double r = sqrt(v1.y);
+  const double inv_r = 1.0 / r;  // the writer's 1 / sqrt(r^2)
   double f, drho, dphi;
   const int pt = pair_type(sA, sa, nel);
   if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
@@ -855,8 +869,8 @@ __global__ __launch_bounds__(kBlock) void eam_grad_coeff_kernel(EamParams P, Dev
     } else if (cls == 1) {
       w = 0.5 * c;
     } else {
-      const double *rec = b.rec + kRecDoubles * (size_t)p;
-      const double dx = rec[0], dy = rec[1], dz = rec[2];
+      const double2 *rec = pair_geom(b, (size_t)p);
+      const double dx = rec[0].x, dy = rec[0].y, dz = rec[1].x;
       const double *m = mom + ((size_t)i * nel + sb) * 9;
       if (cls == 2) {
         w = c * (m[0] * dx + m[1] * dy + m[2] * dz);
