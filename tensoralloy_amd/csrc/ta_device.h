@@ -69,9 +69,9 @@ struct DeviceBatch {
 
   // work buffers
   double *rec = nullptr;    // [P][8]  {Dx,Dy,Dz,r2,1/r,H0,H1,H2}
-  double *rec4 = nullptr;   // [P][4]  {Dx,Dy,Dz,r2}: compact records of the second-generation angular
-                            // path (set instead of `rec`: half the record traffic of the forward,
-                            // backward and gather kernels; 1/r is recomputed where it is needed)
+  double *rec4 = nullptr;   // [P][4]  {Dx,Dy,Dz,r2}: compact records of the second-generation angular,
+                            // GRAP and EAM / ADP paths (set instead of `rec`: half the record traffic
+                            // of the forward, backward and gather kernels; 1/r is recomputed)
   double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
   unsigned long long *masks = nullptr;  // [ceil(nnl_max/128)][P] candidate masks, forward -> backward
   double *G = nullptr;      // [N][D]
