@@ -171,7 +171,7 @@ enum {
   TA_K_PAIR_GEOMETRY = 0, TA_K_G4_FORWARD = 1, TA_K_DESCRIPTOR_REDUCE = 2,
   TA_K_MLP = 3, TA_K_BACKWARD = 4, TA_K_FORCE_GATHER = 5, TA_K_FRAME_REDUCE = 6,
   TA_K_EAM = 7,
-  TA_K_FUSED = 8, /* geometry + descriptors + MLP + dE/dD in one launch */
+  TA_K_NEIGHBOR_UPDATE = 8, /* ta_update_positions: displacement check (+ list rebuild) */
   TA_K_GRAP = 9   /* GRAP moments + features (forward) */
 };
 

@@ -19,8 +19,9 @@ CSRC_DIR = PKG_DIR / "csrc"
 INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
-SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_kernels_v3.hip", "ta_fused.hip", "ta_mlp.hip", "ta_eam.hip", "ta_nlist.hip", "ta_grap.hip", "ta_train.hip",
-           "ta_neighbor.cpp"]
+SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_mlp.hip", "ta_eam.hip",
+           "ta_nlist.hip", "ta_grap.hip", "ta_train.hip", "ta_neighbor.cpp"]
+OBJ_DIR = CSRC_DIR / "build"
 
 TA_OK = 0
 TA_ERR_INVALID, TA_ERR_UNSUPPORTED, TA_ERR_HIP, TA_ERR_NOMEM = -1, -2, -3, -4
@@ -32,7 +33,7 @@ TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
           "sigmoid": 5, "softsign": 6, "elu": 7}
 TA_N_KERNEL_SLOTS = 10
 KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
-                "force_gather", "frame_reduce", "eam", "fused", "grap_forward"]
+                "force_gather", "frame_reduce", "eam", "neighbor_update", "grap_forward"]
 
 # every symbol include/tensoralloy_amd.h declares
 EXPORTED_SYMBOLS = [
@@ -85,10 +86,17 @@ def hipcc_path() -> str:
     return "hipcc"
 
 
+def _compile_flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", f"-I{INCLUDE_DIR}",
+            f"-I{CSRC_DIR}"] + os.environ.get("TA_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 into the in-tree shared library."""
+    """Compile every HIP source for gfx950 into the in-tree shared library: one object per
+    translation unit, compiled in parallel (only the stale ones), then one link."""
     srcs = [CSRC_DIR / s for s in SOURCES]
-    deps = srcs + list(CSRC_DIR.glob("*.h")) + [INCLUDE_DIR / "tensoralloy_amd.h"]
+    headers = list(CSRC_DIR.glob("*.h")) + [INCLUDE_DIR / "tensoralloy_amd.h"]
+    deps = srcs + headers
     if not force and LIB_PATH.exists():
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:
@@ -96,16 +104,40 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     # several ranks may get here at once (torchrun): one builds, the others wait for the lock and
     # then find the library up to date; the output appears atomically
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     lock_path = str(LIB_PATH) + ".lock"
     with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in deps):
                 return LIB_PATH
+            OBJ_DIR.mkdir(exist_ok=True)
+            flags = _compile_flags()
+            stamp = OBJ_DIR / "flags.txt"
+            if not stamp.exists() or stamp.read_text() != " ".join(flags):
+                force = True
+            hdr_time = max(p.stat().st_mtime for p in headers)
+
+            def compile_one(src):
+                obj = OBJ_DIR / (src.stem + ".o")
+                if not force and obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, hdr_time):
+                    return obj
+                cmd = [hipcc_path()] + flags + ["-c", str(src), "-o", str(obj)]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                return obj
+
+            try:
+                jobs = max(1, min(len(srcs), len(os.sched_getaffinity(0))))
+            except AttributeError:
+                jobs = 4
+            with ThreadPoolExecutor(max_workers=jobs) as pool:
+                objs = list(pool.map(compile_one, srcs))
+            stamp.write_text(" ".join(flags))
             tmp = str(LIB_PATH) + f".tmp{os.getpid()}"
-            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                   "-pthread", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}"] + os.environ.get("TA_EXTRA_HIPCC_FLAGS", "").split() + \
-                  [str(s) for s in srcs] + ["-o", tmp]
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + \
+                  [str(o) for o in objs] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

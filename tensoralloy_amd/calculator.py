@@ -146,11 +146,13 @@ class TensorAlloyCalculator(BaseCalculator):
         atoms = atoms if atoms is not None else self.atoms
         gsl = self.get_property("forces", atoms)
         # the engine delivers the caller's order; `results` holds the GSL-ordered copy the reference
-        # exposes. When that copy is the one made by the last `calculate`, mapping it back
-        # (calculator.py:247-249) would only undo the permutation.
+        # exposes. `get_property` hands out copies, so the shortcut is keyed on the evaluation
+        # counter: while `results["forces"]` is still the array the last `calculate` stored, mapping
+        # it back (calculator.py:247-249) would only undo the permutation.
         cached = getattr(self, "_forces_local", None)
-        if cached is not None and cached[0] is gsl:
-            return cached[1].copy()
+        if cached is not None and cached[0] == self._ncalls and \
+                self.results.get("forces") is cached[1] and cached[2].shape == gsl.shape:
+            return cached[2].copy()
         forces = np.insert(gsl, 0, 0, 0)
         clf = self.transformer.get_vap_transformer(atoms)
         return clf.map_forces(forces, reverse=True)
@@ -284,6 +286,9 @@ class TensorAlloyCalculator(BaseCalculator):
                 results[target] = vap.map_forces(res["forces"])[1:]
                 local_forces = res["forces"]
             elif target in ("stress", "virial", "total_pressure"):
+                if target not in res:
+                    raise ValueError(f"'{target}' needs a cell with three lattice vectors: "
+                                     "volume not defined")
                 results[target] = res[target]
         if debug_mode:
             results["descriptors"] = res["descriptors"]
@@ -293,8 +298,9 @@ class TensorAlloyCalculator(BaseCalculator):
             if local_forces is not None:
                 local_forces = np.asarray(local_forces, dtype=self._fp_dtype)
         self.results = results
-        self._forces_local = (results["forces"], local_forces) if local_forces is not None else None
         self._ncalls += 1
+        self._forces_local = (self._ncalls, results["forces"], local_forces) \
+            if local_forces is not None else None
 
     def reset_call_counter(self):
         self._ncalls = 0

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,11 +78,25 @@ struct DevBuf {
   size_t cap = 0;
   void ensure(size_t n) {
     if (n <= cap) return;
-    if (ptr) HIP_CHECK(hipFree(ptr));
-    ptr = nullptr;
-    cap = 0;
+    // the old allocation stays valid until the new one exists: a failed hipMalloc must not
+    // leave a dangling pointer behind (contents are not carried over: every user refills)
     size_t want = n + n / 8 + 64;
-    HIP_CHECK(hipMalloc((void **)&ptr, want * sizeof(T)));
+    T *fresh = nullptr;
+    hipError_t e = hipMalloc((void **)&fresh, want * sizeof(T));
+    if (e != hipSuccess && ptr) {  // retry once with the old block returned first
+      (void)hipGetLastError();
+      HIP_CHECK(hipFree(ptr));
+      ptr = nullptr;
+      cap = 0;
+      e = hipMalloc((void **)&fresh, want * sizeof(T));
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      throw HipError(std::string("hipMalloc of ") + std::to_string(want * sizeof(T)) + " bytes: " +
+                     hipGetErrorString(e));
+    }
+    if (ptr) HIP_CHECK(hipFree(ptr));
+    ptr = fresh;
     cap = want;
   }
   void release() {
@@ -130,9 +145,6 @@ struct ta_context {
   std::vector<ChunkPlan> chunks;     // first-generation kernels: up to 2 betas per launch
   std::vector<ChunkPlan> chunks_v2;  // second-generation kernels: one beta per launch
   bool use_v2 = false;
-  bool use_v3 = false;               // wavefront-balanced kernels (subset of the v2 conditions)
-  bool use_fused = false;            // one-launch per-centre kernel (subset of the v2 conditions)
-  ta::FusedPlan fplan;
   ta::MlpDev *mlp_dev = nullptr;     // device copy of mlp[0..n_elements)
   ta::MlpDev mlp[ta::kMaxElements];
   std::vector<void *> model_allocs;
@@ -491,7 +503,7 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   h->nl_counts.ensure(N * (nel + 1) + 1);
   h->seg_start.ensure(N * (nel + 1) + 1);
   h->pair_start.ensure(N + 1);
-  h->nl_stats.ensure(4);
+  h->nl_stats.ensure(8);
   NlWork w = nl_work(h);
   nl_count((int)N, n_bins, nel, h->rmax, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
            h->pair_start.ptr, s);
@@ -500,11 +512,12 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   h->stage_out.ensure(64 + (N + 1) * sizeof(int32_t));
   unsigned long long *stats = reinterpret_cast<unsigned long long *>(h->stage_out.ptr);
   int32_t *starts = reinterpret_cast<int32_t *>(h->stage_out.ptr + 64);
-  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipMemcpyAsync(starts, h->pair_start.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   const int32_t *si = reinterpret_cast<const int32_t *>(stats);
-  if (si[4] < 0) throw std::runtime_error("batch too large for 32-bit pair indices");
+  if (stats[4] > (unsigned long long)INT32_MAX || si[4] < 0 || (unsigned long long)si[4] != stats[4])
+    throw std::runtime_error("batch too large for 32-bit pair indices");
   hp.n_atoms = (int64_t)N;
   hp.n_pairs = si[4];
   hp.n_triples = (int64_t)stats[0];
@@ -550,23 +563,11 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
                    h->mlp_scratch.ptr, s);
     end(TA_K_MLP);
     used[TA_K_MLP] = true;
-  } else if (h->kind == TA_MODEL_SF_MLP && h->use_fused) {
-    begin(TA_K_FUSED);
-    launch_sf_fused(h->sf, h->chunks_v2[0].ch, h->chunks_v2[0].ng, h->chunks_v2[0].nz, db, h->fplan,
-                    h->mlp_dev, h->activation, need_forces, h->mlp_scratch.ptr, s);
-    end(TA_K_FUSED);
-    used[TA_K_FUSED] = true;
-    if (need_forces) {
-      begin(TA_K_FORCE_GATHER);
-      launch_force_gather(h->sf, db, s);
-      end(TA_K_FORCE_GATHER);
-      used[TA_K_FORCE_GATHER] = true;
-    }
   } else if (h->kind == TA_MODEL_SF_MLP) {
     // second-generation angular path: 32-byte pair records {D, r^2} in the same buffer
     // (TA_FULL_RECORDS=1 keeps the 64-byte ones for A/B runs)
     static const bool full_records = getenv("TA_FULL_RECORDS") != nullptr;
-    h->db.rec4 = (h->sf.angular && h->use_v2 && !h->use_v3 && !h->use_fused && !full_records) ? h->db.rec : nullptr;
+    h->db.rec4 = (h->sf.angular && h->use_v2 && !full_records) ? h->db.rec : nullptr;
     if (!h->use_v2) {
       // second-generation forward kernels compute the pair geometry while staging
       begin(TA_K_PAIR_GEOMETRY);
@@ -576,7 +577,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
     }
     h->sf.ang_scale = h->use_v2 ? 1.0 : 0.5;
     // the second-generation forward kernel assembles the descriptors itself in its last launch
-    const bool reduce_in_forward = h->sf.angular && h->use_v2 && !h->use_v3;
+    const bool reduce_in_forward = h->sf.angular && h->use_v2;
     if (h->sf.angular) {
       begin(TA_K_G4_FORWARD);
       if (h->use_v2) {
@@ -584,10 +585,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
         size_t left = h->chunks_v2.size();
         for (const ChunkPlan &cp : h->chunks_v2) {
           --left;
-          if (h->use_v3)
-            launch_g4_forward_v3(h->sf, cp.ch, cp.ng, cp.nz, geometry, db, s);
-          else
-            launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, left == 0, db, s);
+          launch_g4_forward_v2(h->sf, cp.ch, cp.ng, cp.nz, geometry, left == 0, db, s);
           geometry = false;
         }
       } else
@@ -612,10 +610,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
         bool first = true;
         if (h->use_v2)
           for (const ChunkPlan &cp : h->chunks_v2) {
-            if (h->use_v3)
-              launch_backward_v3(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
-            else
-              launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
             first = false;
           }
         else
@@ -809,6 +804,10 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
         throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
     }
     const auto t_begin = std::chrono::steady_clock::now();
+    // no batch is resident until this call has succeeded: a failure below (allocation, too many
+    // neighbours, asymmetric list ...) must not leave the previous batch's flags standing over
+    // buffers that were already regrown or repointed
+    h->have_batch = false;
     h->descriptors_valid = false;
     size_t N = 0;
     for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
@@ -902,7 +901,7 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
     if (h->pairs_on_device) {
       fill_pairs_on_device(h);
       // "reverse pair missing" counter, read after the synchronisation below
-      HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 4 * sizeof(unsigned long long),
+      HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 8 * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, h->stream));
     }
     // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
@@ -917,23 +916,6 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
                 h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
     const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
     h->db.cap = cap;
-    // wavefront-balanced variant: measured no faster than the per-lane kernels on MI355X
-    // (profiles/r01_tuning_notes.md), kept selectable with TA_USE_V3=1
-    {
-      int stride_max = 0;
-      for (int e = 0; e < h->n_elements; ++e) {
-        const int w = std::max(h->mlp[e].max_np, h->mlp[e].max_kp);
-        stride_max = std::max(stride_max, w + 2);
-      }
-      // one-launch variant: measured on MI355X at parity for one frame and slower in batches
-      // (every workgroup pays a 16-row MFMA tile for its ~2 centres), so it is opt-in
-      h->use_fused = h->use_v2 && h->n_elements <= 3 && h->chunks_v2.size() == 1 && h->hp.nnl_max <= 128 &&
-                     std::getenv("TA_USE_FUSED") != nullptr && std::getenv("TA_USE_FUSED")[0] == '1' &&
-                     ta::fused_plan(h->sf, h->n_elements, h->chunks_v2[0].ng, h->chunks_v2[0].nz, cap,
-                                    stride_max, h->fplan);
-    }
-    h->use_v3 = h->use_v2 && h->n_elements <= 3 && h->hp.nnl_max <= 255 && std::getenv("TA_USE_V3") != nullptr &&
-                std::getenv("TA_USE_V3")[0] == '1';
     {
       int32_t *blk = reinterpret_cast<int32_t *>(hb + o_blk);
       int nb = 0;
@@ -961,7 +943,6 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batc
       if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
         throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
       size_t need = ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start);
-      if (h->use_fused) need = std::max(need, ta::fused_scratch_doubles(h->fplan, h->db.n_blk));
       h->mlp_scratch.ensure(need);
     } else if (h->kind == TA_MODEL_GRAP_MLP) {
       h->mlp_scratch.ensure(ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start));

@@ -15,7 +15,7 @@ constexpr int kRecDoubles = 8;    // pair record = 64 bytes
 constexpr int kMaxLayers = 8;
 constexpr int kCapMin = 192;      // pair records one v2 workgroup (one wavefront) stages in LDS
 constexpr int kCapMax = 1024;
-constexpr int kMaxCentersPerBlock = 16;  // v3 kernels keep per-centre weight tables in LDS
+constexpr int kMaxCentersPerBlock = 16;  // centres one angular workgroup may own
 constexpr int kMaxHd = 24;        // coefficients of the Hd(u) expansion
 
 // Symmetry-function constants, passed by value to every kernel.
@@ -130,30 +130,6 @@ void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz
 void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
 
-// fused per-centre kernel (ta_fused.hip): geometry -> descriptors -> MLP -> dE/dD in one launch
-struct FusedPlan {  // LDS offsets in doubles, computed on the host
-  int cap;
-  int npart;      // per-item partial sums: NSPEC*NG*NZ + n_rad
-  int stride;     // MLP row stride
-  int off_tab;    // gtab[16][ndim], dtab[16][ndim], segs (ints)
-  int off_b;      // phase-dependent region: P / buf1 / gacc
-  int off_buf0;
-  int total;      // doubles
-};
-bool fused_plan(const SFParams &sf, int nspec, int ng, int nz, int cap, int mlp_stride_max,
-                FusedPlan &pl);
-size_t fused_scratch_doubles(const FusedPlan &pl, int n_blk);
-void launch_sf_fused(const SFParams &sf, const AngChunk &ch, int ng, int nz, const DeviceBatch &b,
-                     const FusedPlan &pl, const MlpDev *mlps, int act, bool want_forces,
-                     double *scratch, hipStream_t s);
-
-// third-generation (wavefront-balanced) angular kernels (ta_kernels_v3.hip): cap <= 256,
-// at most kMaxCentersPerBlock centres per workgroup
-void launch_g4_forward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
-                          const DeviceBatch &b, hipStream_t s);
-void launch_backward_v3(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
-                        const DeviceBatch &b, hipStream_t s);
-
 // device-side neighbour list (ta_nlist.hip)
 struct NlGrid {  // linked-cell grid of one frame, in fractional coordinates
   double h[9];
@@ -182,8 +158,8 @@ struct NlWork {  // device work buffers, sized by the caller
   NlRec *recs;          // [N]
   int32_t *counts;      // [N (nel + 1) + 1]
   int32_t *seg_start;   // [N (nel + 1) + 1]
-  // stats[0] = number of triples; as int32: [2] nnl_max, [4] number of pairs, [6] pairs
-  // without a reverse partner (must stay 0)
+  // 8 words. stats[0] = number of triples; as int32: [2] nnl_max, [4] number of pairs (32-bit scan
+  // total), [6] pairs without a reverse partner (must stay 0); stats[4] = number of pairs, 64-bit
   unsigned long long *stats;
 };
 bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g);

@@ -24,6 +24,8 @@
 // (no atomics, no cross-lane traffic); the descriptor sum takes half of it.
 #include <hip/hip_runtime.h>
 
+#include <stdexcept>
+
 #include "ta_device.h"
 #include "ta_math.h"
 #include "ta_reduce.h"
@@ -493,7 +495,7 @@ void launch_pair_geometry(const SFParams &sf, const DeviceBatch &b, hipStream_t 
       case 212: FN<2, 1, 2>(__VA_ARGS__); break;                         \
       case 221: FN<2, 2, 1>(__VA_ARGS__); break;                         \
       case 222: FN<2, 2, 2>(__VA_ARGS__); break;                         \
-      default: break;                                                    \
+      default: throw std::domain_error("no angular kernel for this (beta, gamma, zeta) chunk shape"); \
     }                                                                    \
   } while (0)
 

@@ -32,6 +32,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 
 #include "ta_device.h"
 #include "ta_math.h"
@@ -766,7 +767,8 @@ size_t v2_lds_bytes(bool backward, int cap) {
       case 322: FN<3, 2, 2>(__VA_ARGS__); break;                  \
       case 422: FN<4, 2, 2>(__VA_ARGS__); break;                  \
       case 522: FN<5, 2, 2>(__VA_ARGS__); break;                  \
-      default: break;                                             \
+      default:                                                    \
+        throw std::domain_error("no second-generation angular kernel for this (species, gamma, zeta) shape"); \
     }                                                             \
   } while (0)
 

@@ -227,9 +227,11 @@ __global__ __launch_bounds__(kBlock) void pairs_kernel(int n_atoms, int nel, dou
 // seg_start (from the scan) -> pair_start, and per-atom statistics
 __global__ __launch_bounds__(kBlock) void finish_starts_kernel(int n_atoms, int nel,
                                                                const int32_t *seg_start,
+                                                               const int32_t *counts,
                                                                int32_t *pair_start,
                                                                unsigned long long *n_triples,
-                                                               int32_t *nnl_max) {
+                                                               int32_t *nnl_max,
+                                                               unsigned long long *n_pairs64) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i > n_atoms) return;
   if (i == n_atoms) {
@@ -240,7 +242,12 @@ __global__ __launch_bounds__(kBlock) void finish_starts_kernel(int n_atoms, int 
   pair_start[i] = a;
   const int n = b - a;
   atomicAdd(n_triples, (unsigned long long)n * (unsigned long long)(n - 1) / 2ull);
-  atomicMax(nnl_max, n);
+  // 64-bit total of the per-atom counts (from the int32 counts array, not from the scan): a batch
+  // whose 32-bit running sum wraps is detected by the host even when the wrapped value is positive
+  unsigned long long cnt = 0;
+  for (int sp = 0; sp < nel; ++sp) cnt += (unsigned long long)(unsigned)counts[(size_t)i * (nel + 1) + sp];
+  atomicAdd(n_pairs64, cnt);
+  atomicMax(nnl_max, (int)cnt);
 }
 
 // (i -> j, S) <-> (j -> i, -S): eight lanes search j's segment of species(i)
@@ -357,7 +364,7 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
               hipStream_t s) {
   (void)hipMemsetAsync(w.bin_count, 0, (size_t)(n_bins + 1) * sizeof(int32_t), s);
   (void)hipMemsetAsync(w.bin_cursor, 0, (size_t)(n_bins + 1) * sizeof(int32_t), s);
-  (void)hipMemsetAsync(w.stats, 0, 4 * sizeof(unsigned long long), s);
+  (void)hipMemsetAsync(w.stats, 0, 8 * sizeof(unsigned long long), s);
   if (n_atoms == 0) return;
   hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
                      frame_of_atom, grids, w.wrap, w.binid, w.bin_count);
@@ -374,8 +381,8 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), w.counts,
                      w.seg_start, reinterpret_cast<int32_t *>(w.stats) + 4);
   hipLaunchKernelGGL(finish_starts_kernel, dim3(nblk(n_atoms + 1, kBlock)), dim3(kBlock), 0, s,
-                     n_atoms, nel, w.seg_start, pair_start, w.stats,
-                     reinterpret_cast<int32_t *>(w.stats) + 2);
+                     n_atoms, nel, w.seg_start, w.counts, pair_start, w.stats,
+                     reinterpret_cast<int32_t *>(w.stats) + 2, w.stats + 4);
 }
 
 void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,

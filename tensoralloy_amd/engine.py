@@ -131,9 +131,13 @@ class Engine:
                 d["forces"] = res["forces"][a:a + n].copy()
                 w = res["virial"][f].copy()
                 d["virial"] = w
-                s = w / self._volumes[f]                       # basic.py:317
-                d["stress"] = np.array([s[0, 0], s[1, 1], s[2, 2], s[1, 2], s[0, 2], s[0, 1]])
-                d["total_pressure"] = float(np.trace(s) / (-3.0 * GPa))  # basic.py:403-405
+                # a frame without three lattice vectors has no volume (ASE's `get_volume`, which
+                # feeds the reference's `volume` placeholder at universal.py:865, raises for it):
+                # the virial is still defined, stress and pressure are not and are left out
+                if self._volumes[f] > 0.0:
+                    s = w / self._volumes[f]                       # basic.py:317
+                    d["stress"] = np.array([s[0, 0], s[1, 1], s[2, 2], s[1, 2], s[0, 2], s[0, 1]])
+                    d["total_pressure"] = float(np.trace(s) / (-3.0 * GPa))  # basic.py:403-405
             if "descriptors" in res:
                 d["descriptors"] = res["descriptors"][a:a + n].copy()
             out.append(d)

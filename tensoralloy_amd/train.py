@@ -66,13 +66,19 @@ def unflatten_weights(nn, flat: np.ndarray) -> Dict[str, List]:
 
 
 def trainable_mask(nn) -> np.ndarray:
-    """1 for real parameters, 0 for the bias slots of layers that have no bias."""
+    """1 for real parameters, 0 for the bias slots of layers that have no bias and, when the model
+    was built with `fixed_atomic_static_energy=True`, for every element's output bias: the
+    reference creates that bias with `trainable=False` (atomic.py:249 -> `convolution1x1(...,
+    fixed_output_bias=True)`, convolutional.py:277-290), so the atomic static energies stay put."""
+    frozen_output_bias = bool(getattr(nn, "_fixed_atomic_static_energy", False))
     out = []
     for box, key in _networks(nn):
-        for w, b in box[key]:
+        layers = box[key]
+        for l, (w, b) in enumerate(layers):
             shape = np.shape(w)
             out.append(np.ones(shape[0] * shape[1]))
-            out.append(np.zeros(shape[1]) if b is None else np.ones(shape[1]))
+            frozen = b is None or (frozen_output_bias and l == len(layers) - 1)
+            out.append(np.zeros(shape[1]) if frozen else np.ones(shape[1]))
     return np.concatenate(out)
 
 

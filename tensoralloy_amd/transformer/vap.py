@@ -1,9 +1,12 @@
 """
 Virtual-atom map: permutation between an `Atoms`' own order ("local") and the
-element-sorted, 1-based "global symbol list" order with a virtual atom at row 0.
+element-sorted, 1-based "global symbol list" (GSL) order with a virtual atom at
+row 0 and room for `max_occurs[element]` atoms per element.
 
-Mirrors reference tensoralloy/transformer/vap.py:18-197 (same attribute and
-method names, same index conventions) with vectorised NumPy instead of loops.
+Interface of reference tensoralloy/transformer/vap.py:18-197 (attribute and
+method names, index conventions, error messages); the maps themselves are
+computed here from one stable argsort by element instead of the reference's
+per-atom counters, and `map_array` scatters / gathers with index arrays.
 """
 from __future__ import annotations
 
@@ -19,33 +22,32 @@ class VirtualAtomMap:
     def __init__(self, max_occurs: Counter, symbols: List[str]):
         self._symbols = list(symbols)
         self._max_occurs = max_occurs
-        self._max_vap_natoms = int(sum(max_occurs.values()) + 1)
-        istart = VirtualAtomMap.REAL_ATOM_START
         elements = sorted(max_occurs.keys())
-        offsets = np.concatenate(([0], np.cumsum([max_occurs[e] for e in elements])[:-1]))
-        delta = Counter()
-        index_map = {}
-        mask = np.zeros(self._max_vap_natoms, dtype=bool)
-        for i, symbol in enumerate(self._symbols):
-            idx_new = int(offsets[elements.index(symbol)]) + delta[symbol] + istart
-            index_map[i + istart] = idx_new
-            delta[symbol] += 1
-            mask[idx_new] = True
-        reverse_map = {v: k - 1 for k, v in index_map.items()}
-        index_map[0] = 0
-        reverse_map[0] = -1
-        self._mask = mask
-        self.local_to_gsl_map = index_map
-        self.gsl_to_local_map = reverse_map
-        self._vap_symbols = ["X"]
-        for element in elements:
-            self._vap_symbols.extend([element] * self._max_occurs[element])
-        # array forms for vectorised use
+        capacity = np.array([max_occurs[e] for e in elements], dtype=np.int64)
+        self._max_vap_natoms = int(capacity.sum()) + 1
         n = len(self._symbols)
-        self.local_to_gsl = np.array([index_map[i + istart] for i in range(n)], dtype=np.int64)
-        self._gather_fwd = np.array(
-            [reverse_map.get(i, -1) + istart for i in range(self._max_vap_natoms)],
-            dtype=np.int64)
+
+        # rank of every atom among the atoms of its own element, in local order
+        code_of = {e: k for k, e in enumerate(elements)}
+        codes = np.fromiter((code_of[s] for s in self._symbols), dtype=np.int64, count=n)
+        grouped = np.argsort(codes, kind="stable")
+        present = np.bincount(codes, minlength=len(elements))
+        group_begin = np.cumsum(present) - present
+        rank = np.empty(n, dtype=np.int64)
+        rank[grouped] = np.arange(n) - group_begin[codes[grouped]]
+        # GSL row = 1 + (rows reserved for the elements before it) + rank
+        block_begin = np.cumsum(capacity) - capacity
+        self.local_to_gsl = self.REAL_ATOM_START + block_begin[codes] + rank
+
+        self._mask = np.zeros(self._max_vap_natoms, dtype=bool)
+        self._mask[self.local_to_gsl] = True
+        self._vap_symbols = ["X"] + [e for e, c in zip(elements, capacity) for _ in range(int(c))]
+        # dictionary views with the reference's keys: 1-based local index -> GSL row, and back
+        self.local_to_gsl_map = {0: 0}
+        self.local_to_gsl_map.update(
+            {i + self.REAL_ATOM_START: int(g) for i, g in enumerate(self.local_to_gsl)})
+        self.gsl_to_local_map = {0: -1}
+        self.gsl_to_local_map.update({int(g): i for i, g in enumerate(self.local_to_gsl)})
 
     @property
     def vap_symbols(self):
@@ -68,26 +70,22 @@ class VirtualAtomMap:
         return self._mask
 
     def map_array(self, array: np.ndarray, reverse=False):
-        """local -> GSL (a zero row is inserted for the virtual atom), or
-        GSL -> local when `reverse`."""
+        """local -> GSL (rows of absent atoms and the virtual atom are zero), or
+        GSL -> local when `reverse`. Rank 2 `[atoms, c]` or rank 3 `[batch, atoms, c]`."""
         array = np.asarray(array)
-        rank = np.ndim(array)
-        if rank == 2:
-            array = array[np.newaxis, ...]
-        elif rank <= 1 or rank > 3:
+        rank = array.ndim
+        if rank not in (2, 3):
             raise ValueError("The rank should be 2 or 3")
-        if not reverse:
-            if array.shape[1] == len(self._symbols):
-                array = np.insert(array, 0, np.asarray(0, dtype=array.dtype), axis=1)
-            else:
-                shape = (array.shape[0], len(self._symbols), array.shape[2])
-                raise ValueError(f"The shape should be {shape}")
-            output = array[:, self._gather_fwd]
+        batched = array if rank == 3 else array[np.newaxis]
+        if reverse:
+            out = batched[:, self.local_to_gsl]
         else:
-            output = array[:, self.local_to_gsl]
-        if rank == 2:
-            output = np.squeeze(output, axis=0)
-        return output
+            want = (batched.shape[0], len(self._symbols), batched.shape[2])
+            if batched.shape != want:
+                raise ValueError(f"The shape should be {want}")
+            out = np.zeros((want[0], self._max_vap_natoms, want[2]), dtype=array.dtype)
+            out[:, self.local_to_gsl] = batched
+        return out if rank == 3 else out[0]
 
     def map_positions(self, positions: np.ndarray, reverse=False):
         return self.map_array(positions, reverse=reverse)
@@ -96,12 +94,13 @@ class VirtualAtomMap:
         return self.map_array(forces, reverse=reverse)
 
     def reverse_map_hessian(self, hessian: np.ndarray, phonopy_format=False):
-        rank = np.ndim(hessian)
-        if rank != 4 or hessian.shape[1] != 3 or hessian.shape[3] != 3:
+        """`[n_vap, 3, n_vap, 3]` in GSL order -> local order, as `[3n, 3n]` or, with
+        `phonopy_format`, `[n, n, 3, 3]`."""
+        hessian = np.asarray(hessian)
+        if hessian.ndim != 4 or hessian.shape[1] != 3 or hessian.shape[3] != 3:
             raise ValueError("The input array should be a 4D matrix of shape [Np, 3, Np, 3]")
-        idx = self.local_to_gsl
-        h = np.asarray(hessian)[idx][:, :, idx, :]  # [n, 3, n, 3]
-        n = len(idx)
+        rows = self.local_to_gsl
+        local = hessian[np.ix_(rows, np.arange(3), rows, np.arange(3))]
         if phonopy_format:
-            return np.transpose(h, (0, 2, 1, 3)).copy()
-        return h.reshape(n * 3, n * 3)
+            return np.ascontiguousarray(local.transpose(0, 2, 1, 3))
+        return local.reshape(3 * len(rows), 3 * len(rows))

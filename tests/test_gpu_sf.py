@@ -139,29 +139,19 @@ def test_empty_and_single_atom_frames(lib):
         assert res == []
 
 
-def test_wavefront_balanced_kernels(lib, monkeypatch):
-    """TA_USE_V3 selects the wavefront-balanced kernels; results must not change."""
-    monkeypatch.setenv("TA_USE_V3", "1")
-    nn = make_nn(["Ni", "Mo"], 6.5, True, [32, 32])
-    _compare(nn, [_alloy(["Ni", "Mo"], rep=(2, 2, 2)), fcc(rep=(2, 2, 2))])
-
-
 def test_many_neighbours_multi_pass(lib):
     """rc = 9 A: ~260 neighbours per atom (> 255): second-generation kernels, 2 lanes passes."""
     nn = make_nn(["Ni"], 9.0, True, [16], sf_kwargs=dict(eta=[0.5, 4.0]))
     _compare(nn, [fcc(rep=(2, 2, 2), a=3.4)])
 
 
-def test_mid_neighbour_count_three_passes(lib, monkeypatch):
-    """rc = 8 A: ~180 neighbours per atom: balanced kernels with three 32-step passes."""
-    monkeypatch.setenv("TA_USE_V3", "1")
+def test_mid_neighbour_count(lib):
+    """rc = 8 A: ~180 neighbours per atom: more than one candidate block of 64 per lane."""
     nn = make_nn(["Ni"], 8.0, True, [16], sf_kwargs=dict(eta=[0.5, 4.0]))
     _compare(nn, [fcc(rep=(2, 2, 2), a=3.5)])
 
 
-def test_fused_one_launch_kernel(lib, monkeypatch):
-    """TA_USE_FUSED runs geometry + descriptors + MLP + dE/dD in one launch (opt-in variant)."""
-    monkeypatch.setenv("TA_USE_FUSED", "1")
+def test_alloy_minmax_and_resnet_variants(lib):
     nn = make_nn(["Ni", "Mo"], 6.5, True, [32, 32], minmax=True)
     _compare(nn, [_alloy(["Ni", "Mo"], rep=(2, 2, 2)), fcc(rep=(2, 2, 2))])
     nn = make_nn(["Al", "Cu", "Ni"], 5.0, True, [16, 16], activation="tanh", resnet=True)
