@@ -137,6 +137,12 @@ typedef struct {
   const int32_t *eam_table_n;
   const double *eam_table_dx;
   const double *eam_table_coef;
+
+  /* 1: powers with a non-integer exponent ((1 + gamma cos)^zeta, sf.py:162-164) use the reference's
+   * custom-gradient `safe_pow` (extension/grad_ops.py:16-66, selected there by the environment
+   * variable TENSORALLOY_USE_CUSTOM_POW): an infinite value and an infinite or NaN derivative factor
+   * become 0. 0: plain pow, as `tf.pow`. Integer exponents are products and never singular. */
+  int32_t safe_pow;
 } ta_model_desc;
 
 /* One structure = what `UniversalTransformer.get_np_feed_dict(atoms)`
@@ -190,8 +196,24 @@ const char *ta_last_error(ta_handle h); /* h may be NULL: last create error */
 int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames,
                   ta_batch_info *info);
 
-/* new positions/cells for the resident batch, same neighbour topology is NOT
- * assumed: the list is rebuilt (equivalent to ta_set_frames). */
+/* MD loop. The reference rebuilds its whole feed dict for every call of `calculate`
+ * (calculator.py:355-366 -> get_np_feed_dict, universal.py:851-893). Here the resident batch keeps
+ * its atoms, species and periodicity; only coordinates travel:
+ *   ta_set_skin          Verlet skin (Angstrom, >= 0; default 0). Lists built from now on cover
+ *                        max(rcut, acut) + skin. Pairs beyond the cutoff contribute nothing (cutoff
+ *                        functions; explicit r < rcut test in the EAM / ADP kernels), so results are
+ *                        those of the exact list up to summation order. Changing the skin drops the
+ *                        resident list (the next ta_update_positions / ta_set_frames rebuilds it).
+ *   ta_update_positions  positions [n_atoms_total][3] (and cells [n_frames][9], or NULL = unchanged)
+ *                        for the frames of the last ta_set_frames, in the same order. The list is
+ *                        reused while no atom is further than skin / 2 from where it was when the
+ *                        list was built and no cell has changed; otherwise it is rebuilt exactly as
+ *                        ta_set_frames does. *rebuilt (may be NULL) = 1 when it was rebuilt.
+ *                        With skin = 0 every call rebuilds. Asynchronous on the reuse path.
+ *   ta_list_stats        lists built / reused by this handle so far. */
+int ta_set_skin(ta_handle h, double skin);
+int ta_update_positions(ta_handle h, const double *positions, const double *cells, int32_t *rebuilt);
+int ta_list_stats(ta_handle h, int64_t *n_builds, int64_t *n_reuses);
 
 /* replaces Session.run(ops, feed_dict) (calculator.py:368): enqueues the
  * kernels on the handle's stream; asynchronous. */
@@ -231,6 +253,12 @@ int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
  * bytes by a grid-stride kernel (16 B per lane) on the handle's stream, `reps` timed repetitions
  * after 2 untimed ones; *gbs = (bytes read + bytes written) / average time, in GB/s. */
 int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs);
+
+/* Measurement (bench.py, SURVEY 8(d) FP64 figure): number of unordered neighbour pairs {j, k} of the
+ * resident batch's centres with r_ij, r_ik and r_jk all below acut, i.e. the triples whose G4 term
+ * (sf.py:126-173) is not identically zero; ta_batch_info.n_triples counts all of them. Runs one
+ * energy evaluation first (the count reads the pair records). */
+int ta_count_contributing_triples(ta_handle h, int64_t *n_contributing);
 
 /* sum of the resident batch's frame energies, left on the device for a
  * collective: returns a device pointer to one double (valid until destroy). */

@@ -123,8 +123,12 @@ class SFModel:
                  eta=(0.05, 4.0, 20.0, 80.0), omega=(0.0,), beta=(0.005,),
                  gamma=(1.0, -1.0), zeta=(1.0, 4.0), cutoff_function="cosine",
                  hidden_sizes=None, activation="softplus", weights=None,
-                 use_resnet_dt=False, minmax=None, symmetric=True):
+                 use_resnet_dt=False, minmax=None, symmetric=True, safe_pow=False):
         self.elements = sorted(set(elements))
+        # which `safe_pow` of extension/grad_ops.py:16-74: False = plain tf.pow (the reference's
+        # default: the gradient factor zeta base^(zeta-1) is Inf at base = 0 for zeta < 1),
+        # True = the TENSORALLOY_USE_CUSTOM_POW variant (Inf values and Inf/NaN gradients -> 0)
+        self.safe_pow = bool(safe_pow)
         # symmetric=False lists every neighbour pair of a centre in both orders
         # (universal.py:183-203). The reference's SymmetryFunction holds n(n+1)/2 angular
         # terms (sf.py:131-132), so this only exists for one element.
@@ -334,7 +338,11 @@ def evaluate(model: SFModel, symbols, positions, cell, pbc, want_forces=True,
                           for x, y in zip(ta, tb)], dtype=np.int64)
         fprod = fa * fb * fd
         for c, (beta, gamma, zeta) in enumerate(ang):
-            v = 2.0 ** (1.0 - zeta) * (1.0 + gamma * cos) ** zeta * np.exp(-beta * z) * fprod
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pw = (1.0 + gamma * cos) ** zeta
+            if model.safe_pow:
+                pw = np.where(np.isinf(pw), 0.0, pw)       # grad_ops.py:25-26
+            v = 2.0 ** (1.0 - zeta) * pw * np.exp(-beta * z) * fprod
             np.add.at(G, (ti, model.n_radial + tterm * na + c), v)
         tri = dict(ta=ta, tb=tb, ti=ti, Da=Da, Db=Db, Djk=Djk, ra=ra, rb=rb, rd=rd,
                    fa=fa, fb=fb, fd=fd, dfa=dfa, dfb=dfb, dfd=dfd, cos=cos, z=z,
@@ -380,11 +388,12 @@ def evaluate(model: SFModel, symbols, positions, cell, pbc, want_forces=True,
         for ch, (beta, gamma, zeta) in enumerate(ang):
             w = dEdG[t["ti"], model.n_radial + t["tterm"] * na + ch]
             base = 1.0 + gamma * c_
-            P = base ** zeta
-            # zeta * gamma * base^(zeta-1); base may be 0 -> use product form
             with np.errstate(divide="ignore", invalid="ignore"):
-                dP = np.where(base != 0.0, zeta * gamma * base ** (zeta - 1.0),
-                              zeta * gamma if zeta == 1.0 else 0.0)
+                P = base ** zeta
+                dP = zeta * gamma * base ** (zeta - 1.0)   # tf.pow's gradient, Inf at base = 0, zeta < 1
+            if model.safe_pow:                              # grad_ops.py:25-26, :46-49
+                P = np.where(np.isinf(P), 0.0, P)
+                dP = np.where(np.isfinite(dP), dP, 0.0)
             e = 2.0 ** (1.0 - zeta) * np.exp(-beta * t["z"])
             fa_, fb_, fd_ = t["fa"], t["fb"], t["fd"]
             dva += w * e * (dP * dca * fa_ - 2.0 * beta * a / ac2 * P * fa_ + P * t["dfa"]) * fb_ * fd_

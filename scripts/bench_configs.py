@@ -51,17 +51,10 @@ def sf_parity(nn, atoms, res):
 
 
 def nimo_frame(seed=611):
-    """7x7x8 conventional Ni4Mo-like cells: fcc sites, 2 of every 10 atoms Mo (3920 atoms)."""
-    a = 3.6
-    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
-    rep = (7, 7, 20)
-    pts = np.array([base + np.array([x, y, z]) * a for x in range(rep[0]) for y in range(rep[1])
-                    for z in range(rep[2])]).reshape(-1, 3)
-    rng = np.random.RandomState(seed)
-    pts = pts + rng.normal(0.0, 0.05, pts.shape)
-    syms = np.array(["Ni"] * len(pts), dtype=object)
-    syms[rng.permutation(len(pts))[: len(pts) // 5]] = "Mo"
-    return Atoms(symbols=list(syms), positions=pts, cell=np.diag([a * r for r in rep]), pbc=True)
+    """BASELINE config 3: the reference's Ni4Mo_mp-11507 conventional cell (I4/m, 8 Ni + 2 Mo),
+    7 x 7 x 8 = 3920 atoms, N(0, 0.05 A) jitter."""
+    from tests.helpers import nimo_supercell
+    return nimo_supercell("Ni4Mo_mp-11507", rep=(7, 7, 8), jitter=0.05, seed=seed)
 
 
 def bench_nn_eam(steps=50):

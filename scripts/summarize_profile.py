@@ -55,6 +55,19 @@ def main(out):
             v = counters[k].get("SQ_INSTS_VALU")
             if v:  # wavefront-level VALU instructions per launch (issue-bound kernels)
                 traffic[k]["valu_wave_insts_per_launch"] = sum(v) / len(v)
+    # stamp: the sources the counters were measured on (bench.py drops them when its own differ)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import subprocess
+    from bench import source_stamp
+    try:
+        commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                text=True).stdout.strip() or None
+    except Exception:
+        commit = None
+    import hashlib
+    traffic["_stamp"] = {"source_sha": source_stamp(), "commit": commit or os.environ.get("TA_COMMIT"),
+                         "bench_sha16": hashlib.sha256(open(os.path.join(root, "bench.py"), "rb").read()).hexdigest()[:16]}
     with open(os.path.join(out, "pmc_traffic.json"), "w") as fp:
         json.dump(traffic, fp, indent=1)
 

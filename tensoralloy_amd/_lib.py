@@ -41,7 +41,8 @@ EXPORTED_SYMBOLS = [
     "ta_compute", "ta_get_results", "ta_eval", "ta_set_stream", "ta_synchronize", "ta_time_compute",
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
-    "ta_energy_gradient", "ta_measure_hbm_copy",
+    "ta_energy_gradient", "ta_measure_hbm_copy", "ta_set_skin", "ta_update_positions", "ta_list_stats",
+    "ta_count_contributing_triples",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -64,6 +65,7 @@ class ModelDesc(C.Structure):
         ("n_grap_params", C.c_int32), ("grap_params", _dp),
         ("n_eam_nets", C.c_int32),
         ("eam_table_n", _ip), ("eam_table_dx", _dp), ("eam_table_coef", _dp),
+        ("safe_pow", C.c_int32),
     ]
 
 
@@ -184,6 +186,10 @@ def load():
     lib.ta_neighbor_list.argtypes = [C.POINTER(Frame), C.c_int32, C.c_double,
                                      C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),
                                      C.POINTER(_ip), C.POINTER(_ip)]
+    lib.ta_count_contributing_triples.argtypes = [H, C.POINTER(C.c_int64)]
+    lib.ta_set_skin.argtypes = [H, C.c_double]
+    lib.ta_update_positions.argtypes = [H, _dp, _dp, _ip]
+    lib.ta_list_stats.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.ta_free.argtypes = [C.c_void_p]
     lib.ta_eam_tabulate.argtypes = [H, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.ta_free.restype = None

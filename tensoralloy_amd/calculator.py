@@ -37,13 +37,18 @@ class TensorAlloyCalculator(BaseCalculator):
     default_parameters = {}
     nolabel = True
 
-    def __init__(self, graph_model_path: str, atoms=None, serial_mode=False, device: int = 0):
+    def __init__(self, graph_model_path: str, atoms=None, serial_mode=False, device: int = 0,
+                 skin: float = 0.5):
         """
         graph_model_path : the exported model to load.
         atoms            : the target `Atoms` object.
         serial_mode      : accepted for compatibility (the reference limits TF
                            to one CPU thread, calculator.py:70-75); ignored.
         device           : HIP device index (new; default 0).
+        skin             : Verlet skin in Angstrom (new; default 0.5). Successive calls for the
+                           same system keep the neighbour list while no atom has moved further
+                           than skin / 2; 0 builds an exact list on every call as the reference
+                           does. Results do not depend on it beyond summation order.
         """
         super().__init__(restart=None, ignore_bad_restart_file=False, label=None, atoms=atoms)
         self._graph_model_path = graph_model_path
@@ -54,9 +59,28 @@ class TensorAlloyCalculator(BaseCalculator):
         self._meta = meta
         self._get_ops()
         self._engine = Engine(nn, device=device)
+        self._skin = float(skin)
+        self._engine.set_skin(self._skin)
+        self._vap_cache = (None, None)
         self.implemented_properties = self._predict_properties
         self._ncalls = 0
         self._prerequisite_properties = []
+
+    @property
+    def skin(self) -> float:
+        return self._skin
+
+    @skin.setter
+    def skin(self, value: float):
+        self._skin = float(value)
+        self._engine.set_skin(self._skin)
+
+    def _vap_for(self, atoms):
+        """`get_vap_transformer(atoms)`, remembered for the system of the previous call."""
+        key = np.asarray(atoms.numbers).tobytes()
+        if self._vap_cache[0] != key:
+            self._vap_cache = (key, self.transformer.get_vap_transformer(atoms))
+        return self._vap_cache[1]
 
     # -- TF-specific members of the reference ------------------------------------
     @property
@@ -154,8 +178,7 @@ class TensorAlloyCalculator(BaseCalculator):
                 self.results.get("forces") is cached[1] and cached[2].shape == gsl.shape:
             return cached[2].copy()
         forces = np.insert(gsl, 0, 0, 0)
-        clf = self.transformer.get_vap_transformer(atoms)
-        return clf.map_forces(forces, reverse=True)
+        return self._vap_for(atoms).map_forces(forces, reverse=True)
 
     def get_stress(self, atoms=None, voigt=True):
         """Stress in eV/Angstrom**3; Voigt order (xx, yy, zz, yz, xz, xy)."""
@@ -267,13 +290,13 @@ class TensorAlloyCalculator(BaseCalculator):
         want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC
         if properties & {"forces", "stress", "virial", "total_pressure"}:
             want |= _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
-        vap = self.transformer.get_vap_transformer(atoms)
+        vap = self._vap_for(atoms)
         second = {}
         if "hessian" in properties:
             second["hessian"] = self._hessian(atoms, vap)
         if "elastic" in properties:
             second["elastic"] = self._elastic(atoms)
-        res = self._engine.evaluate([atoms], want=want, descriptors=debug_mode)[0]
+        res = self._engine.evaluate_md(atoms, want=want, descriptors=debug_mode)
         results = dict(second)
         local_forces = None
         for target in properties:

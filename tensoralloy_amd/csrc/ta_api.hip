@@ -49,6 +49,7 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
                   hipStream_t s);
 void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
                  hipEvent_t *ev /* 2 events or null */);
+void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test */);
 int64_t eam_param_count(const EamModel *);
 void eam_update_weights(EamModel *, const double *flat, int64_t n);
 void eam_energy_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, double *grad,
@@ -174,6 +175,17 @@ struct ta_context {
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
   bool descriptors_valid = false;  // db.G holds the resident batch's descriptors
   DevBuf<double> train_scratch, train_partial, train_grad, train_coeff;
+
+  // MD loop (ta_set_skin / ta_update_positions): the list covers rmax + skin and is kept while no
+  // atom has moved more than skin / 2 from where it was when the list was built
+  double skin = 0.0;
+  double r_list = 0.0;                         // rmax + skin: cutoff of the resident list
+  std::vector<int32_t> keep_species;           // [N]
+  std::vector<int32_t> keep_natoms, keep_pbc;  // [F], [3 F]: what a rebuild needs besides stage_in
+  std::vector<double> ref_pos, ref_cells;      // positions / cells the resident list was built for
+  size_t o_pos = 0, o_cells = 0, o_species = 0;  // byte offsets in the packed input
+  hipEvent_t ev_upload = nullptr;              // last H2D copy out of stage_in
+  int64_t n_list_builds = 0, n_list_reuses = 0;
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
   std::string err;
@@ -325,6 +337,7 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
             cp.ch.beta[ib] = m->beta[b0 + ib];
             cp.ch.hslot[ib] = b0 + ib;
           }
+          cp.ch.safe_pow = m->safe_pow ? 1 : 0;
           for (int ig = 0; ig < cp.ng; ++ig) cp.ch.gamma[ig] = m->gamma[g0 + ig];
           for (int iz = 0; iz < cp.nz; ++iz) {
             const double z = m->zeta[z0 + iz];
@@ -505,7 +518,7 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   h->pair_start.ensure(N + 1);
   h->nl_stats.ensure(8);
   NlWork w = nl_work(h);
-  nl_count((int)N, n_bins, nel, h->rmax, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
+  nl_count((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
            h->pair_start.ptr, s);
   HIP_CHECK(hipGetLastError());
   // counts and per-atom offsets come back through page-locked memory
@@ -535,7 +548,7 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
 void fill_pairs_on_device(ta_context *h) {
   using namespace ta;
   NlWork w = nl_work(h);
-  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->rmax, h->db.pos, h->db.species,
+  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->r_list, h->db.pos, h->db.species,
           h->db.frame_of_atom, h->d_grids, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
           h->pair_rev.ptr, h->stream);
   HIP_CHECK(hipGetLastError());
@@ -732,6 +745,7 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
     HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     for (auto &e : h->ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming));
     if (model->kind == TA_MODEL_SF_MLP) {
       build_sf_model(h, model);
     } else if (model->kind == TA_MODEL_GRAP_MLP) {
@@ -789,188 +803,292 @@ int ta_destroy(ta_handle h) {
   h->nl_recs.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return TA_OK;
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+// the body of ta_set_frames (also the rebuild path of ta_update_positions); throws
+void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta_batch_info *info) {
+  for (int f = 0; f < n_frames; ++f) {
+    const ta_frame &fr = frames[f];
+    if (fr.n_atoms < 0 || (fr.n_atoms > 0 && (!fr.species || !fr.positions)) || !fr.cell || !fr.pbc)
+      throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
+  }
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (h->ev_upload) HIP_CHECK(hipEventSynchronize(h->ev_upload));  // stage_in is about to be rewritten
+  // no batch is resident until this call has succeeded: a failure below (allocation, too many
+  // neighbours, asymmetric list ...) must not leave the previous batch's flags standing over
+  // buffers that were already regrown or repointed
+  h->have_batch = false;
+  h->descriptors_valid = false;
+  h->r_list = h->rmax + h->skin;
+  size_t N = 0;
+  for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
+  if (N >= (1u << 30)) throw std::runtime_error("batch too large for 32-bit atom indices");
+  const size_t F = (size_t)n_frames;
+  const int nel = h->n_elements;
+  // packed input, every section 16-byte aligned
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_pos = 0;
+  const size_t o_cells = align16(o_pos + 3 * N * sizeof(double));
+  const size_t o_grids = align16(o_cells + 9 * F * sizeof(double));
+  const size_t o_species = align16(o_grids + F * sizeof(ta::NlGrid));
+  const size_t o_foa = align16(o_species + N * sizeof(int32_t));
+  const size_t o_astart = align16(o_foa + N * sizeof(int32_t));
+  const size_t o_elem = align16(o_astart + (F + 1) * sizeof(int32_t));
+  const size_t o_blk = align16(o_elem + N * sizeof(int32_t));
+  const size_t total = align16(o_blk + (N + 2) * sizeof(int32_t));
+  h->stage_in.ensure(total);
+  h->inbuf.ensure(total);
+  char *hb = h->stage_in.ptr;
+  double *pos = reinterpret_cast<double *>(hb + o_pos);
+  double *cells = reinterpret_cast<double *>(hb + o_cells);
+  ta::NlGrid *grids = reinterpret_cast<ta::NlGrid *>(hb + o_grids);
+  int32_t *species = reinterpret_cast<int32_t *>(hb + o_species);
+  int32_t *foa = reinterpret_cast<int32_t *>(hb + o_foa);
+  int32_t *astart = reinterpret_cast<int32_t *>(hb + o_astart);
+  int32_t *elem_atoms = reinterpret_cast<int32_t *>(hb + o_elem);
+  size_t a = 0;
+  astart[0] = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const ta_frame &fr = frames[f];
+    const size_t n = (size_t)fr.n_atoms;
+    if (n) {
+      std::memcpy(&pos[3 * a], fr.positions, 3 * n * sizeof(double));
+      std::memcpy(&species[a], fr.species, n * sizeof(int32_t));
+    }
+    std::memcpy(&cells[9 * (size_t)f], fr.cell, 9 * sizeof(double));
+    for (size_t i = a; i < a + n; ++i) {
+      foa[i] = f;
+      if (species[i] < 0 || species[i] >= nel)
+        throw std::runtime_error("frame " + std::to_string(f) + ": species index out of range");
+      if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
+        throw std::runtime_error("frame " + std::to_string(f) + ": non-finite position");
+    }
+    a += n;
+    astart[f + 1] = (int32_t)a;
+  }
+  {  // atoms grouped by element for the batched MLP
+    std::vector<int32_t> count(nel + 1, 0);
+    for (size_t i = 0; i < N; ++i) count[species[i] + 1]++;
+    for (int e = 0; e < nel; ++e) count[e + 1] += count[e];
+    for (int e = 0; e <= nel; ++e) h->db.elem_start[e] = count[e];
+    std::vector<int32_t> fill(count.begin(), count.end() - 1);
+    for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
+  }
+  // Neighbour list: on the device when every frame has >= 3 linked-cell bins along its
+  // periodic axes (ta_nlist.hip), otherwise the host builder (ta_neighbor.cpp).
+  const auto t_nl = std::chrono::steady_clock::now();
+  int n_bins = 0;
+  bool device_nl = N > 0 && !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');
+  for (int f = 0; f < n_frames && device_nl; ++f) {
+    device_nl = ta::nl_make_grid(frames[f], h->r_list, n_bins, grids[f]);
+    if (device_nl) n_bins += ta::nl_bins(grids[f]);
+    if (n_bins > (1 << 24)) device_nl = false;
+  }
+  if (!device_nl) std::memset(static_cast<void *>(grids), 0, F * sizeof(ta::NlGrid));
+  // one upload for everything but blk_center (which needs the pair counts)
+  if (o_blk)
+    HIP_CHECK(hipMemcpyAsync(h->inbuf.ptr, hb, o_blk, hipMemcpyHostToDevice, h->stream));
+  char *db_ = h->inbuf.ptr;
+  h->db.n_frames = n_frames;
+  h->db.pos = reinterpret_cast<double *>(db_ + o_pos);
+  h->db.cells = reinterpret_cast<double *>(db_ + o_cells);
+  h->d_grids = reinterpret_cast<ta::NlGrid *>(db_ + o_grids);
+  h->db.species = reinterpret_cast<int32_t *>(db_ + o_species);
+  h->db.frame_of_atom = reinterpret_cast<int32_t *>(db_ + o_foa);
+  h->db.atom_start = reinterpret_cast<int32_t *>(db_ + o_astart);
+  h->db.elem_atoms = reinterpret_cast<int32_t *>(db_ + o_elem);
+  h->db.blk_center = reinterpret_cast<int32_t *>(db_ + o_blk);
+  if (device_nl) {
+    h->hp.atom_start.assign(astart, astart + F + 1);
+    h->hp.frame_of_atom.assign(foa, foa + N);
+    build_pairs_on_device(h, N, n_bins);
+  } else {
+    h->pairs_on_device = false;
+    ta::build_pairs(n_frames, frames, nel, h->r_list, h->hp);
+  }
+  double nl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nl).count();
+  upload_batch(h);
+  const auto t_fill = std::chrono::steady_clock::now();
+  if (h->pairs_on_device) {
+    fill_pairs_on_device(h);
+    // "reverse pair missing" counter, read after the synchronisation below
+    HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 8 * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, h->stream));
+  }
+  // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
+  // second-generation kernels: 1-3 elements for every channel grid; 4 and 5 elements for
+  // launches of 2 gammas x 2 zetas (the default grid) only
+  bool shapes_ok = h->n_elements <= 3;
+  if (h->n_elements == 4 || h->n_elements == 5) {
+    shapes_ok = !h->chunks_v2.empty();
+    for (const ChunkPlan &cp : h->chunks_v2) shapes_ok = shapes_ok && cp.ng == 2 && cp.nz == 2;
+  }
+  h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && shapes_ok &&
+              h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
+  const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
+  h->db.cap = cap;
+  {
+    int32_t *blk = reinterpret_cast<int32_t *>(hb + o_blk);
+    int nb = 0;
+    if (h->use_v2 && N) {
+      blk[nb++] = 0;
+      int32_t load = 0, ncent = 0;
+      for (size_t i = 0; i < N; ++i) {
+        const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
+        if (load + cnt > cap || ncent >= ta::kMaxCentersPerBlock) {
+          blk[nb++] = (int32_t)i;
+          load = 0;
+          ncent = 0;
+        }
+        load += cnt;
+        ++ncent;
+      }
+      blk[nb++] = (int32_t)N;
+    }
+    h->db.n_blk = nb ? nb - 1 : 0;
+    if (nb)
+      HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
+                               h->stream));
+  }
+  if (h->kind == TA_MODEL_SF_MLP) {
+    if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
+      throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
+    size_t need = ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start);
+    h->mlp_scratch.ensure(need);
+  } else if (h->kind == TA_MODEL_GRAP_MLP) {
+    h->mlp_scratch.ensure(ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start));
+    ta::grap_ensure(h->grap, h->db);
+  } else {
+    ta::eam_ensure(h->eam, h->db);
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next call
+  if (h->pairs_on_device) {
+    nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
+    if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
+      throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
+  }
+  // what ta_update_positions needs: the geometry this list was built for and the frames' shapes
+  h->o_pos = o_pos;
+  h->o_cells = o_cells;
+  h->o_species = o_species;
+  h->ref_pos.assign(pos, pos + 3 * N);
+  h->ref_cells.assign(cells, cells + 9 * F);
+  h->keep_species.assign(species, species + N);
+  h->keep_natoms.resize(F);
+  h->keep_pbc.resize(3 * F);
+  for (size_t f = 0; f < F; ++f) {
+    h->keep_natoms[f] = frames[f].n_atoms;
+    for (int a3 = 0; a3 < 3; ++a3) h->keep_pbc[3 * f + a3] = frames[f].pbc[a3] ? 1 : 0;
+  }
+  if (h->eam) ta::eam_set_list_cutoff(h->eam, h->skin > 0.0 ? h->rmax : 0.0);
+  ++h->n_list_builds;
+  h->have_batch = true;
+  if (info) {
+    info->n_frames = n_frames;
+    info->n_atoms = h->hp.n_atoms;
+    info->n_pairs = h->hp.n_pairs;
+    info->n_triples = h->hp.n_triples;
+    info->nnl_max = h->hp.nnl_max;
+    info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP || h->kind == TA_MODEL_GRAP_MLP) ? h->sf.ndim : 0;
+    info->nl_on_device = h->pairs_on_device ? 1 : 0;
+    info->reserved_ = 0;
+    info->nl_ms = nl_ms;
+    info->set_frames_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+}
+}  // namespace
+
+extern "C" {
+
 int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames, ta_batch_info *info) {
   if (!h) return TA_ERR_INVALID;
   if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(h, TA_ERR_INVALID, "bad frames argument");
-  return guarded(h, [&]() {
-    for (int f = 0; f < n_frames; ++f) {
-      const ta_frame &fr = frames[f];
-      if (fr.n_atoms < 0 || (fr.n_atoms > 0 && (!fr.species || !fr.positions)) || !fr.cell || !fr.pbc)
-        throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
-    }
-    const auto t_begin = std::chrono::steady_clock::now();
-    // no batch is resident until this call has succeeded: a failure below (allocation, too many
-    // neighbours, asymmetric list ...) must not leave the previous batch's flags standing over
-    // buffers that were already regrown or repointed
-    h->have_batch = false;
+  return guarded(h, [&]() { set_frames_impl(h, n_frames, frames, info); });
+}
+
+int ta_set_skin(ta_handle h, double skin) {
+  if (!h) return TA_ERR_INVALID;
+  if (!(skin >= 0.0) || !std::isfinite(skin)) return fail(h, TA_ERR_INVALID, "skin must be a finite length >= 0");
+  if (skin != h->skin) {
+    h->skin = skin;
+    h->have_batch = false;  // the resident list was built for another cutoff
     h->descriptors_valid = false;
-    size_t N = 0;
-    for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
-    if (N >= (1u << 30)) throw std::runtime_error("batch too large for 32-bit atom indices");
-    const size_t F = (size_t)n_frames;
-    const int nel = h->n_elements;
-    // packed input, every section 16-byte aligned
-    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_pos = 0;
-    const size_t o_cells = align16(o_pos + 3 * N * sizeof(double));
-    const size_t o_grids = align16(o_cells + 9 * F * sizeof(double));
-    const size_t o_species = align16(o_grids + F * sizeof(ta::NlGrid));
-    const size_t o_foa = align16(o_species + N * sizeof(int32_t));
-    const size_t o_astart = align16(o_foa + N * sizeof(int32_t));
-    const size_t o_elem = align16(o_astart + (F + 1) * sizeof(int32_t));
-    const size_t o_blk = align16(o_elem + N * sizeof(int32_t));
-    const size_t total = align16(o_blk + (N + 2) * sizeof(int32_t));
-    h->stage_in.ensure(total);
-    h->inbuf.ensure(total);
-    char *hb = h->stage_in.ptr;
-    double *pos = reinterpret_cast<double *>(hb + o_pos);
-    double *cells = reinterpret_cast<double *>(hb + o_cells);
-    ta::NlGrid *grids = reinterpret_cast<ta::NlGrid *>(hb + o_grids);
-    int32_t *species = reinterpret_cast<int32_t *>(hb + o_species);
-    int32_t *foa = reinterpret_cast<int32_t *>(hb + o_foa);
-    int32_t *astart = reinterpret_cast<int32_t *>(hb + o_astart);
-    int32_t *elem_atoms = reinterpret_cast<int32_t *>(hb + o_elem);
-    size_t a = 0;
-    astart[0] = 0;
-    for (int f = 0; f < n_frames; ++f) {
-      const ta_frame &fr = frames[f];
-      const size_t n = (size_t)fr.n_atoms;
-      if (n) {
-        std::memcpy(&pos[3 * a], fr.positions, 3 * n * sizeof(double));
-        std::memcpy(&species[a], fr.species, n * sizeof(int32_t));
-      }
-      std::memcpy(&cells[9 * (size_t)f], fr.cell, 9 * sizeof(double));
-      for (size_t i = a; i < a + n; ++i) {
-        foa[i] = f;
-        if (species[i] < 0 || species[i] >= nel)
-          throw std::runtime_error("frame " + std::to_string(f) + ": species index out of range");
-        if (!std::isfinite(pos[3 * i]) || !std::isfinite(pos[3 * i + 1]) || !std::isfinite(pos[3 * i + 2]))
-          throw std::runtime_error("frame " + std::to_string(f) + ": non-finite position");
-      }
-      a += n;
-      astart[f + 1] = (int32_t)a;
-    }
-    {  // atoms grouped by element for the batched MLP
-      std::vector<int32_t> count(nel + 1, 0);
-      for (size_t i = 0; i < N; ++i) count[species[i] + 1]++;
-      for (int e = 0; e < nel; ++e) count[e + 1] += count[e];
-      for (int e = 0; e <= nel; ++e) h->db.elem_start[e] = count[e];
-      std::vector<int32_t> fill(count.begin(), count.end() - 1);
-      for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
-    }
-    // Neighbour list: on the device when every frame has >= 3 linked-cell bins along its
-    // periodic axes (ta_nlist.hip), otherwise the host builder (ta_neighbor.cpp).
-    const auto t_nl = std::chrono::steady_clock::now();
-    int n_bins = 0;
-    bool device_nl = N > 0 && !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');
-    for (int f = 0; f < n_frames && device_nl; ++f) {
-      device_nl = ta::nl_make_grid(frames[f], h->rmax, n_bins, grids[f]);
-      if (device_nl) n_bins += ta::nl_bins(grids[f]);
-      if (n_bins > (1 << 24)) device_nl = false;
-    }
-    if (!device_nl) std::memset(static_cast<void *>(grids), 0, F * sizeof(ta::NlGrid));
-    // one upload for everything but blk_center (which needs the pair counts)
-    if (o_blk)
-      HIP_CHECK(hipMemcpyAsync(h->inbuf.ptr, hb, o_blk, hipMemcpyHostToDevice, h->stream));
-    char *db_ = h->inbuf.ptr;
-    h->db.n_frames = n_frames;
-    h->db.pos = reinterpret_cast<double *>(db_ + o_pos);
-    h->db.cells = reinterpret_cast<double *>(db_ + o_cells);
-    h->d_grids = reinterpret_cast<ta::NlGrid *>(db_ + o_grids);
-    h->db.species = reinterpret_cast<int32_t *>(db_ + o_species);
-    h->db.frame_of_atom = reinterpret_cast<int32_t *>(db_ + o_foa);
-    h->db.atom_start = reinterpret_cast<int32_t *>(db_ + o_astart);
-    h->db.elem_atoms = reinterpret_cast<int32_t *>(db_ + o_elem);
-    h->db.blk_center = reinterpret_cast<int32_t *>(db_ + o_blk);
-    if (device_nl) {
-      h->hp.atom_start.assign(astart, astart + F + 1);
-      h->hp.frame_of_atom.assign(foa, foa + N);
-      build_pairs_on_device(h, N, n_bins);
-    } else {
-      h->pairs_on_device = false;
-      ta::build_pairs(n_frames, frames, nel, h->rmax, h->hp);
-    }
-    double nl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nl).count();
-    upload_batch(h);
-    const auto t_fill = std::chrono::steady_clock::now();
-    if (h->pairs_on_device) {
-      fill_pairs_on_device(h);
-      // "reverse pair missing" counter, read after the synchronisation below
-      HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 8 * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, h->stream));
-    }
-    // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
-    // second-generation kernels: 1-3 elements for every channel grid; 4 and 5 elements for
-    // launches of 2 gammas x 2 zetas (the default grid) only
-    bool shapes_ok = h->n_elements <= 3;
-    if (h->n_elements == 4 || h->n_elements == 5) {
-      shapes_ok = !h->chunks_v2.empty();
-      for (const ChunkPlan &cp : h->chunks_v2) shapes_ok = shapes_ok && cp.ng == 2 && cp.nz == 2;
-    }
-    h->use_v2 = h->kind == TA_MODEL_SF_MLP && h->sf.angular && shapes_ok &&
-                h->hp.nnl_max <= ta::kCapMax && std::getenv("TA_FORCE_V1") == nullptr;
-    const int cap = std::max(ta::kCapMin, (h->hp.nnl_max + 63) / 64 * 64);
-    h->db.cap = cap;
-    {
-      int32_t *blk = reinterpret_cast<int32_t *>(hb + o_blk);
-      int nb = 0;
-      if (h->use_v2 && N) {
-        blk[nb++] = 0;
-        int32_t load = 0, ncent = 0;
-        for (size_t i = 0; i < N; ++i) {
-          const int32_t cnt = h->hp.pair_start[i + 1] - h->hp.pair_start[i];
-          if (load + cnt > cap || ncent >= ta::kMaxCentersPerBlock) {
-            blk[nb++] = (int32_t)i;
-            load = 0;
-            ncent = 0;
-          }
-          load += cnt;
-          ++ncent;
+  }
+  return TA_OK;
+}
+
+int ta_update_positions(ta_handle h, const double *positions, const double *cells, int32_t *rebuilt) {
+  if (!h || !positions) return fail(h, TA_ERR_INVALID, "null argument");
+  if (h->ref_pos.empty() && h->keep_natoms.empty())
+    return fail(h, TA_ERR_INVALID, "ta_update_positions called before ta_set_frames");
+  return guarded(h, [&]() {
+    const size_t N = h->keep_species.size(), F = h->keep_natoms.size();
+    // The list stays valid while every atom is within skin / 2 of where it was when the list was
+    // built and the cells are the same: two atoms then approach each other by less than skin, so
+    // every pair inside rmax is still in the list (pairs beyond rmax contribute nothing: cutoff
+    // functions, or the explicit test of the EAM / ADP kernels). Checked on the host: the
+    // positions pass through here anyway and no device round trip is needed.
+    bool keep = h->have_batch && h->skin > 0.0;
+    if (keep && cells) keep = std::memcmp(cells, h->ref_cells.data(), 9 * F * sizeof(double)) == 0;
+    if (keep) {
+      const double lim2 = 0.25 * h->skin * h->skin;
+      const double *ref = h->ref_pos.data();
+      double worst = 0.0;
+      for (size_t i = 0; i < N; ++i) {
+        const double dx = positions[3 * i] - ref[3 * i], dy = positions[3 * i + 1] - ref[3 * i + 1],
+                     dz = positions[3 * i + 2] - ref[3 * i + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        worst = d2 > worst ? d2 : worst;  // NaN never wins the comparison; caught below
+        if (!(d2 <= lim2)) {
+          keep = false;
+          break;
         }
-        blk[nb++] = (int32_t)N;
       }
-      h->db.n_blk = nb ? nb - 1 : 0;
-      if (nb)
-        HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
-                                 h->stream));
+      (void)worst;
     }
-    if (h->kind == TA_MODEL_SF_MLP) {
-      if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
-        throw std::domain_error("more than 1150 neighbours per atom exceed the LDS staging buffer");
-      size_t need = ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start);
-      h->mlp_scratch.ensure(need);
-    } else if (h->kind == TA_MODEL_GRAP_MLP) {
-      h->mlp_scratch.ensure(ta::mlp_all_scratch_doubles(h->mlp, h->n_elements, h->db.elem_start));
-      ta::grap_ensure(h->grap, h->db);
-    } else {
-      ta::eam_ensure(h->eam, h->db);
+    if (rebuilt) *rebuilt = keep ? 0 : 1;
+    if (keep) {
+      // same list: only the coordinates travel (one H2D copy out of page-locked memory); the
+      // forward kernels recompute the pair geometry from positions + shifts
+      HIP_CHECK(hipEventSynchronize(h->ev_upload));  // the staging buffer is free again
+      double *stage = reinterpret_cast<double *>(h->stage_in.ptr + h->o_pos);
+      std::memcpy(stage, positions, 3 * N * sizeof(double));
+      if (N)
+        HIP_CHECK(hipMemcpyAsync(h->db.pos, stage, 3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIP_CHECK(hipEventRecord(h->ev_upload, h->stream));
+      h->descriptors_valid = false;
+      ++h->n_list_reuses;
+      return;
     }
-    HIP_CHECK(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next call
-    if (h->pairs_on_device) {
-      nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
-      if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
-        throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
+    std::vector<ta_frame> frames(F);
+    const std::vector<int32_t> species(h->keep_species), pbc(h->keep_pbc), natoms(h->keep_natoms);
+    const std::vector<double> old_cells(h->ref_cells);
+    size_t a = 0;
+    for (size_t f = 0; f < F; ++f) {
+      frames[f].n_atoms = natoms[f];
+      frames[f].species = species.data() + a;
+      frames[f].positions = positions + 3 * a;
+      frames[f].cell = (cells ? cells : old_cells.data()) + 9 * f;
+      frames[f].pbc = pbc.data() + 3 * f;
+      a += (size_t)natoms[f];
     }
-    h->have_batch = true;
-    if (info) {
-      info->n_frames = n_frames;
-      info->n_atoms = h->hp.n_atoms;
-      info->n_pairs = h->hp.n_pairs;
-      info->n_triples = h->hp.n_triples;
-      info->nnl_max = h->hp.nnl_max;
-      info->descriptor_dim = (h->kind == TA_MODEL_SF_MLP || h->kind == TA_MODEL_GRAP_MLP) ? h->sf.ndim : 0;
-      info->nl_on_device = h->pairs_on_device ? 1 : 0;
-      info->reserved_ = 0;
-      info->nl_ms = nl_ms;
-      info->set_frames_ms =
-          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    }
+    set_frames_impl(h, (int32_t)F, frames.data(), nullptr);
   });
+}
+
+int ta_list_stats(ta_handle h, int64_t *n_builds, int64_t *n_reuses) {
+  if (!h) return TA_ERR_INVALID;
+  if (n_builds) *n_builds = h->n_list_builds;
+  if (n_reuses) *n_reuses = h->n_list_reuses;
+  return TA_OK;
 }
 
 int ta_compute(ta_handle h, uint32_t want) {
@@ -1073,6 +1191,53 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const double2 *__restrict
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = src[k];
 }
 }  // namespace
+
+namespace {
+// unordered {j, k} of one centre with r_ij, r_ik and r_jk all below acut: the triples whose G4 term
+// is not identically zero (one wavefront per centre, lane a walks b > a; reads the pair records)
+__global__ __launch_bounds__(256) void count_triples_kernel(ta::DeviceBatch b, double ac2, double eps,
+                                                            unsigned long long *out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= b.n_atoms) return;
+  const int p0 = b.pair_start[i], p1 = b.pair_start[i + 1];
+  unsigned long long n = 0;
+  for (int pa = p0 + lane; pa < p1; pa += 64) {
+    const double2 *ra = ta::pair_geom(b, (size_t)pa);
+    const double ax = ra[0].x, ay = ra[0].y, az = ra[1].x;
+    if (!(ra[1].y < ac2)) continue;
+    for (int pb = pa + 1; pb < p1; ++pb) {
+      const double2 *rb = ta::pair_geom(b, (size_t)pb);
+      const double ex = rb[0].x - ax, ey = rb[0].y - ay, ez = rb[1].x - az;
+      n += (rb[1].y < ac2 && ex * ex + ey * ey + ez * ez + eps < ac2) ? 1ull : 0ull;
+    }
+  }
+  for (int off = 32; off; off >>= 1) n += __shfl_xor(n, off);
+  if (lane == 0 && n) atomicAdd(out, n);
+}
+}  // namespace
+
+int ta_count_contributing_triples(ta_handle h, int64_t *n_contributing) {
+  if (!h || !n_contributing) return fail(h, TA_ERR_INVALID, "null argument");
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (h->kind != TA_MODEL_SF_MLP || !h->sf.angular)
+    return fail(h, TA_ERR_INVALID, "only symmetry-function models with angular terms have triples");
+  return guarded(h, [&]() {
+    compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // fills the pair records
+    h->nl_stats.ensure(8);
+    hipStream_t s = h->stream;
+    HIP_CHECK(hipMemsetAsync(h->nl_stats.ptr, 0, sizeof(unsigned long long), s));
+    const int64_t N = h->db.n_atoms;
+    if (N)
+      hipLaunchKernelGGL(count_triples_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, s, h->db,
+                         h->sf.acut * h->sf.acut, h->sf.eps, h->nl_stats.ptr);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long v = 0;
+    HIP_CHECK(hipMemcpyAsync(&v, h->nl_stats.ptr, sizeof(v), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    *n_contributing = (int64_t)v;
+  });
+}
 
 int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs) {
   if (!h || !gbs || bytes < 16 || reps < 1) return fail(h, TA_ERR_INVALID, "bad argument");

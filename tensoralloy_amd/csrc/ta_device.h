@@ -45,6 +45,7 @@ struct AngChunk {
   double kz[2];      // 2^(1 - zeta)
   int zeta_int[2];   // zeta as integer >= 1, or -1 when not an integer
   int chan[8];       // [(ib*NG + ig)*NZ + iz] -> channel index in [0, n_ang)
+  int safe_pow;      // 1: the masked `safe_pow` of extension/grad_ops.py:16-66 for non-integer zeta
   int n_hd;          // 0 (exact), 12, 16 or 24 coefficients of Hd(u) = exp(-beta u) fc(u)
   double hd[kMaxHd]; // power-series coefficients in u (v2 kernels, beta[0] only)
 };

@@ -81,6 +81,9 @@ struct EamParams {
   uint32_t nn_rho, nn_embed, nn_phi, nn_u, nn_w;
   // bit k set: tabulated function (natural cubic spline of a setfl / adp table)
   uint32_t tab_rho, tab_embed, tab_phi, tab_u, tab_w;
+  // > 0: the resident list is a superset (built with a Verlet skin, ta_set_skin): pairs with
+  // r^2 + eps >= list_rc2 are skipped. 0: the list is exact (strict r < rc), no test.
+  double list_rc2;
 };
 
 // one tabulated function: knots at k dx, (n - 1) cubics {c0, c1, c2, c3} in t = x - x_k
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
           dst[2] = make_double2(rec[4], 0.0);
         }
       }
+      if (P.list_rc2 > 0.0 && !(rec[3] < P.list_rc2)) continue;  // beyond rc: not a neighbour
       const double r = sqrt(rec[3]);
       double f, df;
       // density function of the NEIGHBOUR's element (alloy.py:176)
@@ -739,6 +743,12 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const double2 *rec = pair_geom(b, (size_t)p);
   const double2 v0 = rec[0], v1 = rec[1];
   const double dx = v0.x, dy = v0.y, dz = v1.x;
+  if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) {  // beyond rc: not a neighbour
+    b.g[4 * (size_t)p] = 0.0;
+    b.g[4 * (size_t)p + 1] = 0.0;
+    b.g[4 * (size_t)p + 2] = 0.0;
+    return;
+  }
   const double r = sqrt(v1.y);
   const double inv_r = 1.0 / r;  // the writer's 1 / sqrt(r^2)
   double f, drho, dphi;
@@ -862,7 +872,8 @@ __global__ __launch_bounds__(kBlock) void eam_grad_coeff_kernel(EamParams P, Dev
   const int sA = b.species[i], sb = b.species[b.pair_j[p]];
   const int key = cls == 0 ? sb : pair_type(sA, sb, nel);
   double w = 0.0;
-  if (key == k) {
+  const bool listed = !(P.list_rc2 > 0.0) || pair_geom(b, (size_t)p)[1].y < P.list_rc2;
+  if (key == k && listed) {
     const double c = frame_coeff[b.frame_of_atom[i]];
     if (cls == 0) {
       w = c * dF[i];
@@ -1232,6 +1243,8 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
     }
   }
 }
+
+void eam_set_list_cutoff(EamModel *m, double rc) { m->p.list_rc2 = rc > 0.0 ? rc * rc + m->eps : 0.0; }
 
 // ---- training support: parameter vector = the nn slots in order, per layer W [in][out] then b [out] --
 int64_t eam_param_count(const EamModel *m) {

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_kernel(SFParams sf, AngChun
             if (ch.zeta_int[iz] > 0)
               pw = pow_int_m1(base, ch.zeta_int[iz]) * base;
             else
-              pw = pow(base, ch.zeta[iz]);
+              pw = safe_pow_value(ch.safe_pow, base, ch.zeta[iz]);
             acc[ib][ig][iz] = fma(pw, common, acc[ib][ig][iz]);
           }
         }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(SFParams sf, AngChunk 
             if (ch.zeta_int[iz] > 0)
               pm1 = pow_int_m1(base, ch.zeta_int[iz]);
             else
-              pm1 = pow(base, ch.zeta[iz] - 1.0);
+              pm1 = safe_pow_grad(ch.safe_pow, base, ch.zeta[iz] - 1.0);
             S0 = fma(w[ib][ig][iz], pm1 * base, S0);
             S1 = fma(w[ib][ig][iz] * ch.zeta[iz] * ch.gamma[ig], pm1, S1);
           }

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
               if (ch.zeta_int[iz] > 0)
                 pw = pow_int_m1(basev, ch.zeta_int[iz]) * basev;
               else
-                pw = pow(basev, ch.zeta[iz]);
+                pw = safe_pow_value(ch.safe_pow, basev, ch.zeta[iz]);
             }
             const double v = pw * common;
 #pragma unroll
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kBlock)
               if (ch.zeta_int[iz] > 0)
                 pm1 = pow_int_m1(basev, ch.zeta_int[iz]);
               else
-                pm1 = pow(basev, ch.zeta[iz] - 1.0);
+                pm1 = safe_pow_grad(ch.safe_pow, basev, ch.zeta[iz] - 1.0);
               S0 = fma(ws, pm1 * basev, S0);
               S1 = fma(wds, pm1, S1);
             }

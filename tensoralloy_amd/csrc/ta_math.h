@@ -252,4 +252,18 @@ __device__ __forceinline__ void activation_fn(int act, double x, double &h, doub
   }
 }
 
+// `safe_pow` of reference extension/grad_ops.py:16-74. Without TENSORALLOY_USE_CUSTOM_POW it is plain
+// `tf.pow`, whose gradient y x^(y-1) is Inf at x = 0 for y < 1 (safe = 0: IEEE pow, the same). The
+// custom variant (safe = 1) zeroes an infinite value (:25-26) and an infinite or NaN gradient
+// factor (:46-49); a NaN value (negative base, non-integer exponent) stays NaN in both.
+__device__ __forceinline__ double safe_pow_value(int safe, double x, double y) {
+  const double z = pow(x, y);
+  return (safe && isinf(z)) ? 0.0 : z;
+}
+// x^(y - 1) as it enters d(x^y)/dx = y x^(y-1)
+__device__ __forceinline__ double safe_pow_grad(int safe, double x, double ym1) {
+  const double z = pow(x, ym1);
+  return (safe && !isfinite(z)) ? 0.0 : z;
+}
+
 }  // namespace ta

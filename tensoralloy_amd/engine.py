@@ -34,6 +34,8 @@ class Engine:
         self.info = None
         self._frames = None
         self._volumes = None
+        self._md_sig = None   # (n, numbers, pbc) of the single resident frame of `evaluate_md`
+        self._md_cell = None
 
     # -- lifetime ----------------------------------------------------------------
     def close(self):
@@ -70,9 +72,38 @@ class Engine:
         self._check(self._lib.ta_set_frames(self._handle, len(frames), arr, C.byref(info)))
         self.info = info
         self._frames = frames
+        self._md_sig = None
         self._volumes = np.array([abs(np.linalg.det(f.cell)) for f in frames])
         self._natoms = np.array([len(f.species) for f in frames], dtype=np.int64)
         return info
+
+    def set_skin(self, skin: float):
+        """Verlet skin in Angstrom for the lists built from now on (0 = exact list)."""
+        self._check(self._lib.ta_set_skin(self._handle, float(skin)))
+
+    def update_positions(self, positions, cells=None) -> bool:
+        """New coordinates for the resident frames (all atoms of the batch, in order; `cells`
+        [n_frames, 3, 3] or None = unchanged). Returns True when the neighbour list was rebuilt."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        if len(pos) != int(self.info.n_atoms):
+            raise ValueError("positions for every atom of the resident batch are needed")
+        null = C.POINTER(C.c_double)()
+        cptr = null
+        if cells is not None:
+            cells = np.ascontiguousarray(cells, dtype=np.float64).reshape(-1, 3, 3)
+            if len(cells) != int(self.info.n_frames):
+                raise ValueError("one cell per resident frame")
+            cptr = _lib.as_dp(cells)
+            self._volumes = np.abs(np.linalg.det(cells))
+        rebuilt = C.c_int32(0)
+        self._check(self._lib.ta_update_positions(self._handle, _lib.as_dp(pos), cptr, C.byref(rebuilt)))
+        return bool(rebuilt.value)
+
+    def list_stats(self):
+        """(lists built, lists reused) by this engine."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.ta_list_stats(self._handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def compute(self, want: int):
         self._check(self._lib.ta_compute(self._handle, int(want)))
@@ -121,15 +152,17 @@ class Engine:
                     _lib.TA_WANT_ATOMIC)
         self.set_frames(atoms_list)
         self.compute(want)
-        res = self.fetch(want, descriptors=descriptors)
+        return self._per_frame(self.fetch(want, descriptors=descriptors))
+
+    def _per_frame(self, res: dict) -> List[dict]:
         out, a = [], 0
         for f, n in enumerate(self._natoms):
             d = {"energy": float(res["energy"][f])}
             if "atomic" in res:
-                d["atomic"] = res["atomic"][a:a + n].copy()
+                d["atomic"] = res["atomic"][a:a + n]
             if "forces" in res:
-                d["forces"] = res["forces"][a:a + n].copy()
-                w = res["virial"][f].copy()
+                d["forces"] = res["forces"][a:a + n]
+                w = res["virial"][f]
                 d["virial"] = w
                 # a frame without three lattice vectors has no volume (ASE's `get_volume`, which
                 # feeds the reference's `volume` placeholder at universal.py:865, raises for it):
@@ -139,10 +172,32 @@ class Engine:
                     d["stress"] = np.array([s[0, 0], s[1, 1], s[2, 2], s[1, 2], s[0, 2], s[0, 1]])
                     d["total_pressure"] = float(np.trace(s) / (-3.0 * GPa))  # basic.py:403-405
             if "descriptors" in res:
-                d["descriptors"] = res["descriptors"][a:a + n].copy()
+                d["descriptors"] = res["descriptors"][a:a + n]
             out.append(d)
             a += n
         return out
+
+    def evaluate_md(self, atoms, want: int = None, descriptors=False) -> dict:
+        """One structure, as `evaluate([atoms])[0]`, but when it is the system of the previous call
+        (same atoms, species, periodicity) only its coordinates are sent and the neighbour list is
+        kept as long as the Verlet skin allows (`set_skin`): the MD / relaxation loop of the
+        reference's calculator (calculator.py:335-370) without its per-call feed-dict rebuild."""
+        if want is None:
+            want = (_lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL |
+                    _lib.TA_WANT_ATOMIC)
+        periodic = self._clf.periodic
+        pbc = tuple(bool(x) for x in atoms.pbc) if periodic else (False, False, False)
+        sig = (len(atoms), np.asarray(atoms.numbers).tobytes(), pbc)
+        cell = np.ascontiguousarray(atoms.get_cell(complete=True), dtype=np.float64).reshape(3, 3)
+        if sig == self._md_sig and self.info is not None:
+            same_cell = np.array_equal(cell, self._md_cell)
+            self.update_positions(atoms.positions, None if same_cell else cell[None])
+            self._md_cell = cell
+        else:
+            self.set_frames([atoms])
+            self._md_sig, self._md_cell = sig, cell
+        self.compute(want)
+        return self._per_frame(self.fetch(want, descriptors=descriptors))[0]
 
     # -- measurement -------------------------------------------------------------------
     def time_compute(self, want: int, warmup: int, steps: int, per_kernel=True):
@@ -152,6 +207,12 @@ class Engine:
             self._handle, int(want), int(warmup), int(steps), C.byref(total),
             _lib.as_dp(slots) if per_kernel else C.POINTER(C.c_double)()))
         return total.value, dict(zip(_lib.KERNEL_SLOTS, slots.tolist()))
+
+    def count_contributing_triples(self) -> int:
+        """Triples of the resident batch with all three sides below acut (non-zero G4 terms)."""
+        n = C.c_int64(0)
+        self._check(self._lib.ta_count_contributing_triples(self._handle, C.byref(n)))
+        return int(n.value)
 
     def measure_hbm_copy(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
         """Achievable device-to-device copy rate in GB/s (read + written bytes)."""

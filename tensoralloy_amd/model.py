@@ -461,7 +461,21 @@ class AtomicNN:
             desc.xhi = dptr(np.concatenate([np.ravel(self.minmax[el][1]) * scale for el in self._elements]))
         desc.n_eam_params = 0
         desc.eps = 1e-8 if self.precision == "medium" else 1e-14  # precision.py:113-114
+        desc.safe_pow = int(self.use_custom_pow)
         return desc, keep
+
+    @property
+    def use_custom_pow(self) -> bool:
+        """Which `safe_pow` the model runs with. The reference picks it at import time from the
+        environment variable TENSORALLOY_USE_CUSTOM_POW (extension/grad_ops.py:16); the same variable
+        is read here when the engine is created, and `nn.use_custom_pow = True / False` overrides."""
+        import os
+        override = getattr(self, "_use_custom_pow", None)
+        return bool(os.environ.get("TENSORALLOY_USE_CUSTOM_POW", False)) if override is None else override
+
+    @use_custom_pow.setter
+    def use_custom_pow(self, value):
+        self._use_custom_pow = None if value is None else bool(value)
 
     def descriptor_scale(self):
         """Factors that turn the library's (symmetric) descriptors into this model's."""

@@ -302,5 +302,69 @@ def main():
     print(json.dumps(out, default=str, indent=1))
 
 
+def expand_cif(path):
+    """Cell + all sites of a CIF: the `_symmetry_equiv_pos_as_xyz` operators applied to the listed
+    sites, duplicates removed modulo 1 (SURVEY section 10 recipe; the reference reads these files through
+    ASE / pymatgen, tensoralloy/io/read.py)."""
+    import re
+    from fractions import Fraction
+    with open(path) as fp:
+        lines = [ln.strip() for ln in fp if ln.strip() and not ln.startswith("#")]
+    val = {}
+    for ln in lines:
+        t = ln.split()
+        if t[0].startswith("_cell_") and len(t) == 2:
+            val[t[0]] = float(t[1])
+    ops = [m.group(1) for ln in lines for m in [re.match(r"^\d+\s+'([^']+)'$", ln)] if m]
+    sites = []
+    for ln in lines:
+        t = ln.split()
+        if len(t) == 7 and re.match(r"^[A-Z][a-z]?$", t[0]):
+            sites.append((t[0], [float(t[3]), float(t[4]), float(t[5])]))
+
+    def apply(op, xyz):
+        out = []
+        for expr in op.split(","):
+            expr = expr.strip()
+            v = 0.0
+            for sign, num, den, var in re.findall(r"([+-]?)(?:(\d+)/(\d+)|([xyz]))", expr):
+                term = float(Fraction(int(num), int(den))) if num else xyz["xyz".index(var)]
+                v += -term if sign == "-" else term
+            out.append(v % 1.0)
+        return out
+
+    symbols, frac = [], []
+    for sym, xyz in sites:
+        for op in ops:
+            q = apply(op, xyz)
+            if not any(s == sym and np.all(np.abs(((np.array(q) - f) + 0.5) % 1.0 - 0.5) < 1e-4)
+                       for s, f in zip(symbols, frac)):
+                symbols.append(sym)
+                frac.append(np.array(q))
+    a, b, c = val["_cell_length_a"], val["_cell_length_b"], val["_cell_length_c"]
+    al, be, ga = (np.radians(val[k]) for k in ("_cell_angle_alpha", "_cell_angle_beta", "_cell_angle_gamma"))
+    cx = c * np.cos(be)
+    cy = c * (np.cos(al) - np.cos(be) * np.cos(ga)) / np.sin(ga)
+    cell = np.array([[a, 0, 0], [b * np.cos(ga), b * np.sin(ga), 0], [cx, cy, np.sqrt(c * c - cx * cx - cy * cy)]])
+    cell[np.abs(cell) < 1e-12] = 0.0
+    return symbols, np.array(frac), cell
+
+
+def make_nimo_cells():
+    """BASELINE config 3 structures: the Ni-Mo conventional cells the reference ships
+    (tensoralloy/data/crystals), expanded to explicit sites. Data only."""
+    out = {}
+    for name in ("Ni4Mo_mp-11507", "Ni3Mo_mp-11506"):
+        sym, frac, cell = expand_cif(f"{REF}/tensoralloy/data/crystals/{name}_conventional_standard.cif")
+        out[name] = dict(symbols=sym, scaled_positions=frac.round(12).tolist(), cell=cell.round(12).tolist())
+        print(name, len(sym), {s: sym.count(s) for s in set(sym)})
+    with open(os.path.join(HERE, "NiMo_cells.json"), "w") as fp:
+        json.dump(out, fp, indent=0)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nimo":
+        make_nimo_cells()
+    else:
+        main()
+        make_nimo_cells()

@@ -60,7 +60,8 @@ def oracle_model(nn):
                 omega=d["omega"], beta=d["beta"], gamma=d["gamma"], zeta=d["zeta"],
                 cutoff_function=d["cutoff_function"], hidden_sizes=nn.hidden_sizes,
                 activation=nn._activation, weights=nn.weights, use_resnet_dt=nn._use_resnet_dt,
-                minmax=nn.minmax if nn._minmax_scale else None, symmetric=clf.symmetric)
+                minmax=nn.minmax if nn._minmax_scale else None, symmetric=clf.symmetric,
+                safe_pow=nn.use_custom_pow)
     return m
 
 
@@ -210,3 +211,21 @@ def golden_setfl(name, tmp_path):
     with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
         fo.write(fi.read())
     return dst
+
+
+def nimo_supercell(name="Ni4Mo_mp-11507", rep=(7, 7, 8), jitter=0.05, seed=611):
+    """Supercell of one of the Ni-Mo conventional cells the reference ships
+    (tensoralloy/data/crystals/*.cif, expanded by tests/golden/make_golden.py into
+    tests/golden/NiMo_cells.json): BASELINE config 3 is Ni4Mo 7x7x8 = 3920 atoms."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "NiMo_cells.json")) as fp:
+        c = json.load(fp)[name]
+    cell = np.array(c["cell"])
+    frac = np.array(c["scaled_positions"])
+    shifts = np.array([[x, y, z] for x in range(rep[0]) for y in range(rep[1]) for z in range(rep[2])])
+    pts = ((frac[None, :, :] + shifts[:, None, :]).reshape(-1, 3)) @ cell
+    if jitter:
+        pts = pts + np.random.RandomState(seed).normal(0.0, jitter, pts.shape)
+    return Atoms(symbols=list(c["symbols"]) * len(shifts), positions=pts,
+                 cell=cell * np.array(rep)[:, None], pbc=True)

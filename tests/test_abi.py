@@ -29,11 +29,12 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.Frame) == 40
     assert C.sizeof(_lib.BatchInfo) == 64 and _lib.BatchInfo.nl_ms.offset == 48
     assert _lib.ModelDesc.rcut.offset == 8 and _lib.ModelDesc.eta.offset == 56
-    assert _lib.ModelDesc.eam_params.offset == C.sizeof(_lib.ModelDesc) - 64
-    assert _lib.ModelDesc.eps.offset == C.sizeof(_lib.ModelDesc) - 56
-    assert _lib.ModelDesc.grap_params.offset == C.sizeof(_lib.ModelDesc) - 40
-    assert _lib.ModelDesc.n_eam_nets.offset == C.sizeof(_lib.ModelDesc) - 32
-    assert _lib.ModelDesc.eam_table_coef.offset == C.sizeof(_lib.ModelDesc) - 8
+    assert _lib.ModelDesc.eam_params.offset == C.sizeof(_lib.ModelDesc) - 72
+    assert _lib.ModelDesc.eps.offset == C.sizeof(_lib.ModelDesc) - 64
+    assert _lib.ModelDesc.grap_params.offset == C.sizeof(_lib.ModelDesc) - 48
+    assert _lib.ModelDesc.n_eam_nets.offset == C.sizeof(_lib.ModelDesc) - 40
+    assert _lib.ModelDesc.eam_table_coef.offset == C.sizeof(_lib.ModelDesc) - 16
+    assert _lib.ModelDesc.safe_pow.offset == C.sizeof(_lib.ModelDesc) - 8
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -1,0 +1,145 @@
+"""GPU: the multi-rank path with real engines. Two ranks share the one GPU of the test box (gloo
+carries the 8-byte all-reduce; on a multi-GPU node the same code runs one rank per GPU over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+import numpy as np
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from tensoralloy_amd import Engine, _lib
+from tensoralloy_amd.parallel import shard_range, allreduce_sum_
+from tests.helpers import fcc, make_nn
+nn = make_nn(["Ni"], 6.5, True, [16, 16])
+n_frames = 5
+lo, hi = shard_range(n_frames, rank, world)
+frames = [fcc(rep=(2, 2, 2), seed=100 + f) for f in range(lo, hi)]
+with Engine(nn, device=0) as eng:
+    res = eng.evaluate(frames)
+    local = sum(r["energy"] for r in res)
+    # the device-resident batch energy (what bench.py hands to the collective) agrees with it
+    t = torch.tensor([local], dtype=torch.float64)
+    allreduce_sum_(t)
+    fsum = np.sum([np.abs(r["forces"]).sum() for r in res])
+print(json.dumps({{"rank": rank, "lo": lo, "hi": hi, "local": local, "total": float(t.item()),
+                  "fsum": float(fsum)}}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_engine_ranks_share_the_batch(lib, tmp_path):
+    """2 ranks x Engine on the one GPU: frames shard without overlap, the all-reduced energy equals
+    the single-process sum over all frames."""
+    from tensoralloy_amd import Engine
+    from tests.helpers import fcc, make_nn
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    nn = make_nn(["Ni"], 6.5, True, [16, 16])
+    with Engine(nn) as eng:
+        ref = eng.evaluate([fcc(rep=(2, 2, 2), seed=100 + f) for f in range(5)])
+    total = sum(r["energy"] for r in ref)
+    assert sorted((o["lo"], o["hi"]) for o in outs) == [(0, 3), (3, 5)]
+    for o in outs:
+        assert abs(o["total"] - total) < 1e-9
+        assert abs(o["local"] - sum(r["energy"] for r in ref[o["lo"]:o["hi"]])) < 1e-9
+
+
+def test_bench_spawns_its_own_ranks(lib):
+    """`python bench.py --gpus 2` without a launcher starts two ranks and reports n_gpus = 2."""
+    env = dict(os.environ, TA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--rep", "4", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["atoms_per_gpu"] == 256
+    c5 = out["config5"]
+    assert c5["frames_per_gpu"] == 64 and c5["frames_total"] == 128
+    assert c5["batch_energy_check"] < 1e-6 * abs(c5["batch_energy_sum_eV"])
+    assert out["value"] > 0 and c5["value"] > 0
+
+
+def test_update_positions_reuses_and_rebuilds_the_list(lib):
+    """ta_update_positions: small moves keep the skin-padded list, results equal those of an exact
+    list at the new positions; a large move rebuilds; skin = 0 always rebuilds."""
+    from tensoralloy_amd import Engine, _lib
+    from tests.helpers import fcc, make_nn, make_eam
+    want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
+    rng = np.random.RandomState(3)
+    for nn in (make_nn(["Ni"], 6.5, True, [16, 16]), make_eam(["Ni"], 6.0), make_eam(["Ni"], 6.0, adp=True),
+               make_eam(["Ni"], 5.0, potential=None)):
+        atoms = fcc(rep=(4, 4, 4))
+        with Engine(nn) as eng, Engine(nn) as exact:
+            eng.set_skin(0.6)
+            info = eng.set_frames([atoms])
+            exact_info = exact.set_frames([atoms])
+            assert info.n_pairs > exact_info.n_pairs
+            pos = atoms.positions.copy()
+            for step in range(4):
+                pos = pos + rng.normal(0, 0.03, pos.shape)
+                rebuilt = eng.update_positions(pos)
+                eng.compute(want)
+                got = eng.fetch(want)
+                moved = atoms.copy()
+                moved.positions = pos
+                ref = exact.evaluate([moved])[0]
+                assert abs(got["energy"][0] - ref["energy"]) < 1e-9
+                assert np.abs(got["forces"] - ref["forces"]).max() < 1e-10
+                assert np.abs(got["virial"][0] - ref["virial"]).max() < 1e-8
+                assert np.abs(got["atomic"] - ref["atomic"]).max() < 1e-10
+            builds, reuses = eng.list_stats()
+            assert builds >= 1 and reuses >= 1 and builds + reuses == 5
+            # one atom jumps by more than skin / 2: the list must be rebuilt
+            pos[0] += 0.5
+            assert eng.update_positions(pos) is True
+            eng.compute(want)
+            moved = atoms.copy()
+            moved.positions = pos
+            ref = exact.evaluate([moved])[0]
+            assert abs(eng.fetch(want)["energy"][0] - ref["energy"]) < 1e-9
+            # a changed cell rebuilds too
+            cell = np.asarray(atoms.get_cell(complete=True)) * 1.01
+            assert eng.update_positions(pos, cells=cell[None]) is True
+            # skin = 0: exact list, every call rebuilds
+            eng.set_skin(0.0)
+            assert eng.update_positions(pos) is True
+            assert eng.update_positions(pos) is True
+            assert int(eng.info.n_atoms) == len(atoms)

@@ -221,3 +221,54 @@ def test_gpu_descriptors_against_the_reference_fixtures(lib):
     with Engine(nn) as eng:
         G2 = eng.evaluate([b28], descriptors=True)[0]["descriptors"]
     assert np.abs(G2 - z["g2_v2"]).max() < 1e-11
+
+
+def test_safe_pow_edge_non_integer_zeta(lib):
+    """a22, `safe_pow` (extension/grad_ops.py:16-74) at the edge it exists for: a collinear triple,
+    where 1 + gamma cos(theta) -> 0 and, for zeta < 1, the factor zeta base^(zeta-1) of the gradient
+    blows up. The eps under every root (universal.py:470-472) keeps the base a few 1e-14 above 0
+    for real geometries, so both variants (plain pow = the reference's default; the masked one of
+    TENSORALLOY_USE_CUSTOM_POW) stay finite and agree; the huge, ill-conditioned derivative factor
+    (~1e7) is reproduced to the accuracy the 1-ulp differences in cos(theta) allow."""
+    from tensoralloy_amd import Atoms, Engine
+    pos = np.array([[0.0, 0.0, 0.0], [1.3, 0.0, 0.0], [2.9, 0.0, 0.0], [0.4, 1.7, 0.3]])
+    atoms = Atoms(symbols=["Ni"] * 4, positions=pos + 10.0, cell=np.eye(3) * 30.0, pbc=False)
+    got = {}
+    for custom in (False, True):
+        for zeta in ([0.5, 1.5], [1.0, 2.5]):
+            nn = make_nn(["Ni"], 4.0, True, [8], sf_kwargs=dict(eta=[0.5], zeta=zeta, gamma=[1.0, -1.0]))
+            nn.use_custom_pow = custom
+            with Engine(nn) as eng:
+                r = eng.evaluate([atoms])[0]
+            o = oracle_eval(nn, atoms)
+            assert np.isfinite(r["energy"]) and np.all(np.isfinite(r["forces"]))
+            assert np.all(np.isfinite(o["forces"]))
+            assert abs(r["energy"] - o["energy"]) < E_TOL
+            scale = max(1.0, np.abs(o["forces"]).max())
+            tol = 0.05 * scale if min(zeta) < 1.0 else F_TOL
+            assert np.abs(r["forces"] - o["forces"]).max() < tol
+            got[(custom, tuple(zeta))] = r
+    for zeta in ((0.5, 1.5), (1.0, 2.5)):  # nothing is exactly singular: the mask changes nothing
+        a, b = got[(False, zeta)], got[(True, zeta)]
+        assert a["energy"] == b["energy"] and np.array_equal(a["forces"], b["forces"])
+
+
+def test_failed_set_frames_leaves_no_batch_behind(lib):
+    """A ta_set_frames that fails (here: a species index outside the model) must not leave the
+    previous batch's flags standing: the next ta_compute is refused, not run on stale buffers."""
+    from tensoralloy_amd import Engine, _lib as L
+    import ctypes as C
+    nn = make_nn(["Ni"], 6.5, True, [16])
+    atoms = fcc(rep=(2, 2, 2))
+    with Engine(nn) as eng:
+        eng.evaluate([atoms])
+        bad = L.FrameArrays(np.full(len(atoms), 3, dtype=np.int32), atoms.positions,
+                            np.asarray(atoms.get_cell(complete=True)), [True] * 3)
+        arr = (L.Frame * 1)(bad.as_struct())
+        rc = eng._lib.ta_set_frames(eng._handle, 1, arr, None)
+        assert rc == L.TA_ERR_INVALID
+        assert eng._lib.ta_compute(eng._handle, L.TA_WANT_ENERGY) == L.TA_ERR_INVALID
+        null = C.POINTER(C.c_double)()
+        assert eng._lib.ta_get_results(eng._handle, null, null, null, null, null) == L.TA_ERR_INVALID
+        r = eng.evaluate([atoms])[0]  # and the handle is still usable
+        assert abs(r["energy"] - oracle_eval(nn, atoms)["energy"]) < E_TOL
