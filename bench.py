@@ -293,13 +293,14 @@ def main():
         f5 = CONFIG5_FRAMES_PER_GPU
         frames5 = [ni_frame(611 + rank * f5 + k, rep=args.rep) for k in range(f5)]
         info5 = eng.set_frames(frames5)
-        if use_dist:
-            eng.set_stream(torch.cuda.current_stream().cuda_stream)
         k5, w5 = max(5, min(args.steps, 20)), 2
         el5, esum = coll.run(k5, w5, want)
         atoms5 = coll.total(int(info5.n_atoms))
         local_sum = float(eng.fetch(_lib.TA_WANT_ENERGY)["energy"].sum())
         check = coll.total(local_sum)
+        if os.environ.get("TA_BENCH_DEBUG"):
+            sys.stderr.write(f"[rank {rank}] config5 esum={esum} local_sum={local_sum} check={check} "
+                             f"atoms5={atoms5}\n")
         config5 = {"workload": f"{f5} independent {int(info5.n_atoms) // f5}-atom Ni frames per GPU "
                                f"(seeds 611+rank*{f5}+k), {f5 * world} frames in all, one all-reduce "
                                f"of the batch energy per step",

@@ -234,7 +234,8 @@ int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want
 
 /* Enqueue all further work of this handle on `stream` (a hipStream_t of the
  * handle's device owned by the caller, e.g. the stream a RCCL collective is
- * ordered against); NULL restores the handle's own stream. Drains the old
+ * ordered against); NULL restores the handle's own stream (to name the legacy
+ * default stream, whose handle is also 0, pass hipStreamLegacy). Drains the old
  * stream first. */
 int ta_set_stream(ta_handle h, void *stream);
 

@@ -109,8 +109,16 @@ class Engine:
         self._check(self._lib.ta_compute(self._handle, int(want)))
 
     def set_stream(self, stream_ptr):
-        """Run on a caller-owned hipStream_t (int pointer); None = the engine's own."""
-        self._check(self._lib.ta_set_stream(self._handle, C.c_void_p(stream_ptr or 0)))
+        """Run on a caller-owned hipStream_t (int handle); None = the engine's own stream.
+        0 is the handle of the legacy default stream (what `torch.cuda.current_stream().cuda_stream`
+        returns when no other stream was made current): it is passed on as `hipStreamLegacy`,
+        because a NULL argument means "the handle's own stream" to the C ABI."""
+        HIP_STREAM_LEGACY = 1  # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
+        if stream_ptr is None:
+            ptr = 0
+        else:
+            ptr = int(stream_ptr) or HIP_STREAM_LEGACY
+        self._check(self._lib.ta_set_stream(self._handle, C.c_void_p(ptr)))
 
     def synchronize(self):
         self._check(self._lib.ta_synchronize(self._handle))
