@@ -164,7 +164,7 @@ struct ta_context {
   DevBuf<char> inbuf;
   DevBuf<double> results;
   size_t o_blk = 0;  // byte offset of blk_center in the packed input
-  DevBuf<double> rec, part4, G, dEdG, g, wat, benergy, mlp_scratch;
+  DevBuf<double> rec, part4, G, dEdG, g, wat, bpart, benergy, mlp_scratch;
   DevBuf<unsigned long long> masks;
   DevBuf<int32_t> pair_start, seg_start, pair_i, pair_j, pair_shift, pair_rev;
   ta::NlGrid *d_grids = nullptr;  // view into inbuf
@@ -469,6 +469,7 @@ void upload_batch(ta_context *h) {
   h->dEdG.ensure(N * D);
   h->g.ensure(4 * P);
   h->wat.ensure(9 * N);
+  h->bpart.ensure(10 * ((N + 15) / 16) + 10);
   h->results.ensure(10 * F + 4 * N);
   h->benergy.ensure(1);
 
@@ -485,6 +486,7 @@ void upload_batch(ta_context *h) {
   db.dEdG = h->dEdG.ptr;
   db.g = h->g.ptr;
   db.wat = h->wat.ptr;
+  db.bpart = h->bpart.ptr;
   db.energy = h->results.ptr;
   db.virial = h->results.ptr + F;
   db.eatom = h->results.ptr + 10 * F;
@@ -790,7 +792,7 @@ int ta_destroy(ta_handle h) {
   if (h->grap) ta::grap_destroy(h->grap);
   h->stage_in.release(); h->stage_out.release(); h->inbuf.release(); h->results.release();
   h->rec.release(); h->part4.release(); h->G.release();
-  h->dEdG.release(); h->g.release(); h->wat.release();
+  h->dEdG.release(); h->g.release(); h->wat.release(); h->bpart.release();
   h->benergy.release(); h->mlp_scratch.release();
   h->train_scratch.release(); h->train_partial.release(); h->train_grad.release(); h->train_coeff.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();

@@ -80,7 +80,8 @@ struct DeviceBatch {
   double *eatom = nullptr;  // [N]
   double *g = nullptr;      // [P][4]  dE/dD per directed pair (x, y, z, pad)
   double *forces = nullptr; // [N][3]
-  double *wat = nullptr;    // [N][9] per-atom virial
+  double *wat = nullptr;    // [N][9] per-atom virial (only atoms of groups that straddle two frames)
+  double *bpart = nullptr;  // [ceil(N / 16)][10] {E, W[9]} of every group of 16 consecutive atoms
   double *energy = nullptr; // [F]
   double *virial = nullptr; // [F][9]
   double *batch_energy = nullptr;  // [1]

@@ -45,6 +45,7 @@
 #include "ta_device.h"
 #include "ta_math.h"
 #include "ta_mlp_tile.h"
+#include "ta_reduce.h"
 
 namespace ta {
 
@@ -797,6 +798,65 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   b.g[4 * (size_t)p + 2] = gz;
 }
 
+// Plain EAM (no dipole / quadrupole terms, no nn pair functions): forces and per-atom virial in ONE
+// pass per centre instead of eam_pair_kernel + force_gather. With g[p] = dE/dD of the directed pair p,
+//   F_i = sum_{p in N(i)} (g[p] - g[rev p]),   g[p] = (F'(rho_i) rho'_b(r) + phi'_ab(r) / 2) D / r,
+// and the reverse pair has the same r and -D, so g[rev p] = -(F'(rho_j) rho'_a(r) + phi'_ab(r) / 2) D / r:
+// it is recomputed from an 8-byte gather of F'(rho_j) instead of a 32-byte random gather of a stored
+// g[rev p]; neither g nor the reverse-pair index is touched (eam.py:495-570 differentiated;
+// basic.py:277-331). One wavefront per atom, 16 atoms per workgroup (= one record of `bpart`).
+template <bool OTHER>
+__global__ __launch_bounds__(1024) void eam_force_kernel(EamParams P, DeviceBatch b, const double *dF,
+                                                         const TabDev *__restrict__ tabs) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const bool active = i < b.n_atoms;
+  const int nel = P.nel;
+  double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    const int sA = b.species[i];
+    const double dFi = dF[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    for (int sb = 0; sb < nel; ++sb) {
+      const int pt = pair_type(sA, sb, nel);
+      const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+        const double2 *rec = pair_geom(b, (size_t)q);
+        const double2 v0 = rec[0], v1 = rec[1];
+        if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
+        const double dFj = dF[b.pair_j[q]];
+        const double r = sqrt(v1.y);
+        double fn, drhoB, drhoA, dphi;
+        if (rhoB_tab) spline_eval(tabs[slot_rho(sb)], r, fn, drhoB);
+        else el_rho<OTHER>(P, sb, r, fn, drhoB);
+        if (sb == sA) drhoA = drhoB;
+        else if (rhoA_tab) spline_eval(tabs[slot_rho(sA)], r, fn, drhoA);
+        else el_rho<OTHER>(P, sA, r, fn, drhoA);
+        if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
+        else pair_phi<OTHER>(P, sA, sb, r, fn, dphi);
+        const double inv_r = 1.0 / r;
+        const double own = (dFi * drhoB + 0.5 * dphi) * inv_r;   // g[p] = own D
+        const double both = own + (dFj * drhoA + 0.5 * dphi) * inv_r;  // g[p] - g[rev p] = both D
+        const double d[3] = {v0.x, v0.y, v1.x};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          f[c] = fma(both, d[c], f[c]);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) w[3 * c + e] = fma(own * d[c], d[e], w[3 * c + e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = wave_sum(f[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = wave_sum(w[k]);
+  if (lane == 0 && active)
+    for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
+  block_partials(b, blockIdx.x, i, active, lane == 0, w);
+}
+
 // Tables of the analytic functions on caller-supplied abscissae (setfl / ADP export,
 // reference nn/eam/alloy.py:198-381): rows = elements (rho(r), F(rho)) or element pairs a <= b
 // (phi, u, w), evaluated by the same device functions the energy kernels use.
@@ -1411,14 +1471,25 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
                          m->stride);
   }
   if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
-    const dim3 pgrid((unsigned)((b.n_pairs + kBlock - 1) / kBlock));
-    if (other)
-      hipLaunchKernelGGL(eam_pair_kernel<true>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
-                         m->tabs_dev);
-    else
-      hipLaunchKernelGGL(eam_pair_kernel<false>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
-                         m->tabs_dev);
-    launch_force_gather(sf, b, s);
+    // plain EAM with analytic / tabulated pair functions: one pass per centre (eam_force_kernel);
+    // ADP moments or nn pair functions: dE/dD per pair, then the shared force gather
+    static const bool no_fold = getenv("TA_EAM_NO_FOLD") != nullptr;  // A/B switch
+    if (!m->p.adp && !pair_nets && !no_fold) {
+      const dim3 fgrid((unsigned)((b.n_atoms + 15) / 16));
+      if (other)
+        hipLaunchKernelGGL(eam_force_kernel<true>, fgrid, dim3(1024), 0, s, m->p, b, m->dF, m->tabs_dev);
+      else
+        hipLaunchKernelGGL(eam_force_kernel<false>, fgrid, dim3(1024), 0, s, m->p, b, m->dF, m->tabs_dev);
+    } else {
+      const dim3 pgrid((unsigned)((b.n_pairs + kBlock - 1) / kBlock));
+      if (other)
+        hipLaunchKernelGGL(eam_pair_kernel<true>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
+                           m->tabs_dev);
+      else
+        hipLaunchKernelGGL(eam_pair_kernel<false>, pgrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->pf, ps,
+                           m->tabs_dev);
+      launch_force_gather(sf, b, s);
+    }
   } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
     launch_force_gather(sf, b, s);
   }

@@ -396,8 +396,8 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
   for (int k = 0; k < 9; ++k) w[k] = row16_sum(w[k]);
   if (lane == 0 && active) {
     for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
-    for (int k = 0; k < 9; ++k) b.wat[9 * (size_t)i + k] = w[k];
   }
+  block_partials(b, blockIdx.x, i, active, lane == 0, w);
 }
 
 // --------------------------------------------------------------------------
@@ -407,20 +407,38 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
 // --------------------------------------------------------------------------
 constexpr int kRedBlock = 1024;
 
-__global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial) {
+// `use_partials`: force_gather / the EAM force kernel ran and left the 16-atom group records
+__global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial, int use_partials) {
   __shared__ double red[10][kRedBlock / 64];
   const int f = blockIdx.x;
   const int a0 = b.atom_start[f], a1 = b.atom_start[f + 1];
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  for (int a = a0 + threadIdx.x; a < a1; a += kRedBlock) {
-    acc[0] += b.eatom[a];
-    if (want_virial) {
-      const double *w = b.wat + 9 * (size_t)a;
+  if (use_partials) {
+    // whole groups of the frame: [g0, g1); the atoms before 16 g0 and from 16 g1 on sit in groups
+    // shared with a neighbouring frame and come one by one
+    // (the last group of the batch may hold fewer than 16 atoms and still be whole)
+    const int g0 = (a0 + 15) / 16, g1 = max(g0, (a1 == (int)b.n_atoms) ? (a1 + 15) / 16 : a1 / 16);
+    for (int g = g0 + (int)threadIdx.x; g < g1; g += kRedBlock) {
+      const double *p = b.bpart + 10 * (size_t)g;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) acc[1 + k] += w[k];
+      for (int k = 0; k < 10; ++k) acc[k] += p[k];
     }
+    const int e0 = min(a1, 16 * g0), e1 = min(a1, max(e0, 16 * g1));  // edge atoms: [a0, e0) and [e1, a1)
+    const int n_edge = (e0 - a0) + (a1 - e1);
+    if (g1 == g0) {  // no whole group: every atom of the frame is an edge atom
+      for (int a = a0 + (int)threadIdx.x; a < a1; a += kRedBlock) {
+        acc[0] += b.eatom[a];
+        for (int k = 0; k < 9; ++k) acc[1 + k] += b.wat[9 * (size_t)a + k];
+      }
+    } else if ((int)threadIdx.x < n_edge) {
+      const int a = (int)threadIdx.x < e0 - a0 ? a0 + (int)threadIdx.x : e1 + ((int)threadIdx.x - (e0 - a0));
+      acc[0] += b.eatom[a];
+      for (int k = 0; k < 9; ++k) acc[1 + k] += b.wat[9 * (size_t)a + k];
+    }
+  } else {
+    for (int a = a0 + threadIdx.x; a < a1; a += kRedBlock) acc[0] += b.eatom[a];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -531,8 +549,9 @@ void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) 
 
 void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s) {
   if (b.n_frames == 0) return;
+  // `want_virial` = the force path ran: its kernels left the 16-atom group records behind
   hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames), dim3(kRedBlock), 0, s, b,
-                     want_virial ? 1 : 0);
+                     want_virial ? 1 : 0, want_virial ? 1 : 0);
   if (b.n_frames > 1) hipLaunchKernelGGL(batch_energy_kernel, dim3(1), dim3(kBlock), 0, s, b);
 }
 
