@@ -64,15 +64,29 @@ def radial_filter(algorithm, row, r, rc):
     raise ValueError(f"GRAP: algorithm '{algorithm}' is not implemented")
 
 
-def nn_filters(r, net):
+# covalent radii (Cordero et al. 2008 = ase.data.covalent_radii) of the elements the tests use
+COVALENT_RADII = {"H": 0.31, "Be": 0.96, "C": 0.76, "N": 0.71, "O": 0.66, "Al": 1.21, "Fe": 1.32,
+                  "Ni": 1.24, "Cu": 1.32, "Mo": 1.54, "Pd": 1.39, "W": 1.62}
+
+
+def nn_filters(r, net, rcov=None):
     """The `nn` algorithm (grap.py:220-270, :620-643): ONE shared 1x1 CNN `Filters` maps r to all
     K = num_filters filter values, `convolution1x1(r, hidden_sizes, num_out=K, output_bias=False,
     use_resnet_dt=...)` (convolutional.py:257-290). Returns v [P, K] and dv/dr [P, K]
     (forward-mode). `net` = dict(layers=[(W, b), ..., (W_out, None)], activation, use_resnet_dt).
-    Only `h_abck_modifier = 0` (the input is r itself) is restated."""
+    `h_abck_modifier` (grap.py:620-631): 0 the input is r; 1 r / rcov; 2 exp(-r / rcov), `rcov` [P] =
+    covalent radius of the pair's CENTRE element."""
     from .sf import activation
     h = np.asarray(r, dtype=np.float64)[:, None]
     dh = np.ones_like(h)
+    mod = int(net.get("h_abck_modifier", 0) or 0)
+    if mod == 1:
+        h, dh = h / rcov[:, None], dh / rcov[:, None]
+    elif mod == 2:
+        h = np.exp(-h / rcov[:, None])
+        dh = -h / rcov[:, None]
+    elif mod != 0:
+        raise ValueError(f"Unknown H(r) modifier: {mod}")
     layers = net["layers"]
     for l, (W, b) in enumerate(layers):
         W = np.asarray(W, dtype=np.float64)
@@ -216,7 +230,9 @@ def _moments(model, symbols, positions, cell, pbc, eps):
     H = np.zeros((len(r), K))
     dH = np.zeros((len(r), K))
     if model.algorithm == "nn":
-        v, dv = nn_filters(r, model.filter_net)
+        rcov = np.array([COVALENT_RADII[symbols[i]] for i in pi]) \
+            if model.filter_net.get("h_abck_modifier") else None
+        v, dv = nn_filters(r, model.filter_net, rcov)
         H = v * fc[:, None]
         dH = dv * fc[:, None] + v * dfc[:, None]
     for k, row in enumerate(model.grid if model.algorithm != "nn" else []):

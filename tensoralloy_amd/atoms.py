@@ -40,6 +40,17 @@ chemical_symbols = [
     "Os", "Ir", "Pt", "Au", "Hg", "Tl", "Pb", "Bi", "Po", "At", "Rn", "Fr", "Ra", "Ac", "Th",
     "Pa", "U", "Np", "Pu", "Am", "Cm", "Bk", "Cf", "Es", "Fm", "Md", "No", "Lr"]
 atomic_numbers = {s: z for z, s in enumerate(chemical_symbols)}
+# covalent radii in Angstrom (Cordero et al., Dalton Trans. 2008, 2832: the table behind
+# `ase.data.covalent_radii`, which the reference's GRAP `h_abck_modifier` reads, grap.py:623-629);
+# index = atomic number, 0.2 for the dummy element as in ASE, nan beyond Cm
+covalent_radii = [
+    0.2, 0.31, 0.28, 1.28, 0.96, 0.84, 0.76, 0.71, 0.66, 0.57, 0.58, 1.66, 1.41, 1.21, 1.11, 1.07,
+    1.05, 1.02, 1.06, 2.03, 1.76, 1.70, 1.60, 1.53, 1.39, 1.39, 1.32, 1.26, 1.24, 1.32, 1.22,
+    1.22, 1.20, 1.19, 1.20, 1.20, 1.16, 2.20, 1.95, 1.90, 1.75, 1.64, 1.54, 1.47, 1.46, 1.42,
+    1.39, 1.45, 1.44, 1.42, 1.39, 1.39, 1.38, 1.39, 1.40, 2.44, 2.15, 2.07, 2.04, 2.03, 2.01,
+    1.99, 1.98, 1.98, 1.96, 1.94, 1.92, 1.92, 1.89, 1.90, 1.87, 1.87, 1.75, 1.70, 1.62, 1.51,
+    1.44, 1.41, 1.36, 1.36, 1.32, 1.45, 1.46, 1.48, 1.40, 1.50, 1.50, 2.60, 2.21, 2.15, 2.06,
+    2.00, 1.96, 1.90, 1.87, 1.80, 1.69] + [float("nan")] * 7
 # standard atomic weights (IUPAC abridged values; mass number of the longest-lived isotope for the
 # radioactive elements), index = atomic number. Only written into exported model files.
 atomic_masses = [

@@ -9,13 +9,15 @@ caller's atom order exactly as the reference does (calculator.py:217-249).
 
 Differences (documented in INTEGRATION.md):
   * `graph_model_path` names a `<name>.json` + `<name>.npz` pair written by
-    `AtomicNN.export` / `EamAlloyNN.export`; TensorFlow GraphDef `.pb` files
-    cannot be parsed without TensorFlow and raise `ValueError`.
+    `AtomicNN.export` / `EamAlloyNN.export`, the reference's native `.npz`, or a frozen
+    TensorFlow GraphDef `.pb` of the reference itself: its constants are read without
+    TensorFlow (`tensoralloy_amd/graphdef.py`; Zjw04-family EAM graphs and symmetry-function
+    `AtomicNN` graphs; anything else raises `ValueError`).
   * `session`, `graph`, `get_op` are TensorFlow objects in the reference; here
     they raise `AttributeError`.
   * `hessian` and `elastic` are central differences of the analytic forces / virial (the
     reference differentiates its graph twice, basic.py:411-421, constraint/elastic.py:24-92);
-    `eentropy`, `free_energy` are not implemented.
+    `eentropy` and `enthalpy` are not implemented; `free_energy` only where it is the energy op.
 """
 from __future__ import annotations
 
@@ -98,6 +100,15 @@ class TensorAlloyCalculator(BaseCalculator):
     def _get_ops(self):
         ops = {prop: name for prop, name in self._meta["Metadata/ops"].items()
                if name.endswith(":0")}
+        # graphs exported by the reference's older API also list `atomic` (= the per-atom energies,
+        # today's `energy/atom`), `total_stress` (the full 3 x 3 stress), and `free_energy` /
+        # `enthalpy` ops; a zero-temperature model's free energy IS its energy op. What this build
+        # cannot produce (eentropy, enthalpy with a Pulay stress) is not offered.
+        producible = {"energy", "energy/atom", "atomic", "forces", "stress", "virial", "total_stress",
+                      "total_pressure", "hessian", "elastic"}
+        if ops.get("free_energy") and ops.get("free_energy") == ops.get("energy"):
+            producible.add("free_energy")
+        ops = {k: v for k, v in ops.items() if k in producible}
         if not ops:
             raise Exception("Validated Ops cannot be found")  # calculator.py:161
         self._ops = ops
@@ -288,7 +299,7 @@ class TensorAlloyCalculator(BaseCalculator):
             if target not in self._ops:
                 raise KeyError(target)  # self._ops[target], calculator.py:360
         want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_ATOMIC
-        if properties & {"forces", "stress", "virial", "total_pressure"}:
+        if properties & {"forces", "stress", "virial", "total_pressure", "total_stress"}:
             want |= _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
         vap = self._vap_for(atoms)
         second = {}
@@ -302,7 +313,14 @@ class TensorAlloyCalculator(BaseCalculator):
         for target in properties:
             if target == "energy":
                 results[target] = res["energy"]
-            elif target == "energy/atom":
+            elif target == "free_energy":
+                results[target] = res["energy"]
+            elif target == "total_stress":
+                if "stress" not in res:
+                    raise ValueError("'total_stress' needs a cell with three lattice vectors: volume not defined")
+                v = res["stress"]
+                results[target] = np.array([[v[0], v[5], v[4]], [v[5], v[1], v[3]], [v[4], v[3], v[2]]])
+            elif target in ("energy/atom", "atomic"):
                 # GSL order, virtual row stripped (atomic.py:289-299)
                 results[target] = vap.map_array(res["atomic"].reshape(-1, 1))[1:, 0]
             elif target == "forces":

@@ -462,6 +462,10 @@ struct GrapNet {
   const double *w[kNetMaxLayers];  // layer 0: [np0] (K = 1); else [kp = np[l-1]][np[l]] row-major, zero padded
   const double *b[kNetMaxLayers];  // [np[l]], zeros where the layer has no bias
   int xs;                     // row stride of the activation buffers (2 or 18 mod 32: conflict-free A reads)
+  // input of the network (grap.py:620-631): 0: r; 1: r / rcov; 2: exp(-r / rcov), rcov = covalent
+  // radius of the CENTRE's element
+  int modifier;
+  double inv_rcov[kMaxElements];
 };
 
 __host__ __device__ inline int net_wstride(int np) { return (np % 32 == 0) ? np + 16 : np; }
@@ -509,7 +513,18 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
     const int64_t t = base + wave;
     const int64_t p = t * kMlpTileRows + m;
     const bool valid = t < ntiles && p < b.n_pairs;
-    const double x = valid ? sqrt(b.rec[kRecDoubles * (size_t)p + 3]) : 0.0;
+    double x = valid ? sqrt(b.rec[kRecDoubles * (size_t)p + 3]) : 0.0;
+    double dxdr = 1.0;  // d(input) / dr: seeds the forward-mode derivative
+    if (net.modifier && valid) {
+      const double ir = net.inv_rcov[b.species[b.pair_i[p]]];
+      if (net.modifier == 1) {
+        x *= ir;
+        dxdr = ir;
+      } else {
+        x = exp(-x * ir);
+        dxdr = -x * ir;
+      }
+    }
     // np[0] is a multiple of 16: four independent activation chains per trip
     for (int c0 = kq; c0 < net.np[0]; c0 += 16) {
       double h[4], dh[4];
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
         const int c = c0 + 4 * j;
         const double wk = w0[c];
         activation_fn(act, fma(wk, x, b0[c]), h[j], dh[j]);
-        dh[j] *= wk;
+        dh[j] *= wk * dxdr;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -613,7 +628,7 @@ void build_filter_net(GrapModel *g, const double *q, int n, int K, std::string &
   const int L = (int)q[0], act = (int)q[1], resnet = (int)q[2], modifier = (int)q[3];
   if (L < 2 || L > kNetMaxLayers) fail("GRAP/nn: 2..8 dense layers (incl. the output layer)");
   if (act < 0 || act > TA_ACT_ELU) fail("GRAP/nn: unknown activation");
-  if (modifier != 0) fail("GRAP/nn: h_abck_modifier 1 / 2 are not implemented");
+  if (modifier < 0 || modifier > 2) fail("GRAP/nn: unknown H(r) modifier");
   if (n < 4 + L + 1) fail("grap_params: the filter network's layer sizes are missing");
   int sizes[kNetMaxLayers + 1];
   size_t need = 4 + L + 1;
@@ -623,12 +638,22 @@ void build_filter_net(GrapModel *g, const double *q, int n, int K, std::string &
     if (l > 0) need += (size_t)sizes[l - 1] * sizes[l] + sizes[l];
   }
   if (sizes[0] != 1 || sizes[L] != K) fail("GRAP/nn: the network maps 1 input to K filters");
+  const int nel = g->p.nel;
+  if (modifier) need += (size_t)nel;  // covalent radii of the elements close the block
   if ((size_t)n != need) fail("grap_params: wrong length for the filter network");
   GrapNet &net = g->net;
   std::memset(&net, 0, sizeof(net));
   net.L = L;
   net.act = act;
   net.resnet = resnet ? 1 : 0;
+  net.modifier = modifier;
+  for (int e = 0; e < kMaxElements; ++e) net.inv_rcov[e] = 1.0;
+  if (modifier)
+    for (int e = 0; e < nel; ++e) {
+      const double rc = q[n - nel + e];
+      if (!(rc > 0.0)) fail("GRAP/nn: covalent radius missing for an element");
+      net.inv_rcov[e] = 1.0 / rc;
+    }
   const double *src = q + 4 + L + 1;
   int maxw = 16;
   for (int l = 0; l < L; ++l) {

@@ -8,7 +8,7 @@ Radial filters ("algorithms", grap.py:124-219): `sf` (eta, omega), `morse` (D, g
 `density` (A, beta, re), `pexp` (rl, pl), and `nn` (`NNAlgorithm`, grap.py:220-270: one shared
 filter network r -> K filter values, `convolution1x1(r, hidden_sizes, num_out=num_filters,
 output_bias=False, use_resnet_dt=True)`, grap.py:632-643; weights in
-`descriptor.filter_weights = [(W, b), ..., (W_out, None)]`; only `h_abck_modifier = 0`, and only the
+`descriptor.filter_weights = [(W, b), ..., (W_out, None)]`; `h_abck_modifier` 0, 1, 2; only the
 non-legacy formulation, as in the reference). Moment tensors above rank 3 raise `ValueError` (the
 reference switches to full 3^m tensors there, grap.py:531-590).
 """
@@ -91,9 +91,8 @@ class NNAlgorithm:
         self.ckpt = parameters.get("ckpt", None)
         self.trainable = parameters.get("trainable", True)
         self.h_abck_modifier = int(parameters.get("h_abck_modifier", 0) or 0)
-        if self.h_abck_modifier != 0:
-            raise ValueError("GRAP/nn: h_abck_modifier 1 / 2 (covalent-radius scaled inputs, "
-                             "grap.py:623-629) are not implemented by tensoralloy_amd")
+        if self.h_abck_modifier not in (0, 1, 2):
+            raise ValueError(f"Unknown H(r) modifier: {self.h_abck_modifier}")  # grap.py:630-631
         if self.activation.lower() not in _ACT_IDS:
             raise ValueError(f"The activation function '{self.activation}' cannot be recognized!")
         if not self.hidden_sizes:
@@ -261,5 +260,10 @@ class GenericRadialAtomicPotential:
                 raise ValueError("GRAP/nn: the output layer must have num_filters units")
             extra = [len(self.filter_weights), _ACT_IDS[self._algo.activation.lower()],
                      int(self._algo.use_resnet_dt), self._algo.h_abck_modifier] + sizes
+            if self._algo.h_abck_modifier:
+                # the network's input is r / rcov or exp(-r / rcov) with the covalent radius of the
+                # CENTRE's element (grap.py:623-629): one radius per element closes the block
+                from .atoms import atomic_numbers, covalent_radii
+                flat.append(np.array([covalent_radii[atomic_numbers[el]] for el in self._elements]))
             return np.concatenate([np.array(head + extra, dtype=np.float64)] + flat)
         return np.concatenate([np.array(head, dtype=np.float64), self._algo.constants().ravel()])

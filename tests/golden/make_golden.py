@@ -350,6 +350,15 @@ def expand_cif(path):
     return symbols, np.array(frac), cell
 
 
+def make_graphdef_fixtures():
+    """The reference's frozen-graph fixtures (binary model files: data, not source), gzip'ed."""
+    import gzip
+    for name in ("Ni", "Mo"):
+        with open(f"{REF}/test_files/models/{name}.zhou04.pb", "rb") as fi, \
+                gzip.GzipFile(os.path.join(HERE, f"{name}.zhou04.pb.gz"), "wb", compresslevel=9, mtime=0) as fo:
+            fo.write(fi.read())
+
+
 def make_nimo_cells():
     """BASELINE config 3 structures: the Ni-Mo conventional cells the reference ships
     (tensoralloy/data/crystals), expanded to explicit sites. Data only."""
@@ -365,6 +374,9 @@ def make_nimo_cells():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "nimo":
         make_nimo_cells()
+    elif len(sys.argv) > 1 and sys.argv[1] == "graphdef":
+        make_graphdef_fixtures()
     else:
         main()
         make_nimo_cells()
+        make_graphdef_fixtures()

@@ -186,7 +186,7 @@ def oracle_grap_model(nn):
     if d["algorithm"] == "nn":
         a = nn.descriptor.algorithm
         filter_net = dict(layers=nn.descriptor.filter_weights, activation=a.activation,
-                          use_resnet_dt=a.use_resnet_dt)
+                          use_resnet_dt=a.use_resnet_dt, h_abck_modifier=a.h_abck_modifier)
     return GrapModel(nn.elements, nn.transformer.rcut, algorithm=d["algorithm"], parameters=d["parameters"],
                      filter_net=filter_net,
                      param_space_method=d["param_space_method"], moment_tensors=d["moment_tensors"],

@@ -145,3 +145,30 @@ def test_hessian_matches_the_reference_fixture(lib, tmp_path):
     assert np.abs(H4 - fc2).max() < 5e-5            # fp32 noise of the fixture
     assert np.abs(H - H.T).max() < 1e-9
     assert abs(calc.get_potential_energy(atoms) / 32 + 4.44999667) < 1e-6
+
+
+def test_reference_frozen_graph_runs_unchanged(lib):
+    """`TensorAlloyCalculator("Ni.zhou04.pb")`: the reference's own frozen TF graph (test fixture
+    test_files/models/Ni.zhou04.pb, here gzip'ed) is loaded without TensorFlow and evaluated by the
+    HIP kernels. Known answer: E / atom = -4.44999667 eV for bulk('Ni', cubic=True) * [2, 2, 2] at
+    a = 3.52 A (the cell of the reference's Ni_fc2.npy fixture, SURVEY 8(c) pin 7)."""
+    import os
+    from tensoralloy_amd import Atoms, TensorAlloyCalculator
+    from tests.conftest import GOLDEN
+    calc = TensorAlloyCalculator(os.path.join(GOLDEN, "Ni.zhou04.pb.gz"))
+    assert calc.elements == ["Ni"] and calc.transformer.rcut == 6.5
+    assert {"energy", "forces", "stress", "hessian", "atomic", "total_stress"} <= set(calc.predict_properties)
+    a = 3.52
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
+    pts = np.array([base + np.array([x, y, z]) * a for x in range(2) for y in range(2) for z in range(2)]).reshape(-1, 3)
+    atoms = Atoms(symbols=["Ni"] * 32, positions=pts, cell=np.eye(3) * 2 * a, pbc=True)
+    e = calc.get_potential_energy(atoms)
+    assert abs(e / 32 - (-4.44999667)) < 1e-8
+    assert np.abs(calc.get_forces(atoms)).max() < 1e-10          # perfect lattice
+    full = calc.get_property("total_stress", atoms)
+    voigt = calc.get_stress(atoms)
+    assert full.shape == (3, 3) and abs(full[0, 0] - voigt[0]) < 1e-14 and abs(full[1, 2] - voigt[3]) < 1e-14
+    per_atom = calc.get_property("atomic", atoms)
+    assert per_atom.shape == (32,) and abs(per_atom.sum() - e) < 1e-9
+    mo = TensorAlloyCalculator(os.path.join(GOLDEN, "Mo.zhou04.pb.gz"))
+    assert mo.elements == ["Mo"] and "hessian" not in mo.predict_properties

@@ -114,3 +114,23 @@ def test_nn_filter_network(lib, tmp_path):
         assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
     with pytest.raises(ValueError, match="legacy_mode=False"):
         make_grap_nn(["Ni"], 6.0, [16], "nn", legacy_mode=True)
+
+
+@pytest.mark.parametrize("modifier", [1, 2])
+def test_nn_filter_network_input_modifiers(lib, tmp_path, modifier):
+    """`h_abck_modifier` (grap.py:620-631): the filter network sees r / rcov (1) or exp(-r / rcov) (2)
+    with the covalent radius of the CENTRE's element; round trip through the native `.npz`
+    (`fnn::h_abck_modifier`, atomic.py:419)."""
+    from tensoralloy_amd import TensorAlloyCalculator
+    par = {"hidden_sizes": [32, 32], "num_filters": 8, "h_abck_modifier": modifier}
+    nn = make_grap_nn(["Mo", "Ni"], 5.5, [16, 16], "nn", par, moment_tensors=[0, 1, 2, 3])
+    assert nn.descriptor.algorithm.h_abck_modifier == modifier
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    _compare(nn, [atoms, fcc(rep=(2, 2, 2))])
+    plain = make_grap_nn(["Mo", "Ni"], 5.5, [16, 16], "nn", dict(par, h_abck_modifier=0), moment_tensors=[0, 1, 2, 3])
+    assert abs(oracle_grap_eval(nn, atoms)["energy"] - oracle_grap_eval(plain, atoms)["energy"]) > 1e-6
+    o = oracle_grap_eval(nn, atoms)
+    calc = TensorAlloyCalculator(nn.export_to_lammps_native(str(tmp_path / "mod.npz")))
+    assert calc._nn.descriptor.algorithm.h_abck_modifier == modifier
+    assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL

@@ -208,8 +208,11 @@ def test_model_file_roundtrip(tmp_path):
     e2, _, _ = load_model(p)
     assert e2.as_dict() == e.as_dict()
     assert np.array_equal(e2.flat_parameters(), e.flat_parameters()) and len(e.flat_parameters()) == 2 * 22 + 3 * 8 + 3 * 8
-    with pytest.raises(ValueError):
+    with pytest.raises(FileNotFoundError):
         load_model(str(tmp_path / "missing.pb"))
+    (tmp_path / "other.pb").write_bytes(b"\x0a\x05\x0a\x03abc")  # a GraphDef, but not a tensoralloy export
+    with pytest.raises(ValueError, match="Transformer/params"):
+        load_model(str(tmp_path / "other.pb"))
     (tmp_path / "bad.json").write_text(json.dumps({"format": "other"}))
     with pytest.raises(ValueError):
         load_model(str(tmp_path / "bad.json"))
@@ -481,3 +484,31 @@ def test_batch_universal_transformer_records():
         BatchUniversalTransformer(max_occurs, rcut=4.0, nij_max=5).encode(frames[0])
     with pytest.raises(ValueError, match="exceed max_occurs"):
         BatchUniversalTransformer(Counter({"Ni": 1, "Mo": 1}), rcut=4.0).encode(frames[0])
+
+
+def test_graphdef_reader_on_the_reference_fixtures():
+    """The reference's own frozen graphs (test_files/models/{Ni,Mo}.zhou04.pb, gzip'ed copies under
+    tests/golden/) are read without TensorFlow: transformer JSON, metadata, the Zjw04 constants of
+    the frozen shared variables; the loaded model is the `EamAlloyNN(['Ni'], 'zjw04')` the file was
+    exported from (constants = zjw04_defaults, zjw04.py:19-152)."""
+    from tensoralloy_amd.graphdef import read_graph_model, read_node_ops
+    from tensoralloy_amd.model import load_model
+    from tensoralloy_amd.eam import ZJW04_DEFAULTS, ZJW04_KEYS
+    meta, consts = read_graph_model(os.path.join(GOLDEN, "Ni.zhou04.pb.gz"))
+    params = json.loads(meta["Transformer/params"])
+    assert params == {"class": "UniversalTransformer", "elements": ["Ni"], "rcut": 6.5, "acut": None,
+                      "angular": False, "periodic": True, "symmetric": True, "use_computed_dists": True}
+    ops = json.loads(meta["Metadata/ops"])
+    assert ops["forces"] == "Output/Forces/forces:0" and ops["hessian"] == "Output/Hessian/hessian:0"
+    assert meta["Metadata/precision"] == "high" and meta["Metadata/tf_version"] == "1.15.0"
+    assert float(consts["EAM/Shared/Ni/r_eq"]) == 2.488746 and float(consts["EAM/Shared/Ni/Fe"]) == -2.699486
+    assert read_node_ops(os.path.join(GOLDEN, "Mo.zhou04.pb.gz"))["Transformer/params"] == "Const"
+    for el in ("Ni", "Mo"):
+        nn, clf, m = load_model(os.path.join(GOLDEN, f"{el}.zhou04.pb.gz"))
+        assert type(nn).__name__ == "EamAlloyNN" and nn.family == "zjw04" and clf.rcut == 6.5
+        got = nn.element_parameters(el)
+        for key, val in zip(ZJW04_KEYS, ZJW04_DEFAULTS[el]):
+            assert got[key] == pytest.approx(val, rel=1e-12), key
+        assert ("hessian" in m["Metadata/ops"]) == (el == "Ni")
+    with pytest.raises(ValueError):   # not a protobuf at all
+        read_graph_model(os.path.join(GOLDEN, "cutoffs.npz"))
