@@ -50,6 +50,7 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
 void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
                  hipEvent_t *ev /* 2 events or null */);
 void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test */);
+bool eam_is_plain(const EamModel *);
 int64_t eam_param_count(const EamModel *);
 void eam_update_weights(EamModel *, const double *flat, int64_t n);
 void eam_energy_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, double *grad,
@@ -184,6 +185,10 @@ struct ta_context {
   std::vector<int32_t> keep_natoms, keep_pbc;  // [F], [3 F]: what a rebuild needs besides stage_in
   std::vector<double> ref_pos, ref_cells;      // positions / cells the resident list was built for
   size_t o_pos = 0, o_cells = 0, o_species = 0;  // byte offsets in the packed input
+  // exact list of the current step, extracted on the device from the resident skin list (nl_filter)
+  DevBuf<int32_t> ex_pair_i, ex_pair_j, ex_pair_shift, ex_pair_rev, ex_pair_start, ex_seg_start, ex_counts,
+      ex_map, ex_blk;
+  bool filtered = false;                       // db points at the ex_* arrays
   hipEvent_t ev_upload = nullptr;              // last H2D copy out of stage_in
   int64_t n_list_builds = 0, n_list_reuses = 0;
 
@@ -797,6 +802,9 @@ int ta_destroy(ta_handle h) {
   h->train_scratch.release(); h->train_partial.release(); h->train_grad.release(); h->train_coeff.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release();
+  for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start,
+                  &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk})
+    b->release();
   h->masks.release();
   for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
                   &h->nl_bin_atoms, &h->nl_counts})
@@ -814,6 +822,54 @@ int ta_destroy(ta_handle h) {
 }  // extern "C" (reopened below)
 
 namespace {
+// MD loop with a Verlet skin: the evaluation kernels get the EXACT list of the current positions,
+// extracted from the resident skin list on the device (ta_nlist.hip::nl_filter; no host round trip),
+// so they never pay for the skin. Only for models whose kernels are driven by centres (second-
+// generation symmetry-function kernels, plain EAM); the others run on the skin list itself, where
+// pairs beyond the cutoff contribute nothing.
+bool filter_applies(const ta_context *h) {
+  if (!(h->skin > 0.0) || h->hp.n_atoms == 0 || std::getenv("TA_NO_LIST_FILTER")) return false;
+  if (h->kind == TA_MODEL_SF_MLP) return h->use_v2;
+  if (h->kind == TA_MODEL_EAM_ALLOY) return ta::eam_is_plain(h->eam);
+  return false;
+}
+
+void apply_filter(ta_context *h) {
+  using namespace ta;
+  const size_t N = (size_t)h->hp.n_atoms, P = (size_t)h->hp.n_pairs;
+  const int nel = h->n_elements;
+  h->ex_pair_i.ensure(P + 1);
+  h->ex_pair_j.ensure(P + 1);
+  h->ex_pair_shift.ensure(3 * P + 3);
+  h->ex_pair_rev.ensure(P + 1);
+  h->ex_pair_start.ensure(N + 1);
+  h->ex_seg_start.ensure(N * (nel + 1) + 1);
+  h->ex_counts.ensure(N * (nel + 1) + 1);
+  h->ex_map.ensure(P + 1);
+  h->ex_blk.ensure(N + 4);
+  h->nl_stats.ensure(8);
+  const bool blocks = h->kind == TA_MODEL_SF_MLP;
+  int32_t *n_blk_dev = h->ex_blk.ptr + N + 2;
+  nl_filter((int)N, (int64_t)P, nel, h->rmax, h->db.pos, h->db.cells, h->db.frame_of_atom, h->seg_start.ptr,
+            h->pair_j.ptr, h->pair_shift.ptr, h->pair_rev.ptr, h->ex_counts.ptr, h->ex_map.ptr,
+            h->ex_seg_start.ptr, h->ex_pair_start.ptr, h->ex_pair_i.ptr, h->ex_pair_j.ptr,
+            h->ex_pair_shift.ptr, h->ex_pair_rev.ptr, h->nl_stats.ptr, h->db.cap,
+            blocks ? h->ex_blk.ptr : nullptr, n_blk_dev, (int)N, h->stream);
+  HIP_CHECK(hipGetLastError());
+  h->db.pair_start = h->ex_pair_start.ptr;
+  h->db.seg_start = h->ex_seg_start.ptr;
+  h->db.pair_i = h->ex_pair_i.ptr;
+  h->db.pair_j = h->ex_pair_j.ptr;
+  h->db.pair_shift = h->ex_pair_shift.ptr;
+  h->db.pair_rev = h->ex_pair_rev.ptr;
+  if (blocks) {
+    h->db.blk_center = h->ex_blk.ptr;
+    h->db.n_blk = (int)N;  // upper bound of the grid: every run holds at least one centre
+    h->db.n_blk_dev = n_blk_dev;
+  }
+  h->filtered = true;
+}
+
 // the body of ta_set_frames (also the rebuild path of ta_update_positions); throws
 void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta_batch_info *info) {
   for (int f = 0; f < n_frames; ++f) {
@@ -828,6 +884,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   // buffers that were already regrown or repointed
   h->have_batch = false;
   h->descriptors_valid = false;
+  h->filtered = false;
+  h->db.n_blk_dev = nullptr;
   h->r_list = h->rmax + h->skin;
   size_t N = 0;
   for (int f = 0; f < n_frames; ++f) N += (size_t)frames[f].n_atoms;
@@ -989,7 +1047,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
     h->keep_natoms[f] = frames[f].n_atoms;
     for (int a3 = 0; a3 < 3; ++a3) h->keep_pbc[3 * f + a3] = frames[f].pbc[a3] ? 1 : 0;
   }
-  if (h->eam) ta::eam_set_list_cutoff(h->eam, h->skin > 0.0 ? h->rmax : 0.0);
+  if (filter_applies(h)) apply_filter(h);
+  if (h->eam) ta::eam_set_list_cutoff(h->eam, (h->skin > 0.0 && !h->filtered) ? h->rmax : 0.0);
   ++h->n_list_builds;
   h->have_batch = true;
   if (info) {
@@ -1066,6 +1125,7 @@ int ta_update_positions(ta_handle h, const double *positions, const double *cell
       if (N)
         HIP_CHECK(hipMemcpyAsync(h->db.pos, stage, 3 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
       HIP_CHECK(hipEventRecord(h->ev_upload, h->stream));
+      if (h->filtered) apply_filter(h);  // the exact list of the new positions, on the device
       h->descriptors_valid = false;
       ++h->n_list_reuses;
       return;

@@ -64,6 +64,8 @@ struct DeviceBatch {
   int32_t *pair_i = nullptr, *pair_j = nullptr, *pair_shift = nullptr, *pair_rev = nullptr;
   int32_t *blk_center = nullptr; // [n_blk+1] first centre of every v2 workgroup
   int n_blk = 0;
+  const int32_t *n_blk_dev = nullptr;  // MD loop: the packing was made on the device, `n_blk` is only an upper
+                                       // bound of the grid; workgroups beyond *n_blk_dev leave at once
   int cap = kCapMin;             // records per v2 workgroup (multiple of 64)
   int32_t *elem_atoms = nullptr; // atoms grouped by element
   int32_t elem_start[kMaxElements + 1] = {0};
@@ -169,6 +171,12 @@ int nl_bins(const NlGrid &g);
 void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, int32_t *pair_start,
               hipStream_t s);
+void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double *pos, const double *cells,
+               const int32_t *frame_of_atom, const int32_t *seg_super, const int32_t *pj_super,
+               const int32_t *ps_super, const int32_t *rev_super, int32_t *counts, int32_t *map,
+               int32_t *seg_exact, int32_t *pair_start, int32_t *pi_out, int32_t *pj_out, int32_t *ps_out,
+               int32_t *rev_out, unsigned long long *stats, int cap, int32_t *blk_center, int32_t *n_blk_dev,
+               int max_blk, hipStream_t s);
 void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,
              const int32_t *species, const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w,
              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, hipStream_t s);

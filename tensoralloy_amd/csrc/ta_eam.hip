@@ -1304,6 +1304,9 @@ void eam_tabulate(EamModel *m, int n_r, const double *r, int n_rho, const double
   }
 }
 
+// centre-driven kernels only (atom + force kernel): no per-pair launch that walks [0, n_pairs)
+bool eam_is_plain(const EamModel *m) { return !m->p.adp && !m->pair_nets; }
+
 void eam_set_list_cutoff(EamModel *m, double rc) { m->p.list_rc2 = rc > 0.0 ? rc * rc + m->eps : 0.0; }
 
 // ---- training support: parameter vector = the nn slots in order, per layer W [in][out] then b [out] --

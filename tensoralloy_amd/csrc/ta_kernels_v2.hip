@@ -345,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
                                                                DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int geom = flags & 1;
+  if (b.n_blk_dev && (int)blockIdx.x >= *b.n_blk_dev) return;  // grid sized by an upper bound (MD loop)
   stagger(flags);
   extern __shared__ double lds[];
   const Fields f = carve(lds, b.cap);
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(kBlock)
                                                              DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int first = flags & 1;
+  if (b.n_blk_dev && (int)blockIdx.x >= *b.n_blk_dev) return;  // grid sized by an upper bound (MD loop)
   stagger(flags);
   extern __shared__ double lds[];
   const int kCap = b.cap;  // multiple of 64

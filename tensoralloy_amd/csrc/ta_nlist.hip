@@ -58,32 +58,42 @@ __global__ __launch_bounds__(kBlock) void bin_atoms_kernel(int n_atoms, const do
   atomicAdd(&bin_count[id], 1);
 }
 
+// inclusive scan of one int per lane over the 1024 lanes of a workgroup: wavefront scans by
+// cross-lane shuffles, the 16 wavefront totals through LDS (two barriers instead of thirty)
+__device__ __forceinline__ int block_scan_1024(int v, int *wtot /* [16], shared */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(v, off);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wtot[wave] = v;
+  __syncthreads();
+  int add = 0;
+  for (int w = 0; w < wave; ++w) add += wtot[w];
+  __syncthreads();
+  return v + add;
+}
+
 // exclusive scan of `n` ints by one workgroup (n is small: bins, or atoms x species)
 __global__ __launch_bounds__(1024) void scan_kernel(int n, const int32_t *in, int32_t *out,
                                                     int32_t *total) {
-  __shared__ int part[1024];
+  __shared__ int wtot[16];
   const int t = threadIdx.x;
   const int chunk = (n + 1023) / 1024;
-  const int lo = t * chunk, hi = min(n, lo + chunk);
+  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
   int s = 0;
   for (int k = lo; k < hi; ++k) s += in[k];
-  part[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;
+  const int incl = block_scan_1024(s, wtot);
+  int run = incl - s;
   for (int k = lo; k < hi; ++k) {
     const int v = in[k];
     out[k] = run;
     run += v;
   }
   if (t == 1023) {
-    out[n] = part[1023];
-    if (total) *total = part[1023];
+    out[n] = incl;
+    if (total) *total = incl;
   }
 }
 
@@ -233,21 +243,29 @@ __global__ __launch_bounds__(kBlock) void finish_starts_kernel(int n_atoms, int 
                                                                int32_t *nnl_max,
                                                                unsigned long long *n_pairs64) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i > n_atoms) return;
-  if (i == n_atoms) {
-    pair_start[i] = seg_start[(size_t)n_atoms * (nel + 1)];
-    return;
+  unsigned long long tri = 0, cnt = 0;
+  if (i == n_atoms) pair_start[i] = seg_start[(size_t)n_atoms * (nel + 1)];
+  if (i < n_atoms) {
+    const int a = seg_start[(size_t)i * (nel + 1)], b = seg_start[(size_t)(i + 1) * (nel + 1)];
+    pair_start[i] = a;
+    const int n = b - a;
+    tri = (unsigned long long)n * (unsigned long long)(n - 1) / 2ull;
+    // 64-bit total of the per-atom counts (from the int32 counts array, not from the scan): a batch
+    // whose 32-bit running sum wraps is detected by the host even when the wrapped value is positive
+    for (int sp = 0; sp < nel; ++sp) cnt += (unsigned long long)(unsigned)counts[(size_t)i * (nel + 1) + sp];
   }
-  const int a = seg_start[(size_t)i * (nel + 1)], b = seg_start[(size_t)(i + 1) * (nel + 1)];
-  pair_start[i] = a;
-  const int n = b - a;
-  atomicAdd(n_triples, (unsigned long long)n * (unsigned long long)(n - 1) / 2ull);
-  // 64-bit total of the per-atom counts (from the int32 counts array, not from the scan): a batch
-  // whose 32-bit running sum wraps is detected by the host even when the wrapped value is positive
-  unsigned long long cnt = 0;
-  for (int sp = 0; sp < nel; ++sp) cnt += (unsigned long long)(unsigned)counts[(size_t)i * (nel + 1) + sp];
-  atomicAdd(n_pairs64, cnt);
-  atomicMax(nnl_max, (int)cnt);
+  // one atomic per wavefront and statistic, not one per atom (they all hit the same three words)
+  int mx = (int)cnt;
+  for (int off = 32; off; off >>= 1) {
+    tri += __shfl_xor(tri, off);
+    cnt += __shfl_xor(cnt, off);
+    mx = max(mx, __shfl_xor(mx, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (tri) atomicAdd(n_triples, tri);
+    if (cnt) atomicAdd(n_pairs64, cnt);
+    if (mx) atomicMax(nnl_max, mx);
+  }
 }
 
 // (i -> j, S) <-> (j -> i, -S): eight lanes search j's segment of species(i)
@@ -290,6 +308,128 @@ __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, 
   if (p < n_pairs && sub == 0) {
     pair_rev[p] = found;
     if (found < 0) atomicAdd(n_missing, 1);
+  }
+}
+
+// ---- MD loop: the exact list of a step from the resident skin list ------------------------------
+// The resident list covers rmax + skin (ta_set_skin); while it is valid, the pairs inside rmax at the
+// CURRENT positions are a subset of it. These kernels extract that subset, in the same order and
+// with the same layout as the builder's output (sorted by centre and neighbour species, reverse
+// index, workgroup packing), so that the evaluation kernels run on an exact list and never see the
+// skin: same traversal twice (count, fill) with ballots, as pairs_kernel.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void filter_kernel(int n_atoms, int nel, double rmax, const double *pos,
+                                                        const double *cells, const int32_t *frame_of_atom,
+                                                        const int32_t *seg_super, const int32_t *pj_super,
+                                                        const int32_t *ps_super, int32_t *counts,
+                                                        const int32_t *seg_exact, int32_t *pi_out,
+                                                        int32_t *pj_out, int32_t *ps_out, int32_t *map) {
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n_atoms) return;
+  const double *h = cells + 9 * (size_t)frame_of_atom[i];
+  const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
+  const int32_t *seg = seg_super + (size_t)i * (nel + 1);
+  for (int s = 0; s < nel; ++s) {
+    int running = 0;
+    for (int q0 = seg[s]; q0 < seg[s + 1]; q0 += 64) {
+      const int q = q0 + lane;
+      bool valid = false;
+      int j = 0, Sx = 0, Sy = 0, Sz = 0;
+      if (q < seg[s + 1]) {
+        j = pj_super[q];
+        Sx = ps_super[3 * (size_t)q];
+        Sy = ps_super[3 * (size_t)q + 1];
+        Sz = ps_super[3 * (size_t)q + 2];
+        const double Dx = pos[3 * (size_t)j] - rix + (Sx * h[0] + Sy * h[3] + Sz * h[6]);
+        const double Dy = pos[3 * (size_t)j + 1] - riy + (Sx * h[1] + Sy * h[4] + Sz * h[7]);
+        const double Dz = pos[3 * (size_t)j + 2] - riz + (Sx * h[2] + Sy * h[5] + Sz * h[8]);
+        valid = sqrt(Dx * Dx + Dy * Dy + Dz * Dz) < rmax;  // the builder's test (pairs_kernel)
+      }
+      const unsigned long long m = __ballot(valid);
+      if (MODE == 1 && q < seg[s + 1]) {
+        int slot = -1;
+        if (valid) {
+          slot = seg_exact[(size_t)i * (nel + 1) + s] + running + __popcll(m & ((1ull << lane) - 1ull));
+          pi_out[slot] = i;
+          pj_out[slot] = j;
+          ps_out[3 * (size_t)slot] = Sx;
+          ps_out[3 * (size_t)slot + 1] = Sy;
+          ps_out[3 * (size_t)slot + 2] = Sz;
+        }
+        map[q] = slot;
+      }
+      running += __popcll(m);
+    }
+    if (MODE == 0 && lane == 0) counts[(size_t)i * (nel + 1) + s] = running;
+  }
+  if (MODE == 0 && lane == 0) counts[(size_t)i * (nel + 1) + nel] = 0;
+}
+
+// reverse index of the exact list through the map (a pair and its reverse have the same length, so
+// both are inside rmax or neither is)
+__global__ __launch_bounds__(kBlock) void filter_rev_kernel(int64_t n_super, const int32_t *rev_super,
+                                                            const int32_t *map, int32_t *rev_out) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n_super) return;
+  const int slot = map[q];
+  if (slot >= 0) rev_out[slot] = map[rev_super[q]];
+}
+
+// Workgroup packing of the angular kernels on the device: runs of whole centres with <= cap pairs and
+// <= kMaxCentersPerBlock centres, greedy inside chunks of 32 consecutive centres (a chunk end closes
+// a run), one lane per chunk walking the chunk's offsets in LDS; the runs of all chunks are laid
+// out by a prefix sum. One workgroup, rounds of 8192 centres.
+constexpr int kPackChunk = 32, kPackRound = 8192;
+
+__global__ __launch_bounds__(1024) void pack_blocks_kernel(int n_atoms, int cap, const int32_t *pair_start,
+                                                           int32_t *blk_center, int32_t *n_blk_out,
+                                                           int max_blk) {
+  __shared__ int ps[kPackRound + 1];
+  __shared__ int cnt[16];
+  __shared__ int total;
+  const int t = threadIdx.x;
+  int base = 0;
+  for (int r0 = 0; r0 < n_atoms; r0 += kPackRound) {
+    const int nr = min(kPackRound, n_atoms - r0);
+    for (int idx = t; idx <= nr; idx += 1024) ps[idx] = pair_start[r0 + idx];
+    __syncthreads();
+    const int lo = min(nr, t * kPackChunk), hi = min(nr, lo + kPackChunk);
+    int nb = 0, load = 0, nc = 0;
+    for (int i = lo; i < hi; ++i) {
+      const int k = ps[i + 1] - ps[i];
+      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
+        ++nb;
+        load = 0;
+        nc = 0;
+      }
+      load += k;
+      ++nc;
+    }
+    const int incl = block_scan_1024(nb, cnt);
+    int slot = base + incl - nb;
+    load = 0;
+    nc = 0;
+    for (int i = lo; i < hi; ++i) {
+      const int k = ps[i + 1] - ps[i];
+      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
+        if (slot < max_blk) blk_center[slot] = r0 + i;
+        ++slot;
+        load = 0;
+        nc = 0;
+      }
+      load += k;
+      ++nc;
+    }
+    if (t == 1023) total = base + incl;
+    __syncthreads();
+    base = total;
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int nb = min(base, max_blk);
+    blk_center[nb] = n_atoms;
+    *n_blk_out = nb;
   }
 }
 
@@ -397,6 +537,35 @@ void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *p
     hipLaunchKernelGGL(reverse_pairs_kernel, dim3(nblk(n_pairs * 8, kBlock)), dim3(kBlock), 0, s, n_pairs,
                        nel, species, w.seg_start, pair_i, pair_j, pair_shift, pair_rev,
                        reinterpret_cast<int32_t *>(w.stats) + 6);
+}
+
+// Exact list of the current positions out of the resident skin list (all device, no host round trip):
+// exact (i, j, S, rev), pair_start, seg_start; workgroup packing for the angular kernels when
+// `blk_center` is given. `seg_exact` doubles as the scan's output; `counts`, `map` are work buffers.
+void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double *pos, const double *cells,
+               const int32_t *frame_of_atom, const int32_t *seg_super, const int32_t *pj_super,
+               const int32_t *ps_super, const int32_t *rev_super, int32_t *counts, int32_t *map,
+               int32_t *seg_exact, int32_t *pair_start, int32_t *pi_out, int32_t *pj_out, int32_t *ps_out,
+               int32_t *rev_out, unsigned long long *stats, int cap, int32_t *blk_center, int32_t *n_blk_dev,
+               int max_blk, hipStream_t s) {
+  if (n_atoms == 0) return;
+  (void)hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), s);
+  const dim3 agrid(nblk((int64_t)n_atoms * 64, kBlock));
+  hipLaunchKernelGGL(filter_kernel<0>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
+                     seg_super, pj_super, ps_super, counts, (const int32_t *)nullptr, (int32_t *)nullptr,
+                     (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), counts, seg_exact,
+                     reinterpret_cast<int32_t *>(stats) + 4);
+  hipLaunchKernelGGL(finish_starts_kernel, dim3(nblk(n_atoms + 1, kBlock)), dim3(kBlock), 0, s, n_atoms, nel,
+                     seg_exact, counts, pair_start, stats, reinterpret_cast<int32_t *>(stats) + 2, stats + 4);
+  hipLaunchKernelGGL(filter_kernel<1>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
+                     seg_super, pj_super, ps_super, (int32_t *)nullptr, seg_exact, pi_out, pj_out, ps_out, map);
+  if (n_super > 0)
+    hipLaunchKernelGGL(filter_rev_kernel, dim3(nblk(n_super, kBlock)), dim3(kBlock), 0, s, n_super, rev_super,
+                       map, rev_out);
+  if (blk_center)
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3(1), dim3(1024), 0, s, n_atoms, cap, pair_start, blk_center,
+                       n_blk_dev, max_blk);
 }
 
 }  // namespace ta
