@@ -102,31 +102,46 @@ def nn_filters(r, net, rcov=None):
 
 
 # packed moment components: exponents (nx, ny, nz) of the unit vector, in the reference's order
-# (grap.py:501-511): 1 | x y z | xx xy xz yy yz zz | xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
-COMPONENTS = [(0, 0, 0),
-              (1, 0, 0), (0, 1, 0), (0, 0, 1),
-              (2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2),
-              (3, 0, 0), (2, 1, 0), (2, 0, 1), (1, 2, 0), (1, 1, 1), (1, 0, 2),
-              (0, 3, 0), (0, 2, 1), (0, 1, 2), (0, 0, 3)]
-N_COMPONENTS = {0: 1, 1: 4, 2: 10, 3: 20}
+# (grap.py:501-511): 1 | x y z | xx xy xz yy yz zz | xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz, and
+# continued the same way (nx descending, then ny) for the ranks 4 and 5
+COMPONENTS = [(nx, ny, deg - nx - ny) for deg in range(6) for nx in range(deg, -1, -1)
+              for ny in range(deg - nx, -1, -1)]
+N_COMPONENTS = {0: 1, 1: 4, 2: 10, 3: 20, 4: 35, 5: 56}
 
 
 def multiplicity_tensor(max_moment, symmetric=False):
-    """T[d, m] (grap.py:470-492)."""
+    """T[d, m]. Moments up to 3: grap.py:470-492 (with the traceless corrections when `symmetric`).
+    max_moment > 3: the reference sums the FULL 3^m tensors with unit weights (get_moment_tensor /
+    get_T_dm, grap.py:538-600), which on packed components is the multinomial coefficient of every
+    component at every rank; `symmetric` plays no role there."""
+    from math import factorial
     nd = N_COMPONENTS[max_moment]
     T = np.zeros((nd, max_moment + 1))
-    T[0, 0] = 1.0
-    if max_moment >= 1:
-        T[1:4, 1] = 1.0
-    if max_moment >= 2:
-        T[4:10, 2] = [1, 2, 2, 1, 2, 1]
-        if symmetric:
+    for d, (nx, ny, nz) in enumerate(COMPONENTS[:nd]):
+        m = nx + ny + nz
+        T[d, m] = factorial(m) / (factorial(nx) * factorial(ny) * factorial(nz))
+    if symmetric and max_moment <= 3:
+        if max_moment >= 2:
             T[0, 2] = -1.0 / 3.0
-    if max_moment >= 3:
-        T[10:20, 3] = [1, 3, 3, 3, 6, 3, 1, 3, 3, 1]
-        if symmetric:
+        if max_moment >= 3:
             T[1:4, 3] = -3.0 / 5.0
     return T
+
+
+def full_moment_sums(P_of_components, u, H, max_moment):
+    """The reference's literal max_moment > 3 formulation for ONE centre and block, as a check of
+    the packed one: M = [1, u, u (x) u, ...] flattened (1 + 3 + 9 + ... + 3^m components,
+    grap.py:538-575), P = H^T M, Q[k, m] = sum over the 3^m components of rank m of P^2 (T_dm of
+    ones, :577-600). `u` [n, 3], `H` [n, K] -> Q [K, max_moment + 1]."""
+    blocks = [np.ones((len(u), 1))]
+    for _ in range(max_moment):
+        prev = blocks[-1]
+        blocks.append((prev[:, :, None] * u[:, None, :]).reshape(len(u), -1))
+    Q = np.zeros((H.shape[1], max_moment + 1))
+    for m, M in enumerate(blocks):
+        P = H.T @ M            # [K, 3^m]
+        Q[:, m] = (P ** 2).sum(axis=1)
+    return Q
 
 
 def moment_coefficients(u, max_moment):

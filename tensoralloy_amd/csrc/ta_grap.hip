@@ -38,7 +38,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxFilters = 32;
-constexpr int kMaxComp = 20;
+constexpr int kMaxComp = 56;   // packed components of the moments 0..5: 1 + 3 + 6 + 10 + 15 + 21
+constexpr int kSmallComp = 20; // ... of the moments 0..3 (the usual case: smaller LDS tables)
+constexpr int kMaxMom = 6;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double mlp_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMlpTileRows = 16;
@@ -46,12 +48,15 @@ constexpr int kMlpTileRows = 16;
 enum { GRAP_SF = 0, GRAP_MORSE = 1, GRAP_DENSITY = 2, GRAP_PEXP = 3, GRAP_NN = 4 };
 
 struct GrapParams {
-  int nel, K, max_moment, nd;  // nd = 1, 4, 10, 20 packed components
+  int nel, K, max_moment, nd;  // nd = 1, 4, 10, 20, 35, 56 packed components
   int nf;                      // features per (block, filter)
   int legacy, algo, cutoff;
-  int col_of_m[4];             // feature column of moment m, -1 = not emitted
+  int col_of_m[kMaxMom];       // feature column of moment m, -1 = not emitted
   double rcut, inv_rc2;
-  double T[kMaxComp][4];       // multiplicity tensor (grap.py:470-492)
+  const double *T;             // device [nd][kMaxMom] multiplicity tensor (grap.py:470-492, :577-600)
+  // device [nd] component words: bits 0-5 own index, 6-11 / 12-17 / 18-23 index of the component with
+  // one power of ux / uy / uz less (0 where that exponent is 0), 24-26 / 27-29 / 30-32 the exponents
+  const unsigned long long *cw;
   const double *fp;            // device [K][4] filter constants
   // algorithm `nn`: per pair the K filter values and their r-derivatives, written by
   // grap_nn_filter_kernel: Hbuf[p][0 .. Ks) = v_k(r_p), Hbuf[p][Ks .. 2 Ks) = dv_k/dr
@@ -59,27 +64,10 @@ struct GrapParams {
   int Ks;                      // K rounded up to 16
 };
 
-// exponents (nx, ny, nz) packed 2 bits each, in the reference's component order (grap.py:501-511)
-__device__ __forceinline__ int comp_code(int d) {
-  constexpr unsigned char tab[kMaxComp] = {
-      0x00, 0x01, 0x04, 0x10, 0x02, 0x05, 0x11, 0x08, 0x14, 0x20,
-      0x03, 0x06, 0x12, 0x09, 0x15, 0x21, 0x0c, 0x18, 0x24, 0x30};
-  // select chain instead of a memory table: d is lane-dependent
-  int c = 0;
-#pragma unroll
-  for (int k = 0; k < kMaxComp; ++k) c = (d == k) ? tab[k] : c;
-  return c;
-}
-
-// packed index of the component with exponents (nx, ny, nz); 0 when any exponent is negative
-__device__ __forceinline__ int comp_index(int nx, int ny, int nz) {
-  if (nx < 0 || ny < 0 || nz < 0) return 0;
-  const int code = nx | (ny << 2) | (nz << 4);
-  int idx = 0;
-#pragma unroll
-  for (int k = 0; k < kMaxComp; ++k) idx = (comp_code(k) == code) ? k : idx;
-  return idx;
-}
+// The packed components M_d = ux^nx uy^ny uz^nz come in the reference's order (grap.py:501-511):
+// degree after degree, inside a degree with nx descending, then ny (1 | x y z | xx xy xz yy yz zz |
+// xxx xxy ...); their exponents and the indices of the components with one power less (what
+// dM_d/du needs) are tabulated on the host (component words, see GrapParams::cw).
 
 // v(r) and dv/dr of one radial filter (without the cutoff), from constants preprocessed on the
 // host (grap_create) so that no division and no logarithm is left per (pair, filter):
@@ -129,17 +117,19 @@ constexpr int kBwdChunk = 64;
 // all packed monomials M[t][d] (every lane of a 16-lane row needs a different component of the
 // same pair: one ds_read instead of a per-lane select chain). Entries n .. round_up(n, 16) are
 // zero-filled so that the MFMA loops need no tail predicates.
-template <int CH>
+template <int CH, int MC>
 struct PairLds {
   double r[CH], logr[CH], inv_r[CH], f[CH], df[CH], ux[CH], uy[CH], uz[CH];
-  double M[CH][kMaxComp];
+  double M[CH][MC];
 };
 
 // GEOM: the pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474) is computed here
 // (forward pass) and left in the pair record for the backward kernel and the force gather.
-template <int CH, bool GEOM>
+// `cwl`: the component words in LDS.
+template <int CH, int MC, bool GEOM>
 __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBatch &b, int first, int n,
-                                            PairLds<CH> &L, int lane, int64_t centre = 0, double eps = 0.0) {
+                                            PairLds<CH, MC> &L, const unsigned long long *cwl, int lane,
+                                            int64_t centre = 0, double eps = 0.0) {
   const int npad = min(CH, (n + 15) & ~15);
   for (int t = lane; t < npad; t += kWave) {
     double ux = 0.0, uy = 0.0, uz = 0.0, r = 1.0, inv_r = 1.0, f = 0.0, df = 0.0, one = 0.0;
@@ -194,49 +184,37 @@ __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBat
     L.ux[t] = ux;
     L.uy[t] = uy;
     L.uz[t] = uz;
+    // every monomial is its parent (one power of one axis less, always an earlier component) times
+    // that axis: one multiplication per component
     double *M = L.M[t];
     M[0] = one;
-    if (g.nd > 1) {
-      M[1] = ux;
-      M[2] = uy;
-      M[3] = uz;
-    }
-    if (g.nd > 4) {
-      const double xx = ux * ux, xy = ux * uy, xz = ux * uz, yy = uy * uy, yz = uy * uz, zz = uz * uz;
-      M[4] = xx;
-      M[5] = xy;
-      M[6] = xz;
-      M[7] = yy;
-      M[8] = yz;
-      M[9] = zz;
-      if (g.nd > 10) {
-        M[10] = xx * ux;
-        M[11] = xx * uy;
-        M[12] = xx * uz;
-        M[13] = xy * uy;
-        M[14] = xy * uz;
-        M[15] = xz * uz;
-        M[16] = yy * uy;
-        M[17] = yy * uz;
-        M[18] = yz * uz;
-        M[19] = zz * uz;
-      }
+    for (int d = 1; d < g.nd; ++d) {
+      const unsigned long long w = cwl[d];
+      const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7);
+      const int parent = ex ? (int)((w >> 6) & 63) : (ey ? (int)((w >> 12) & 63) : (int)((w >> 18) & 63));
+      M[d] = M[parent] * (ex ? ux : (ey ? uy : uz));
     }
   }
 }
 
 // One wavefront (= workgroup) per atom: P (kept for the backward pass) and the features.
+// MC = size of the monomial table: 20 (moments 0..3) or 56 (moments 4, 5): NT = 2 or 4 column tiles.
+template <int MC>
 __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, DeviceBatch b, double *Pbuf,
                                                             int ndim, double eps) {
-  __shared__ PairLds<kFwdChunk> L;
+  constexpr int NT = (MC + 15) / 16;
+  __shared__ PairLds<kFwdChunk, MC> L;
+  __shared__ unsigned long long cwl[MC];
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const int m16 = lane & 15, q4 = lane >> 4;
   const int nel = g.nel, K = g.K, nd = g.nd;
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
-  const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
-  const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
+  for (int d = lane; d < MC; d += kWave) cwl[d] = d < nd ? g.cw[d] : 0ull;
+  bool d_ok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) d_ok[t] = 16 * t + m16 < nd;
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     const int tb = term_block(sA, sb);
@@ -245,14 +223,16 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
       const bool k_ok = k < K;
       const double fp0 = k_ok ? g.fp[4 * k] : 0.0, fp1 = k_ok ? g.fp[4 * k + 1] : 0.0,
                    fp2 = k_ok ? g.fp[4 * k + 2] : 0.0;
-      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      f64x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = {0.0, 0.0, 0.0, 0.0};
       for (int first = lo; first < hi; first += kFwdChunk) {
         const int n = min(kFwdChunk, hi - first);
         __syncthreads();
         if (kt == 0)
-          stage_pairs<kFwdChunk, true>(g, b, first, n, L, lane, i, eps);
+          stage_pairs<kFwdChunk, MC, true>(g, b, first, n, L, cwl, lane, i, eps);
         else
-          stage_pairs<kFwdChunk, false>(g, b, first, n, L, lane);
+          stage_pairs<kFwdChunk, MC, false>(g, b, first, n, L, cwl, lane);
         __syncthreads();
         for (int base = 0; base < n; base += 4) {
           const int t = base + q4;  // < round_up(n, 16): staged (zero beyond n)
@@ -262,34 +242,41 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
           else
             filter_fn(g.algo, fp0, fp1, fp2, L.r[t], L.logr[t], L.inv_r[t], v, dv);
           const double h = k_ok ? v * L.f[t] : 0.0;
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d0_ok ? L.M[t][m16] : 0.0, acc0, 0, 0, 0);
-          if (nd > 16)
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d1_ok ? L.M[t][d1] : 0.0, acc1, 0, 0, 0);
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+            if (16 * ct < nd)
+              acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, d_ok[ct] ? L.M[t][16 * ct + m16] : 0.0, acc[ct], 0, 0, 0);
         }
       }
-      // accumulator register r holds P[k' = 16 kt + q4 + 4 r][d = m16 (+ 16)]
-      double T0[4], T1[4];
+      // accumulator register r of tile ct holds P[k' = 16 kt + q4 + 4 r][d = 16 ct + m16]
+      double Tm[NT][kMaxMom];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        T0[m] = d0_ok ? g.T[m16][m] : 0.0;
-        T1[m] = d1_ok ? g.T[d1][m] : 0.0;
-      }
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int m = 0; m < kMaxMom; ++m)
+          Tm[ct][m] = (d_ok[ct] && m <= g.max_moment) ? g.T[(16 * ct + m16) * kMaxMom + m] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = kt * 16 + q4 + 4 * r;
         const bool kk_ok = kk < K;
         double *Prow = Pbuf + (((size_t)i * nel + tb) * K + (kk_ok ? kk : 0)) * nd;
-        const double pa = acc0[r], pb = acc1[r];
-        if (kk_ok && d0_ok) Prow[m16] = pa;
-        if (kk_ok && d1_ok) Prow[16 + m16] = pb;
-        const double s0 = pa * pa, s1 = pb * pb;
-        const double p_lin = row16_sum(m16 == 0 ? pa : 0.0);  // P[k'][0] in every lane of the row
+        double sq[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          const double pv = acc[ct][r];
+          if (kk_ok && d_ok[ct]) Prow[16 * ct + m16] = pv;
+          sq[ct] = pv * pv;
+        }
+        const double p_lin = row16_sum(m16 == 0 ? acc[0][r] : 0.0);  // P[k'][0] in every lane of the row
         double feat = 0.0;
         int col = -1;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < kMaxMom; ++m) {
           if (m > g.max_moment) break;
-          double q = row16_sum(T0[m] * s0 + T1[m] * s1);
+          double part = 0.0;
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) part = fma(Tm[ct][m], sq[ct], part);
+          double q = row16_sum(part);
           if (m == 0) {
             // legacy: the raw sum (grap.py:425-428); new: sign(P0) sqrt(Q0 + 1e-16) (:663-672)
             const double sgn = p_lin > 0.0 ? 1.0 : (p_lin < 0.0 ? -1.0 : 0.0);
@@ -310,9 +297,12 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
 //   A[k][d] = dE/dP[k][d] = 2 P[k][d] sum_m c[k][m] T[d][m]  (+ dE/dG0 for d = 0 in legacy mode)
 // is formed while staging it in LDS. dM_d/du_c = n_c M_{d - e_c}: a second read of the monomial
 // table at the index of the component with one power of u_c less.
+template <int MC>
 __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, DeviceBatch b,
                                                              const double *Pbuf, int ndim) {
-  __shared__ PairLds<kBwdChunk> L;
+  constexpr int NT = (MC + 15) / 16;
+  __shared__ PairLds<kBwdChunk, MC> L;
+  __shared__ unsigned long long cwl[MC];
   extern __shared__ double dyn[];  // A[Kp][nd], then FP[4 K]
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
@@ -322,29 +312,12 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   double *A = dyn, *FP = dyn + Kp * nd, *wrow = FP + 4 * K;  // wrow: this atom's dE/dG row
   const int sA = b.species[i];
   const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
-  const int d1 = 16 + m16 < kMaxComp ? 16 + m16 : 0;
-  const bool d0_ok = m16 < nd, d1_ok = 16 + m16 < nd;
   // The pair tiles are computed transposed (rows = components, columns = pairs): accumulator
-  // register r of this lane then holds component d = q4 + 4 r (tile 0) or 16 + q4 (tile 1, r = 0)
-  // of ITS OWN pair j = m16, so the sum over components is 5 terms in registers plus one
-  // exchange between the four 16-lane rows, and the pair's unit vector is read once.
-  // Per-lane constants of those 5 components: table indices of M_{d - e_c}, exponents, degree.
-  // packed into one word each to keep the register count (and so the occupancy) down
-  int cw[5];
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int d = r < 4 ? q4 + 4 * r : 16 + q4;
-    const bool ok = d < nd;
-    const int c = comp_code(ok ? d : 0);
-    const int ex = c & 3, ey = (c >> 2) & 3, ez = (c >> 4) & 3;
-    // components beyond nd read a written table entry with zero weights (0 * stale LDS = NaN)
-    const int id = ok ? d : 0;
-    const int ix = ok ? comp_index(ex - 1, ey, ez) : 0;
-    const int iy = ok ? comp_index(ex, ey - 1, ez) : 0;
-    const int iz = ok ? comp_index(ex, ey, ez - 1) : 0;
-    cw[r] = id | (ix << 5) | (iy << 10) | (iz << 15) | ((ok ? ex : 0) << 20) | ((ok ? ey : 0) << 22) |
-            ((ok ? ez : 0) << 24);
-  }
+  // register r of tile ct holds component d = 16 ct + q4 + 4 r of this lane's OWN pair j = m16, so
+  // the sum over components is 4 NT terms in registers plus one exchange between the four 16-lane
+  // rows, and the pair's unit vector is read once. The constants of those components (table indices
+  // of M_{d - e_c}, exponents) are the component words in LDS.
+  for (int d = lane; d < MC; d += kWave) cwl[d] = d < nd ? g.cw[d] : 0ull;
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
   for (int t = lane; t < ndim; t += kWave) wrow[t] = b.dEdG[(size_t)i * ndim + t];
   for (int sb = 0; sb < nel; ++sb) {
@@ -361,7 +334,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
         const double *w = wrow + ((size_t)tb * K + k) * g.nf;
         double s = 0.0, lin = 0.0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < kMaxMom; ++m) {
           if (m > g.max_moment) break;
           const int col = g.col_of_m[m];
           if (col < 0) continue;
@@ -376,7 +349,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
               c = c * sgn / (2.0 * sqrt(P0 * P0 + 1e-16));
             }
           }
-          s = fma(c, g.T[d][m], s);
+          s = fma(c, g.T[d * kMaxMom + m], s);
         }
         val = 2.0 * P * s + lin;
       }
@@ -385,13 +358,18 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
     for (int first = lo; first < hi; first += kBwdChunk) {
       const int n = min(kBwdChunk, hi - first);
       __syncthreads();
-      stage_pairs<kBwdChunk, false>(g, b, first, n, L, lane);
+      stage_pairs<kBwdChunk, MC, false>(g, b, first, n, L, cwl, lane);
       __syncthreads();
       for (int j0 = 0; j0 < n; j0 += 16) {
         // B-operand columns: this lane's pair (zero-filled beyond n: f = df = 0)
         const int ta = j0 + m16;
         const double r = L.r[ta], logr = L.logr[ta], inv_r = L.inv_r[ta], f = L.f[ta], df = L.df[ta];
-        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+        f64x4 av[NT], bv[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          av[ct] = {0.0, 0.0, 0.0, 0.0};
+          bv[ct] = {0.0, 0.0, 0.0, 0.0};
+        }
         for (int k0 = 0; k0 < Kp; k0 += 4) {
           const int k = k0 + q4;
           double H = 0.0, dH = 0.0;
@@ -407,32 +385,34 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
             H = v * f;
             dH = dv * f + v * df;
           }
-          // A operand = A^T[d = m16 (+ 16)][k], B operand = H[k][pair = m16]
-          const double A0 = d0_ok ? A[k * nd + m16] : 0.0;
-          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, H, a0, 0, 0, 0);
-          b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, dH, b0, 0, 0, 0);
-          if (nd > 16) {
-            const double A1 = d1_ok ? A[k * nd + d1] : 0.0;
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, H, a1, 0, 0, 0);
-            b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, dH, b1, 0, 0, 0);
-          }
+          // A operand = A^T[d = 16 ct + m16][k], B operand = H[k][pair = m16]
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+            if (16 * ct < nd) {
+              const double At = (16 * ct + m16 < nd) ? A[k * nd + 16 * ct + m16] : 0.0;
+              av[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(At, H, av[ct], 0, 0, 0);
+              bv[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(At, dH, bv[ct], 0, 0, 0);
+            }
         }
-        // this lane: pair ta, components cd[0..4]
+        // this lane: pair ta, components 16 ct + q4 + 4 rr
         const double ux = L.ux[ta], uy = L.uy[ta], uz = L.uz[ta];
         const double *M = L.M[ta];
         double gx = 0.0, gy = 0.0, gz = 0.0;
 #pragma unroll
-        for (int rr = 0; rr < 5; ++rr) {
-          if (rr == 4 && nd <= 16) break;
-          const double ad = rr < 4 ? a0[rr] : a1[0], bd = rr < 4 ? b0[rr] : b1[0];
-          const double at = ad * inv_r;
-          const int w = cw[rr];
-          const int ex = (w >> 20) & 3, ey = (w >> 22) & 3, ez = (w >> 24) & 3;
-          const double rad = (bd - (double)(ex + ey + ez) * at) * M[w & 31];  // multiplies u
-          gx = fma(rad, ux, fma(at * (double)ex, M[(w >> 5) & 31], gx));
-          gy = fma(rad, uy, fma(at * (double)ey, M[(w >> 10) & 31], gy));
-          gz = fma(rad, uz, fma(at * (double)ez, M[(w >> 15) & 31], gz));
-        }
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int d = 16 * ct + q4 + 4 * rr;
+            if (d >= nd) continue;  // (accumulators of components beyond nd are zero anyway)
+            const unsigned long long w = cwl[d];
+            const double ad = av[ct][rr], bd = bv[ct][rr];
+            const double at = ad * inv_r;
+            const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7), ez = (int)((w >> 30) & 7);
+            const double rad = (bd - (double)(ex + ey + ez) * at) * M[d];  // multiplies u
+            gx = fma(rad, ux, fma(at * (double)ex, M[(w >> 6) & 63], gx));
+            gy = fma(rad, uy, fma(at * (double)ey, M[(w >> 12) & 63], gy));
+            gz = fma(rad, uz, fma(at * (double)ez, M[(w >> 18) & 63], gz));
+          }
         // components live in the four 16-lane rows: lanes m16, m16 + 16, + 32, + 48
         gx += __shfl_xor(gx, 16);
         gy += __shfl_xor(gy, 16);
@@ -606,6 +586,8 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
 struct GrapModel {
   GrapParams p;
   double *fp = nullptr;                  // device filter constants
+  double *T_dev = nullptr;               // device multiplicity tensor [nd][kMaxMom]
+  unsigned long long *cw_dev = nullptr;  // device component words [nd]
   double *Pbuf = nullptr;
   size_t cap_atoms = 0;
   int ndim = 0;
@@ -712,8 +694,8 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
     err = "GRAP supports 1.." + std::to_string(kMaxFilters) + " radial filters";
     return nullptr;
   }
-  if (mm < 0 || mm > 3) {
-    err = "GRAP moment tensors above rank 3 are not implemented";
+  if (mm < 0 || mm > 5) {
+    err = "The maximum angular moment should be <= 5";  // grap.py:580-581
     return nullptr;
   }
   if (legacy && mm > 2) {
@@ -734,14 +716,15 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
   p.nel = m->n_elements;
   p.K = K;
   p.max_moment = mm;
-  p.nd = mm == 0 ? 1 : (mm == 1 ? 4 : (mm == 2 ? 10 : 20));
+  const int nd_of[6] = {1, 4, 10, 20, 35, 56};
+  p.nd = nd_of[mm];
   p.legacy = legacy ? 1 : 0;
   p.algo = algo;
   p.cutoff = m->cutoff_function;
   p.rcut = m->rcut;
   p.inv_rc2 = 1.0 / (m->rcut * m->rcut);
   int col = 0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kMaxMom; ++k) {
     const bool on = legacy ? ((mask >> k) & 1) && k <= 2 : k <= mm;
     p.col_of_m[k] = (on && k <= mm) ? col++ : -1;
   }
@@ -751,22 +734,51 @@ GrapModel *grap_create(const ta_model_desc *m, std::string &err) {
     err = "GRAP needs at least one moment tensor";
     return nullptr;
   }
-  // multiplicity tensor, grap.py:470-492 (the legacy sums are the non-symmetric one)
-  const bool sym = symmetric && !legacy;
-  p.T[0][0] = 1.0;
-  if (mm >= 1)
-    for (int d = 1; d < 4; ++d) p.T[d][1] = 1.0;
-  if (mm >= 2) {
-    const double t2[6] = {1, 2, 2, 1, 2, 1};
-    for (int d = 0; d < 6; ++d) p.T[4 + d][2] = t2[d];
-    if (sym) p.T[0][2] = -1.0 / 3.0;
+  // Packed components in the reference's order (grap.py:501-511, continued for the ranks 4 and 5):
+  // degree after degree, nx descending, then ny. Multiplicity tensor: grap.py:470-492 for moments up
+  // to 3 (with the traceless corrections of the `symmetric` variant); for max_moment > 3 the
+  // reference sums the FULL 3^m tensors with unit weights (get_moment_tensor / get_T_dm, :538-600),
+  // i.e. every packed component counts with its multinomial coefficient, at every rank, and
+  // `symmetric` plays no role.
+  std::vector<int> ex, ey, ez;
+  for (int deg = 0; deg <= mm; ++deg)
+    for (int nx = deg; nx >= 0; --nx)
+      for (int ny = deg - nx; ny >= 0; --ny) {
+        ex.push_back(nx);
+        ey.push_back(ny);
+        ez.push_back(deg - nx - ny);
+      }
+  auto find = [&](int a, int b2, int c) {
+    if (a < 0 || b2 < 0 || c < 0) return 0;
+    for (int d = 0; d < p.nd; ++d)
+      if (ex[d] == a && ey[d] == b2 && ez[d] == c) return d;
+    return 0;
+  };
+  auto fact = [](int n) { double f = 1.0; for (int k = 2; k <= n; ++k) f *= k; return f; };
+  std::vector<double> T((size_t)p.nd * kMaxMom, 0.0);
+  std::vector<unsigned long long> cw(p.nd, 0ull);
+  const bool sym = symmetric && !legacy && mm <= 3;
+  for (int d = 0; d < p.nd; ++d) {
+    const int deg = ex[d] + ey[d] + ez[d];
+    T[(size_t)d * kMaxMom + deg] = fact(deg) / (fact(ex[d]) * fact(ey[d]) * fact(ez[d]));
+    cw[d] = (unsigned long long)d | ((unsigned long long)find(ex[d] - 1, ey[d], ez[d]) << 6) |
+            ((unsigned long long)find(ex[d], ey[d] - 1, ez[d]) << 12) |
+            ((unsigned long long)find(ex[d], ey[d], ez[d] - 1) << 18) | ((unsigned long long)ex[d] << 24) |
+            ((unsigned long long)ey[d] << 27) | ((unsigned long long)ez[d] << 30);
   }
-  if (mm >= 3) {
-    const double t3[10] = {1, 3, 3, 3, 6, 3, 1, 3, 3, 1};
-    for (int d = 0; d < 10; ++d) p.T[10 + d][3] = t3[d];
-    if (sym)
-      for (int d = 1; d < 4; ++d) p.T[d][3] = -3.0 / 5.0;
+  if (sym && mm >= 2) T[0 * kMaxMom + 2] = -1.0 / 3.0;
+  if (sym && mm >= 3)
+    for (int d = 1; d < 4; ++d) T[(size_t)d * kMaxMom + 3] = -3.0 / 5.0;
+  if (hipMalloc((void **)&g->T_dev, T.size() * sizeof(double)) != hipSuccess ||
+      hipMemcpy(g->T_dev, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc((void **)&g->cw_dev, cw.size() * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemcpy(g->cw_dev, cw.data(), cw.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) {
+    grap_destroy(g);
+    err = "device allocation failed";
+    return nullptr;
   }
+  p.T = g->T_dev;
+  p.cw = g->cw_dev;
   p.Ks = (K + 15) / 16 * 16;
   if (algo == GRAP_NN) {
     try {
@@ -823,6 +835,8 @@ bool grap_uses_filter_net(const GrapModel *g) { return g->p.algo == GRAP_NN; }
 void grap_destroy(GrapModel *g) {
   if (!g) return;
   if (g->fp) (void)hipFree(g->fp);
+  if (g->T_dev) (void)hipFree(g->T_dev);
+  if (g->cw_dev) (void)hipFree(g->cw_dev);
   if (g->Pbuf) (void)hipFree(g->Pbuf);
   if (g->Hbuf) (void)hipFree(g->Hbuf);
   for (double *d : g->owned) (void)hipFree(d);
@@ -877,16 +891,24 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStre
     }
 #undef TA_GRAP_NET
   }
-  hipLaunchKernelGGL(grap_forward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->Pbuf,
-                     g->ndim, eps);
+  if (g->p.nd <= kSmallComp)
+    hipLaunchKernelGGL(grap_forward_kernel<kSmallComp>, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b,
+                       g->Pbuf, g->ndim, eps);
+  else
+    hipLaunchKernelGGL(grap_forward_kernel<kMaxComp>, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b,
+                       g->Pbuf, g->ndim, eps);
 }
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
   const int Kp = (g->p.K + 3) & ~3;
   const size_t lds = ((size_t)Kp * g->p.nd + 4 * (size_t)g->p.K + (size_t)g->ndim) * sizeof(double);
-  hipLaunchKernelGGL(grap_backward_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), lds, s, g->p, b,
-                     g->Pbuf, g->ndim);
+  if (g->p.nd <= kSmallComp)
+    hipLaunchKernelGGL(grap_backward_kernel<kSmallComp>, dim3((unsigned)b.n_atoms), dim3(kWave), lds, s, g->p, b,
+                       g->Pbuf, g->ndim);
+  else
+    hipLaunchKernelGGL(grap_backward_kernel<kMaxComp>, dim3((unsigned)b.n_atoms), dim3(kWave), lds, s, g->p, b,
+                       g->Pbuf, g->ndim);
 }
 
 }  // namespace ta

@@ -9,8 +9,9 @@ Radial filters ("algorithms", grap.py:124-219): `sf` (eta, omega), `morse` (D, g
 filter network r -> K filter values, `convolution1x1(r, hidden_sizes, num_out=num_filters,
 output_bias=False, use_resnet_dt=True)`, grap.py:632-643; weights in
 `descriptor.filter_weights = [(W, b), ..., (W_out, None)]`; `h_abck_modifier` 0, 1, 2; only the
-non-legacy formulation, as in the reference). Moment tensors above rank 3 raise `ValueError` (the
-reference switches to full 3^m tensors there, grap.py:531-590).
+non-legacy formulation, as in the reference). Moment tensors up to rank 5: above rank 3 the
+reference sums the full 3^m tensors with unit weights (get_moment_tensor / get_T_dm, grap.py:538-600),
+here the packed components carry their multinomial coefficients instead: the same numbers.
 """
 from __future__ import annotations
 
@@ -123,8 +124,8 @@ class GenericRadialAtomicPotential:
         moment_tensors = list(set(int(m) for m in moment_tensors))  # grap.py:295
         if any(m < 0 for m in moment_tensors):
             raise ValueError("moment tensors must be >= 0")
-        if max(moment_tensors) > 3:
-            raise ValueError("GRAP: moment tensors above rank 3 are not implemented by tensoralloy_amd")
+        if max(moment_tensors) > 5:
+            raise ValueError("The maximum angular moment should be <= 5")  # grap.py:580-581
         if cutoff_function not in ("cosine", "polynomial"):
             raise ValueError(f"Unknown cutoff function: {cutoff_function}")
         self.filter_weights = None

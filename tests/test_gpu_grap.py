@@ -134,3 +134,30 @@ def test_nn_filter_network_input_modifiers(lib, tmp_path, modifier):
     assert calc._nn.descriptor.algorithm.h_abck_modifier == modifier
     assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
     assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
+
+
+@pytest.mark.parametrize("mm", [4, 5])
+def test_moment_tensors_of_rank_4_and_5(lib, tmp_path, mm):
+    """max_moment 4 / 5 (grap.py:538-600: the reference switches to full 3^m tensors with unit
+    weights there; here 35 / 56 packed components with multinomial weights, four column tiles of
+    the MFMA kernels): analytic filters for one and two elements, the `nn` filter network, the
+    native `.npz` round trip."""
+    from tensoralloy_amd import TensorAlloyCalculator
+    rl = [1.0 + 0.2 * k for k in range(16)]
+    pl = [5.0 - 0.25 * k for k in range(16)]
+    nn = make_grap_nn(["Ni"], 6.0, [32, 32], "pexp", {"rl": rl, "pl": pl}, moment_tensors=list(range(mm + 1)))
+    assert nn.ndim() == (mm + 1) * len(rl)
+    _compare(nn, [fcc(rep=(2, 2, 2)), fcc(rep=(2, 2, 2), a=3.3, seed=5)])
+    nn2 = make_grap_nn(["Mo", "Ni"], 5.5, [16], "morse",
+                       {"D": [0.5, 1.0, 1.5], "gamma": [1.0, 1.2, 1.4], "r0": [2.0, 2.5, 3.0]},
+                       moment_tensors=[mm], symmetric=True)
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
+    _compare(nn2, [atoms])
+    nn3 = make_grap_nn(["Ni"], 5.0, [16], "nn", {"hidden_sizes": [16, 16], "num_filters": 6},
+                       moment_tensors=list(range(mm + 1)))
+    _compare(nn3, [fcc(rep=(2, 2, 2), seed=3)])
+    o = oracle_grap_eval(nn2, atoms)
+    calc = TensorAlloyCalculator(nn2.export_to_lammps_native(str(tmp_path / "m.npz")))
+    assert calc._nn.descriptor.max_moment == mm
+    assert abs(calc.get_potential_energy(atoms) - o["energy"]) < E_TOL
+    assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL

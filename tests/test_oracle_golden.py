@@ -377,3 +377,17 @@ def test_grap_nn_filters_oracle_finite_differences():
             a2.positions = p
             e.append(oracle_grap_eval(nn, a2)["energy"])
         assert abs(o["forces"][i, k] + (e[0] - e[1]) / 2e-5) < 1e-6
+
+
+def test_packed_components_equal_the_full_tensors():
+    """The reference's max_moment > 3 formulation sums the full 3^m tensors with unit weights
+    (grap.py:538-600); the packed components with multinomial weights give the same Q (cf. the
+    reference's own packed-vs-full identity, test_grap.py:152-200)."""
+    from oracle.grap import full_moment_sums, moment_coefficients, multiplicity_tensor
+    rng = np.random.RandomState(1)
+    u = rng.randn(40, 3)
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    H = rng.randn(40, 7)
+    for mm in range(6):
+        Q = ((H.T @ moment_coefficients(u, mm)) ** 2) @ multiplicity_tensor(mm)
+        assert np.abs(Q - full_moment_sums(None, u, H, mm)).max() < 1e-12
