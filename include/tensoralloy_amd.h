@@ -303,6 +303,21 @@ int ta_update_weights(ta_handle h, const double *weights, int64_t n_weights);
  * energy term of nn/losses.py:204-285. The batch's descriptors are computed once and reused. */
 int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int64_t n_grad);
 
+/* The whole loss gradient of an energy + forces + stress loss (nn/losses.py:204-437 through
+ * `tf.gradients`, nn/opt.py:89-166) for the per-atom MLP models, analytically. With u = dL/dF per
+ * atom and the symmetric Y = (dL/dstress) / V per frame, sum u.F + sum Y.W is the directional
+ * derivative D_delta E of the energy along
+ *     dR = R.Y - u   [n_atoms_total][3],      dh = h.Y   [n_frames][9]
+ * (W = -F^T R + (dE/dh)^T h, basic.py:306-316), and
+ *     grad = d/dtheta ( sum_f frame_coeff[f] E_f  +  D_delta E ).
+ * The descriptors do not depend on theta: their Jacobian with respect to the pair vectors is made
+ * once per resident batch (one backward launch per descriptor channel), every call then costs a
+ * pair sweep and ONE second-order pass through the MLP. frame_coeff, dR, dh may each be NULL (= 0).
+ * dG_out (may be NULL): the directional derivative of the raw descriptors [n_atoms_total][D] that
+ * entered the pass (parity tests). */
+int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
+                     double *grad, int64_t n_grad, double *dG_out);
+
 /* Tables of an EAM / ADP model's functions (analytic, nn or tabulated) on caller-supplied abscissae: what
  * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it
  * writes a LAMMPS setfl file. Rows: elements (sorted) for rho(r) [n_elements][n_r] and F(rho)

@@ -59,3 +59,89 @@ def flatten(model, grads):
             parts.append(np.ravel(dW))
             parts.append(np.ravel(db))
     return np.concatenate(parts)
+
+
+def activation2(name, x):
+    """Second derivative of the reference activations (nn/utils.py:39-74)."""
+    name = name.lower()
+    if name == "softplus":
+        s = 1.0 / (1.0 + np.exp(-x))
+        return s * (1.0 - s)
+    if name in ("relu", "leaky_relu"):
+        return np.zeros_like(x)
+    if name == "tanh":
+        t = np.tanh(x)
+        return -2.0 * t * (1.0 - t * t)
+    if name == "sigmoid":
+        s = 1.0 / (1.0 + np.exp(-x))
+        return s * (1.0 - s) * (1.0 - 2.0 * s)
+    if name == "softsign":
+        d = 1.0 + np.abs(x)
+        return -2.0 * np.sign(x) / d ** 3
+    if name == "elu":
+        return np.where(x > 0, 0.0, np.exp(np.minimum(x, 0.0)))
+    if name == "squareplus":
+        s = np.sqrt(x * x + 4.0)
+        return 2.0 / s ** 3
+    raise ValueError(name)
+
+
+def tangent_weight_gradients(model, symbols, G, dG, atom_coeff=None):
+    """{element: [(dW, db), ...]} of  sum_atoms atom_coeff y_atom  +  J,  J = sum_atoms (dMLP/dG)(G_atom) . dG_atom:
+    what `tf.gradients` yields for the forces / stress terms of the reference's loss
+    (nn/losses.py:285-437; J = D_delta E is linear in forces and virial) when the descriptors' change
+    `dG` along the direction delta is given. Forward carries value and tangent, the reverse sweep the
+    adjoints of both (see tensoralloy_amd/csrc/ta_train.hip::mlp_grad2_kernel for the recurrences)."""
+    out = {}
+    N = len(symbols)
+    atom_coeff = np.zeros(N) if atom_coeff is None else np.asarray(atom_coeff, dtype=np.float64)
+    for el in model.elements:
+        idx = np.array([k for k, s in enumerate(symbols) if s == el], dtype=np.int64)
+        layers = model.weights[el]
+        grads = [(np.zeros_like(np.asarray(W, dtype=float)), np.zeros(np.shape(W)[1])) for W, _ in layers]
+        if len(idx) == 0:
+            out[el] = grads
+            continue
+        x, xt = G[idx], dG[idx]
+        if model.minmax is not None and el in model.minmax:
+            xlo, xhi = model.minmax[el]
+            den = xhi - xlo
+            ok = den != 0.0
+            safe = np.where(ok, den, 1.0)
+            x = np.where(ok, (xhi - x) / safe, 0.0)
+            xt = np.where(ok, -xt / safe, 0.0)
+        xs, ts, das, dds, ress = [], [], [], [], []
+        for l, (W, b) in enumerate(layers):
+            W = np.asarray(W, dtype=float)
+            xs.append(x)
+            ts.append(xt)
+            z = x @ W + (b if b is not None else 0.0)
+            zt = xt @ W
+            if l < len(layers) - 1:
+                a, da = activation(model.activation, z)
+                d2 = activation2(model.activation, z)
+                res = (l > 0 and model.use_resnet_dt and W.shape[0] == W.shape[1])
+                x_new, xt_new = a, da * zt
+                if res:
+                    x_new, xt_new = x_new + x, xt_new + xt
+                das.append(da)
+                dds.append(d2 * zt)
+                ress.append(res)
+                x, xt = x_new, xt_new
+            else:
+                das.append(np.ones_like(z))
+                dds.append(np.zeros_like(z))
+                ress.append(False)
+        kappa = atom_coeff[idx][:, None] * np.ones((len(idx), 1))
+        nu = np.ones((len(idx), 1))
+        for l in range(len(layers) - 1, -1, -1):
+            W = np.asarray(layers[l][0], dtype=float)
+            lam = kappa * das[l] + nu * dds[l]
+            mu = nu * das[l]
+            grads[l] = (xs[l].T @ lam + ts[l].T @ mu, lam.sum(axis=0))
+            k_in, n_in = lam @ W.T, mu @ W.T
+            if ress[l]:
+                k_in, n_in = k_in + kappa, n_in + nu
+            kappa, nu = k_in, n_in
+        out[el] = grads
+    return out

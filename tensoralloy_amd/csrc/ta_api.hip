@@ -30,6 +30,14 @@ size_t mlp_grad_partial_doubles(const MlpDev &mlp, int n_atoms);
 void launch_mlp_grad(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                      const DeviceBatch &b, const double *frame_coeff, double *scratch, double *partial,
                      double *grad, hipStream_t s);
+size_t mlp_grad2_scratch_doubles(const MlpDev &mlp, int n_atoms);
+void launch_mlp_grad2(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
+                      const DeviceBatch &b, const double *dG, const double *frame_coeff, double *scratch,
+                      double *partial, double *grad, hipStream_t s);
+void launch_pair_tangent(const DeviceBatch &b, const double *dR, const double *dh, double *dD, hipStream_t s);
+void launch_descriptor_jvp(const DeviceBatch &b, int ndim, const double *J, const double *dD, double *dG,
+                           hipStream_t s);
+void launch_one_hot(double *dEdG, int64_t n_atoms, int ndim, int c, hipStream_t s);
 // GRAP (ta_grap.hip)
 struct GrapModel;
 GrapModel *grap_create(const ta_model_desc *m, std::string &err);
@@ -176,6 +184,10 @@ struct ta_context {
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
   bool descriptors_valid = false;  // db.G holds the resident batch's descriptors
   DevBuf<double> train_scratch, train_partial, train_grad, train_coeff;
+  // force / stress terms of the loss: J[c][p] = dG_c / dD_p of the resident batch (made once per
+  // batch by one backward launch per descriptor channel), the direction and its images
+  DevBuf<double> jvp_J, tan_dD, tan_dG, tan_dir;
+  bool jvp_valid = false;
 
   // MD loop (ta_set_skin / ta_update_positions): the list covers rmax + skin and is kept while no
   // atom has moved more than skin / 2 from where it was when the list was built
@@ -800,6 +812,7 @@ int ta_destroy(ta_handle h) {
   h->dEdG.release(); h->g.release(); h->wat.release(); h->bpart.release();
   h->benergy.release(); h->mlp_scratch.release();
   h->train_scratch.release(); h->train_partial.release(); h->train_grad.release(); h->train_coeff.release();
+  h->jvp_J.release(); h->tan_dD.release(); h->tan_dG.release(); h->tan_dir.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release();
   for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start,
@@ -884,6 +897,7 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   // buffers that were already regrown or repointed
   h->have_batch = false;
   h->descriptors_valid = false;
+  h->jvp_valid = false;
   h->filtered = false;
   h->db.n_blk_dev = nullptr;
   h->r_list = h->rmax + h->skin;
@@ -1127,6 +1141,7 @@ int ta_update_positions(ta_handle h, const double *positions, const double *cell
       HIP_CHECK(hipEventRecord(h->ev_upload, h->stream));
       if (h->filtered) apply_filter(h);  // the exact list of the new positions, on the device
       h->descriptors_valid = false;
+      h->jvp_valid = false;
       ++h->n_list_reuses;
       return;
     }
@@ -1454,6 +1469,109 @@ int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
+namespace {
+// the dE/dD launches of compute_impl alone, on the dE/dG that is in `db.dEdG` (the forward pass of
+// this batch has run: pair records, candidate masks and, for GRAP, the moments are resident)
+void backward_only(ta_context *h) {
+  using namespace ta;
+  const DeviceBatch &db = h->db;
+  hipStream_t s = h->stream;
+  if (h->kind == TA_MODEL_SF_MLP) {
+    if (h->sf.angular) {
+      bool first = true;
+      if (h->use_v2)
+        for (const ChunkPlan &cp : h->chunks_v2) {
+          launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+          first = false;
+        }
+      else
+        for (const ChunkPlan &cp : h->chunks) {
+          launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
+          first = false;
+        }
+    } else {
+      AngChunk dummy;
+      std::memset(&dummy, 0, sizeof(dummy));
+      launch_backward(h->sf, dummy, 1, 1, 1, true, true, db, s);
+    }
+  } else {
+    launch_grap_backward(h->grap, db, s);
+  }
+}
+}  // namespace
+
+int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh, double *grad,
+                     int64_t n_grad, double *dG_out) {
+  if (!h || !grad) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term exists for the per-atom MLP models");
+  if (!dR && !dh) {
+    if (!frame_coeff) return fail(h, TA_ERR_INVALID, "nothing to differentiate");
+    return ta_energy_gradient(h, frame_coeff, grad, n_grad);
+  }
+  return guarded(h, [&]() {
+    int64_t total = 0;
+    for (int e = 0; e < h->n_elements; ++e) total += ta::mlp_param_count(h->mlp[e]);
+    if (n_grad != total)
+      throw std::invalid_argument("ta_loss_gradient: expected room for " + std::to_string(total) + " values");
+    hipStream_t s = h->stream;
+    const size_t N = (size_t)h->db.n_atoms, P = (size_t)h->db.n_pairs, F = (size_t)h->db.n_frames;
+    const int D = h->sf.ndim;
+    if (!h->descriptors_valid || !h->jvp_valid)
+      compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // pair records, masks, moments, descriptors
+    if (!h->jvp_valid) {
+      // J[c][p] = dG_{i(p), c} / dD_p: the backward kernels with a one-hot dE/dG, once per channel
+      h->jvp_J.ensure((size_t)D * 4 * P + 8);
+      for (int c = 0; c < D; ++c) {
+        ta::launch_one_hot(h->db.dEdG, (int64_t)N, D, c, s);
+        backward_only(h);
+        if (P)
+          HIP_CHECK(hipMemcpyAsync(h->jvp_J.ptr + (size_t)c * 4 * P, h->db.g, 4 * P * sizeof(double),
+                                   hipMemcpyDeviceToDevice, s));
+      }
+      HIP_CHECK(hipGetLastError());
+      h->jvp_valid = true;
+    }
+    // direction -> pairs -> descriptors
+    h->tan_dir.ensure(3 * N + 9 * F + 8);
+    h->tan_dD.ensure(4 * P + 8);
+    h->tan_dG.ensure(N * (size_t)D + 8);
+    double *d_dR = h->tan_dir.ptr, *d_dh = h->tan_dir.ptr + 3 * N;
+    if (dR) HIP_CHECK(hipMemcpyAsync(d_dR, dR, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+    else HIP_CHECK(hipMemsetAsync(d_dR, 0, 3 * N * sizeof(double), s));
+    if (dh) HIP_CHECK(hipMemcpyAsync(d_dh, dh, 9 * F * sizeof(double), hipMemcpyHostToDevice, s));
+    else HIP_CHECK(hipMemsetAsync(d_dh, 0, 9 * F * sizeof(double), s));
+    ta::launch_pair_tangent(h->db, d_dR, d_dh, h->tan_dD.ptr, s);
+    ta::launch_descriptor_jvp(h->db, D, h->jvp_J.ptr, h->tan_dD.ptr, h->tan_dG.ptr, s);
+    size_t scratch = 0, partial = 0;
+    for (int e = 0; e < h->n_elements; ++e) {
+      const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+      scratch = std::max(scratch, ta::mlp_grad2_scratch_doubles(h->mlp[e], n_el));
+      partial = std::max(partial, ta::mlp_grad_partial_doubles(h->mlp[e], n_el));
+    }
+    h->train_scratch.ensure(scratch + 8);
+    h->train_partial.ensure(partial + 8);
+    h->train_grad.ensure((size_t)total + 8);
+    h->train_coeff.ensure(F + 8);
+    if (frame_coeff && F)
+      HIP_CHECK(hipMemcpyAsync(h->train_coeff.ptr, frame_coeff, F * sizeof(double), hipMemcpyHostToDevice, s));
+    size_t off = 0;
+    for (int e = 0; e < h->n_elements; ++e) {
+      const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+      ta::launch_mlp_grad2(h->mlp[e], h->activation, D, h->db.elem_atoms + h->db.elem_start[e], n_el, h->db,
+                           h->tan_dG.ptr, frame_coeff ? h->train_coeff.ptr : nullptr, h->train_scratch.ptr,
+                           h->train_partial.ptr, h->train_grad.ptr + off, s);
+      off += (size_t)ta::mlp_param_count(h->mlp[e]);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (dG_out && N)
+      HIP_CHECK(hipMemcpyAsync(dG_out, h->tan_dG.ptr, N * (size_t)D * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
   });
 }

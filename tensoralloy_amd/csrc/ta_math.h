@@ -252,6 +252,37 @@ __device__ __forceinline__ void activation_fn(int act, double x, double &h, doub
   }
 }
 
+// activation value, first and second derivative (the weight gradient of a force / stress loss
+// differentiates the MLP's input gradient once more, nn/losses.py:285-437)
+__device__ __forceinline__ void activation_fn2(int act, double x, double &h, double &dh, double &d2h) {
+  activation_fn(act, x, h, dh);
+  switch (act) {
+    case TA_ACT_SOFTPLUS:
+    case TA_ACT_SIGMOID:
+      // softplus' = sigmoid = s: s' = s (1 - s); sigmoid'' = s (1 - s)(1 - 2 s) with dh = s (1 - s)
+      d2h = (act == TA_ACT_SOFTPLUS) ? dh * (1.0 - dh) : dh * (1.0 - 2.0 * h);
+      break;
+    case TA_ACT_TANH:
+      d2h = -2.0 * h * dh;
+      break;
+    case TA_ACT_SOFTSIGN: {
+      const double d = 1.0 + fabs(x);
+      d2h = (x >= 0.0 ? -2.0 : 2.0) / (d * d * d);
+      break;
+    }
+    case TA_ACT_ELU:
+      d2h = x > 0.0 ? 0.0 : exp(x);
+      break;
+    case TA_ACT_SQUAREPLUS: {
+      const double s = sqrt(x * x + 4.0);
+      d2h = 2.0 / (s * s * s);
+      break;
+    }
+    default:  // relu, leaky relu, linear
+      d2h = 0.0;
+  }
+}
+
 // `safe_pow` of reference extension/grad_ops.py:16-74. Without TENSORALLOY_USE_CUSTOM_POW it is plain
 // `tf.pow`, whose gradient y x^(y-1) is Inf at x = 0 for y < 1 (safe = 0: IEEE pow, the same). The
 // custom variant (safe = 1) zeroes an infinite value (:25-26) and an infinite or NaN gradient

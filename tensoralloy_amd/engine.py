@@ -257,6 +257,30 @@ class Engine:
         self._check(self._lib.ta_energy_gradient(self._handle, _lib.as_dp(coeff), _lib.as_dp(grad), len(grad)))
         return grad
 
+    def loss_gradient(self, frame_coeff=None, dR=None, dh=None, return_tangent=False):
+        """d/dtheta (sum_f frame_coeff[f] E_f + D_delta E) for the resident batch, delta = (dR
+        [n_atoms, 3], dh [n_frames, 3, 3]): the gradient of an energy + forces + stress loss in one
+        analytic pass (`ta_loss_gradient`); flat parameter layout."""
+        null = C.POINTER(C.c_double)()
+        N, F = int(self.info.n_atoms), int(self.info.n_frames)
+
+        def arr(a, shape):
+            if a is None:
+                return None, null
+            a = np.ascontiguousarray(a, dtype=np.float64).reshape(shape)
+            return a, _lib.as_dp(a)
+        c, cp = arr(frame_coeff, (F,))
+        r, rp = arr(dR, (N, 3))
+        hh, hp = arr(dh, (F, 9))
+        grad = np.zeros(self.param_count())
+        tangent = np.zeros((N, int(self.info.descriptor_dim))) if return_tangent else None
+        self._check(self._lib.ta_loss_gradient(self._handle, cp, rp, hp, _lib.as_dp(grad), len(grad),
+                                               _lib.as_dp(tangent) if return_tangent else null))
+        if return_tangent:   # directional derivative of the raw descriptors [N, D]
+            scale = getattr(self._nn, "descriptor_scale", None)
+            return grad, (tangent * scale() if scale is not None else tangent)
+        return grad
+
     def energies(self, reuse_descriptors=True) -> np.ndarray:
         """Frame energies of the resident batch; with `reuse_descriptors` only the MLP is re-run."""
         want = _lib.TA_WANT_ENERGY | (_lib.TA_WANT_REUSE_DESCRIPTORS if reuse_descriptors else 0)

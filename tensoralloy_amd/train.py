@@ -104,6 +104,11 @@ def energy_loss(predictions, labels, n_atoms, method="rmse", per_atom_loss=True,
     return float(weight * loss), mae, weight * dl
 
 
+def _lib_want_all():
+    from . import _lib
+    return _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
+
+
 class Adam:
     """tf.train.AdamOptimizer as configured by nn/opt.py:89-166: bias-corrected step, optional
     exponential decay `lr * rate ** (step / steps)` (staircase optional)."""
@@ -254,18 +259,21 @@ def stress_loss(predictions, labels, method="rmse", weight=1.0):
 class Trainer:
     """Energy + forces + stress loss (nn/basic.py `get_total_loss`: the sum of the weighted terms).
 
-    The weight gradient of the force and stress terms needs second derivatives of the energy. They
-    are taken as a DIRECTIONAL derivative instead of a new backward pass: with u = dL/dF per atom and
-    the symmetric Y built from dL/dstress,
+    The weight gradient of the force and stress terms needs second derivatives of the energy
+    (the reference: `tf.gradients` through nn/losses.py:285-437). With u = dL/dF per atom and the
+    symmetric Y built from dL/dstress,
         sum u.F + sum Y.W = D_delta E,   delta R = R.Y - u,  delta h = h.Y,
-    so   d/dtheta (that sum) = [g(R + e dR, h + e dh) - g(R - e dR, h - e dh)] / (2 e)
-    with g = dE/dtheta from `ta_energy_gradient` on two displaced copies of every frame (central
-    difference, step `fd_step` Angstrom on the largest displacement; error O(step^2)).
+    the directional derivative of the energy; for the per-atom MLP models the descriptors do not
+    depend on the weights, so d/dtheta of it is ONE analytic second-order pass through the MLP
+    (`ta_loss_gradient`: descriptor Jacobian once per resident batch, then a pair sweep + the MLP
+    pass per step, energy term included). The nn functions of EAM / ADP models, whose pair networks
+    see r itself, keep the central difference of g = dE/dtheta on two displaced copies of every
+    frame (`analytic=False` forces it everywhere; step `fd_step` Angstrom, error O(step^2)).
     """
 
     def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
                  energy_weight=1.0, forces_weight=1.0, stress_weight=1.0, method="rmse",
-                 per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, **adam_kwargs):
+                 per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, analytic=None, **adam_kwargs):
         from .engine import Engine
         rank, local_rank, world = world_from_env()
         lo, hi = shard_range(len(frames), rank, world)
@@ -273,6 +281,9 @@ class Trainer:
         self.rank, self.world = rank, world
         self.device = local_rank if device is None else device
         self.engine = Engine(nn, device=self.device)
+        # the analytic second-order pass exists for the per-atom MLP models
+        self.analytic = (not hasattr(nn, "nn_functions")) if analytic is None else bool(analytic)
+        self._resident = False
         self.frames = list(frames[lo:hi])
         self.e_ref = np.asarray(energies, dtype=np.float64)[lo:hi]
         self.f_ref = None if forces is None else [np.asarray(f, dtype=np.float64) for f in forces[lo:hi]]
@@ -288,13 +299,21 @@ class Trainer:
     def loss_and_gradient(self):
         from .atoms import Atoms
         eng = self.engine
-        res = eng.evaluate(self.frames)
+        if self.analytic and self._resident:
+            # same frames as the last step: the batch, its neighbour list, descriptors and their
+            # Jacobian are resident; only the MLP changed
+            eng.compute(_lib_want_all())
+            res = eng._per_frame(eng.fetch(_lib_want_all()))
+        else:
+            res = eng.evaluate(self.frames)
+            self._resident = self.analytic
         pred_e = np.array([r["energy"] for r in res])
         we, wf, ws = self.weights
         terms = {}
         loss_e, mae_e, c = energy_loss(pred_e, self.e_ref, self.n_atoms, self.method, self.per_atom_loss, we)
         terms["energy"] = loss_e
-        grad = eng.energy_gradient(c)          # the resident batch is the undisplaced one
+        if not self.analytic:
+            grad = eng.energy_gradient(c)      # the resident batch is the undisplaced one
         u = [np.zeros((len(a), 3)) for a in self.frames]
         Y = [np.zeros((3, 3)) for _ in self.frames]
         second = False
@@ -311,7 +330,13 @@ class Trainer:
                 xx, yy, zz, yz, xz, xy = ds[k] / V
                 Y[k] = np.array([[xx, xy / 2, xz / 2], [xy / 2, yy, yz / 2], [xz / 2, yz / 2, zz]])
             second = True
-        if second:
+        if self.analytic:
+            dR = np.concatenate([a.positions @ Y[k] - u[k] for k, a in enumerate(self.frames)]) \
+                if self.frames else np.zeros((0, 3))
+            dh = np.array([np.asarray(a.get_cell(complete=True), dtype=np.float64) @ Y[k]
+                           for k, a in enumerate(self.frames)])
+            grad = eng.loss_gradient(c, dR if second else None, dh if second else None)
+        elif second:
             disp, coeff = [], []
             for k, a in enumerate(self.frames):
                 h = np.asarray(a.get_cell(complete=True), dtype=np.float64)

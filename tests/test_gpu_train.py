@@ -211,3 +211,57 @@ def test_nn_eam_fit_recovers_teacher_energies(lib):
     tr.close()
     # the RMSE loss has gradients of constant size near its minimum: Adam hovers around it
     assert min(hist) < 0.15 * hist[0] and np.mean(hist[-20:]) < 0.4 * hist[0]
+
+
+@pytest.mark.parametrize("kind", ["sf_binary_minmax_resnet", "sf_single_tanh", "grap"])
+def test_analytic_loss_gradient_matches_oracle(lib, kind):
+    """`ta_loss_gradient`: d/dtheta (sum_f c_f E_f + D_delta E) in one analytic pass, in two parts.
+    (1) The directional derivative dG of the descriptors (Jacobian from one-hot backward launches,
+    pair sweep: linear maps) against a sixth-order central difference of the ORACLE's descriptors
+    (accuracy of that difference: ~1e-7; the cutoffs sit between neighbour shells, because the
+    cosine cutoff's second derivative jumps at rc and a difference quotient across it is poor). (2) The second-order sweep through the MLP against the
+    oracle's restatement of the same recurrences (checked by finite differences in
+    tests/test_train_cpu.py) on the SAME dG: 1e-9, where the finite-difference path it replaces had 2e-6."""
+    from tensoralloy_amd import Atoms, Engine
+    from oracle.train import tangent_weight_gradients, flatten
+    grap = kind == "grap"
+    if kind == "sf_binary_minmax_resnet":
+        nn = make_nn(["Mo", "Ni"], 4.75, True, [16, 16], minmax=True, resnet=True)
+        frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2)), _alloy(["Ni", "Mo"], rep=(2, 2, 2), seed=8)]
+    elif kind == "sf_single_tanh":
+        nn = make_nn(["Ni"], 5.25, True, [24, 24], activation="tanh")
+        frames = [fcc(rep=(2, 2, 2)), fcc(rep=(2, 2, 3), seed=4)]
+    else:
+        nn = make_grap_nn(["Mo", "Ni"], 4.75, [16, 16], moment_tensors=[0, 1, 2])
+        frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))]
+    rng = np.random.RandomState(5)
+    coeff = rng.randn(len(frames))
+    dR = [rng.randn(len(a), 3) * 0.3 for a in frames]
+    dh = [rng.randn(3, 3) * 0.05 for _ in frames]
+    with Engine(nn) as eng:
+        eng.set_frames(frames)
+        g, dG_gpu = eng.loss_gradient(coeff, np.concatenate(dR), np.array(dh), return_tangent=True)
+        g_again = eng.loss_gradient(coeff, np.concatenate(dR), np.array(dh))   # Jacobian reused
+        g_energy = eng.loss_gradient(coeff)                                     # = ta_energy_gradient
+        assert np.array_equal(g_energy, eng.energy_gradient(coeff))
+    assert np.abs(g - g_again).max() < 1e-12 * max(1.0, np.abs(g).max())
+    m = oracle_grap_model(nn) if grap else oracle_model(nn)
+    evaluate = oracle_grap_eval if grap else oracle_eval
+    ref, a0 = None, 0
+    for a, c, d_r, d_h in zip(frames, coeff, dR, dh):
+        h0 = np.asarray(a.get_cell(complete=True), dtype=np.float64)
+
+        def G_at(t):
+            moved = Atoms(numbers=np.asarray(a.numbers).copy(), positions=a.positions + t * d_r,
+                          cell=h0 + t * d_h, pbc=np.asarray(a.pbc).copy())
+            return evaluate(nn, moved)["descriptors"]
+        e = 1e-3
+        dG_fd = (45.0 * (G_at(e) - G_at(-e)) - 9.0 * (G_at(2 * e) - G_at(-2 * e)) +
+                 (G_at(3 * e) - G_at(-3 * e))) / (60.0 * e)
+        mine = dG_gpu[a0:a0 + len(a)]
+        assert np.abs(mine - dG_fd).max() < 1e-6 * max(1.0, np.abs(dG_fd).max())
+        part = flatten(m, tangent_weight_gradients(m, a.get_chemical_symbols(), G_at(0.0), mine,
+                                                   np.full(len(a), c)))
+        ref = part if ref is None else ref + part
+        a0 += len(a)
+    assert np.abs(g - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())

@@ -142,3 +142,39 @@ def test_forces_and_stress_loss_derivatives():
     # nn/losses.py:285-332: one RMSE over every component of every real atom
     allc = np.concatenate([l - p for p, l in zip(pred, lab)])
     assert abs(forces_loss(pred, lab)[0] - np.sqrt(np.mean(allc ** 2) + np.finfo(float).eps)) < 1e-15
+
+
+def test_oracle_second_order_gradient_against_finite_differences():
+    """oracle.train.tangent_weight_gradients (the restatement the GPU's analytic force / stress loss
+    gradient is compared with): d/dtheta [sum c y + (dMLP/dG) . dG] against central differences in
+    single weights, for every activation family, with and without skip connections and min-max."""
+    import copy
+    from oracle.sf import apply_mlp
+    from oracle import train as ot
+    from tensoralloy_amd.train import flatten_weights, unflatten_weights
+    from tests.helpers import make_nn, oracle_model
+    rng = np.random.RandomState(0)
+    symbols = ["Ni", "Mo", "Ni", "Ni", "Mo"]
+    for act, res, mm in (("softplus", False, False), ("tanh", True, True), ("squareplus", True, False),
+                         ("elu", False, True), ("sigmoid", False, False), ("softsign", True, False),
+                         ("leaky_relu", False, False)):
+        nn = make_nn(["Ni", "Mo"], 5.0, True, [12, 12], activation=act, resnet=res, minmax=mm)
+        m = oracle_model(nn)
+        D = nn.ndim()
+        G, dG, c = rng.rand(5, D) * 2, rng.randn(5, D), rng.randn(5)
+
+        def J(model):
+            y, w = apply_mlp(model, symbols, G)
+            return (c * y).sum() + (w * dG).sum()
+        g = ot.flatten(m, ot.tangent_weight_gradients(m, symbols, G, dG, c))
+        th = flatten_weights(nn)
+        for k in rng.choice(len(th), 10, replace=False):
+            vals = []
+            for sgn in (1.0, -1.0):
+                t2 = th.copy()
+                t2[k] += sgn * 1e-5
+                nn2 = copy.deepcopy(nn)
+                nn2.weights = unflatten_weights(nn2, t2)
+                vals.append(J(oracle_model(nn2)))
+            fd = (vals[0] - vals[1]) / 2e-5
+            assert abs(fd - g[k]) < 1e-8 * max(1.0, abs(fd)), (act, k)
