@@ -148,7 +148,7 @@ def allreduce_mean(grad: np.ndarray, device=None) -> np.ndarray:
         return grad
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return grad
-    t = torch.from_numpy(np.ascontiguousarray(grad))
+    t = torch.from_numpy(np.array(grad, dtype=np.float64, copy=True))  # the all-reduce is in place: not on the caller's array
     if device is not None and dist.get_backend() == "nccl":
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -143,3 +143,79 @@ def test_update_positions_reuses_and_rebuilds_the_list(lib):
             assert eng.update_positions(pos) is True
             assert eng.update_positions(pos) is True
             assert int(eng.info.n_atoms) == len(atoms)
+
+
+TRAIN_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+import numpy as np
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from tensoralloy_amd.train import Trainer
+from tests.helpers import fcc, make_nn
+data = np.load({data!r}, allow_pickle=True)
+frames = [fcc(rep=(2, 2, 2), a=3.4 + 0.05 * k, seed=k, jitter=0.1) for k in range(4)]
+student = make_nn(["Ni"], 5.0, True, [12, 12], seed=77)
+tr = Trainer(student, frames, data["e"], list(data["f"]), data["s"], device=0, learning_rate=0.01)
+total, terms, grad = tr.loss_and_gradient()
+from tensoralloy_amd.train import allreduce_mean
+mean = allreduce_mean(grad, None)
+l0 = tr.step()[0]
+for _ in range(3):
+    l1 = tr.step()[0]
+print(json.dumps({{"rank": rank, "n_local": len(tr.frames), "grad": grad.tolist(), "mean": mean.tolist(),
+                  "theta": tr.theta.tolist(), "l0": l0, "l1": l1}}))
+tr.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_training_step_with_engines(lib, tmp_path):
+    """The reference's only collective is the gradient all-reduce of its replicas
+    (train/distribute_utils.py:56-81). Two ranks, each an Engine on the one GPU with its shard of the
+    frames: the mean of their (analytic, energy + forces + stress) gradients equals the mean of the
+    two shard gradients computed one after the other in this process, and both ranks hold the same
+    weights after four Adam steps."""
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import Trainer
+    from tests.helpers import fcc, make_nn
+    teacher = make_nn(["Ni"], 5.0, True, [12, 12], seed=5)
+    frames = [fcc(rep=(2, 2, 2), a=3.4 + 0.05 * k, seed=k, jitter=0.1) for k in range(4)]
+    with Engine(teacher) as eng:
+        ref = eng.evaluate(frames)
+    data = tmp_path / "labels.npz"
+    np.savez(data, e=np.array([r["energy"] for r in ref]), f=np.array([r["forces"] for r in ref]),
+             s=np.array([r["stress"] for r in ref]))
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER.format(root=ROOT, data=str(data)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert [o["n_local"] for o in outs] == [2, 2]
+    # the same two shard gradients, one after the other, in this process
+    shard = []
+    for lo, hi in ((0, 2), (2, 4)):
+        student = make_nn(["Ni"], 5.0, True, [12, 12], seed=77)
+        tr = Trainer(student, frames[lo:hi], [r["energy"] for r in ref[lo:hi]], [r["forces"] for r in ref[lo:hi]],
+                     [r["stress"] for r in ref[lo:hi]], device=0)
+        shard.append(tr.loss_and_gradient()[2])
+        tr.close()
+    mean = 0.5 * (shard[0] + shard[1])
+    for o, g in zip(outs, shard):
+        assert np.abs(np.array(o["grad"]) - g).max() < 1e-10 * max(1.0, np.abs(g).max())
+        assert np.abs(np.array(o["mean"]) - mean).max() < 1e-10 * max(1.0, np.abs(mean).max())
+    assert np.abs(np.array(outs[0]["theta"]) - np.array(outs[1]["theta"])).max() < 1e-12
+    assert all(np.isfinite(o["l1"]) for o in outs)
