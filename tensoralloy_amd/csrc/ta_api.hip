@@ -174,7 +174,9 @@ struct ta_context {
   DevBuf<double> results;
   size_t o_blk = 0;  // byte offset of blk_center in the packed input
   DevBuf<double> rec, part4, G, dEdG, g, wat, bpart, benergy, mlp_scratch;
-  DevBuf<unsigned long long> masks;
+  DevBuf<unsigned long long> masks, job_mask;
+  DevBuf<unsigned short> job_code;
+  DevBuf<int32_t> job_count;
   DevBuf<int32_t> pair_start, seg_start, pair_i, pair_j, pair_shift, pair_rev;
   ta::NlGrid *d_grids = nullptr;  // view into inbuf
   // device neighbour list (ta_nlist.hip)
@@ -818,7 +820,7 @@ int ta_destroy(ta_handle h) {
   for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start,
                   &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk})
     b->release();
-  h->masks.release();
+  h->masks.release(); h->job_mask.release(); h->job_code.release(); h->job_count.release();
   for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
                   &h->nl_bin_atoms, &h->nl_counts})
     b->release();
@@ -835,6 +837,23 @@ int ta_destroy(ta_handle h) {
 }  // extern "C" (reopened below)
 
 namespace {
+// job lists of the angular kernels (ta_kernels_v2.hip::make_jobs): room for `n_blk` workgroups
+void ensure_job_lists(ta_context *h, size_t n_blk) {
+  static const bool off = std::getenv("TA_NO_JOBS") != nullptr;  // A/B switch: per-lane masks + re-dealing
+  if (off || !h->use_v2 || n_blk == 0) {
+    h->db.job_count = nullptr;
+    return;
+  }
+  const int stride = ta::v2_job_stride(h->db.cap);
+  h->job_mask.ensure(n_blk * (size_t)stride + 8);
+  h->job_code.ensure(n_blk * (size_t)stride + 8);
+  h->job_count.ensure(n_blk + 8);
+  h->db.job_mask = h->job_mask.ptr;
+  h->db.job_code = h->job_code.ptr;
+  h->db.job_count = h->job_count.ptr;
+  h->db.job_stride = stride;
+}
+
 // MD loop with a Verlet skin: the evaluation kernels get the EXACT list of the current positions,
 // extracted from the resident skin list on the device (ta_nlist.hip::nl_filter; no host round trip),
 // so they never pay for the skin. Only for models whose kernels are driven by centres (second-
@@ -879,6 +898,7 @@ void apply_filter(ta_context *h) {
     h->db.blk_center = h->ex_blk.ptr;
     h->db.n_blk = (int)N;  // upper bound of the grid: every run holds at least one centre
     h->db.n_blk_dev = n_blk_dev;
+    ensure_job_lists(h, N);
   }
   h->filtered = true;
 }
@@ -1027,6 +1047,7 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
       blk[nb++] = (int32_t)N;
     }
     h->db.n_blk = nb ? nb - 1 : 0;
+    ensure_job_lists(h, (size_t)h->db.n_blk);
     if (nb)
       HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
                                h->stream));

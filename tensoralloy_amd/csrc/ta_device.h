@@ -77,6 +77,14 @@ struct DeviceBatch {
                             // of the forward, backward and gather kernels; 1/r is recomputed)
   double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
   unsigned long long *masks = nullptr;  // [ceil(nnl_max/128)][P] candidate masks, forward -> backward
+  // Lane balance of the angular kernels: the forward kernel cuts every lane's surviving partners
+  // into jobs of <= K set bits, sorts them by size and leaves the list here for the backward
+  // kernel: per workgroup `job_count[blk]` jobs at [blk * job_stride ..): 64-bit partner mask and
+  // 16-bit code (item of the workgroup). null: the per-lane masks above are used.
+  unsigned long long *job_mask = nullptr;
+  unsigned short *job_code = nullptr;
+  int32_t *job_count = nullptr;
+  int job_stride = 0;
   double *G = nullptr;      // [N][D]
   double *dEdG = nullptr;   // [N][D]
   double *eatom = nullptr;  // [N]
@@ -127,7 +135,8 @@ void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s);
 size_t g4_lds_bytes(int nnl_max);
 
 // second-generation angular kernels (ta_kernels_v2.hip); `ch` holds one beta
-size_t v2_lds_bytes(bool backward, int cap);
+size_t v2_lds_bytes(bool backward, int cap, int n_local = 0);
+int v2_job_stride(int cap);
 // `reduce`: last forward launch of an evaluation, also assembles the descriptor vectors
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           bool reduce, const DeviceBatch &b, hipStream_t s);

@@ -258,6 +258,95 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
   }
 }
 
+// Finer lane balance than the re-dealing above: the surviving partners of every lane are cut into
+// JOBS of at most K set bits; full jobs (exactly K bits) are laid out by a prefix sum over the
+// lanes, the remainders (one per lane, 1 .. K-1 bits) follow sorted by size, largest first
+// (counting sort: one LDS atomic per remainder over K - 1 buckets); lane t then takes jobs t,
+// t + T, ... CPU simulation on the benchmark frame: 73 % (re-dealing) -> 91-94 % busy lanes in the
+// triple loops (K = 12 / 8). The list aliases the fp32 rings (dead once the masks exist), is written
+// to HBM by the forward kernel and read back by the backward kernel: one construction serves both
+// sweeps.
+__device__ __forceinline__ unsigned long long peel_bits(unsigned long long &m, int K) {
+  unsigned long long rest = m;
+  for (int k = 0; k < K && rest; ++k) rest &= rest - 1;
+  const unsigned long long sub = m ^ rest;
+  m = rest;
+  return sub;
+}
+
+struct JobLists {
+  unsigned long long *mask;  // [max_items]
+  unsigned short *code;      // [max_items]
+  int *hist, *start, *ctl;   // [66], [66], [8]
+};
+
+__device__ __forceinline__ JobLists job_lists(const Fields &f, int max_items) {
+  JobLists j;
+  j.mask = reinterpret_cast<unsigned long long *>(f.xf);
+  j.code = reinterpret_cast<unsigned short *>(j.mask + max_items);
+  return j;
+}
+
+// byte offset of the job counters (hist[66], start[66], ctl[8] ints: 640 bytes reserved) and, behind
+// them, of the forward kernel's per-pair partial sums P[n_local][cap]
+__host__ __device__ inline size_t v2_counter_offset(int cap) {
+  const size_t end = (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap;
+  return (end + 15) & ~(size_t)15;
+}
+__host__ __device__ inline int v2_max_jobs(int cap) { return (int)(3 * (size_t)(2 * cap + kRingPad) * sizeof(float) / 10); }
+
+// `j.hist` must be zero on entry (the kernel clears it before staging). Three barriers per attempt;
+// K = 8 unless the list would overflow (then 16, 32, 64: at most one job per lane).
+__device__ __forceinline__ int make_jobs(JobLists &j, int max_items, bool active, int item,
+                                         unsigned long long m0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+  const int p0 = active ? __popcll(m0) : 0;
+  for (int K = 8;; K *= 2) {
+    const int f0 = p0 / K, r0 = p0 - f0 * K;
+    int incl = f0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) j.ctl[wave] = incl;  // wave totals of the full jobs
+    int rank0 = 0;
+    if (r0) rank0 = atomicAdd(&j.hist[K - r0], 1);
+    __syncthreads();  // also: every lane is done with the rings (its mask exists)
+    int base = incl - f0, n_full = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const int t = j.ctl[w];
+      if (w < wave) base += t;
+      n_full += t;
+    }
+    int before = 0, n_rem = 0;  // remainders larger than this lane's, and all of them
+    for (int k = 1; k < K; ++k) {
+      const int c = j.hist[k];
+      before += (k < K - r0) ? c : 0;
+      n_rem += c;
+    }
+    if (n_full + n_rem <= max_items || K >= 64) {
+      if (active) {
+        unsigned long long w = m0;
+        for (int q = 0; q < f0; ++q) {
+          j.mask[base] = peel_bits(w, K);
+          j.code[base++] = (unsigned short)item;
+        }
+        if (r0) {
+          const int slot = n_full + before + rank0;
+          j.mask[slot] = w;
+          j.code[slot] = (unsigned short)item;
+        }
+      }
+      __syncthreads();
+      return n_full + n_rem;
+    }
+    __syncthreads();  // overflow: clear the histogram and try a coarser cut
+    if (tid < 66) j.hist[tid] = 0;
+    __syncthreads();
+  }
+}
+
 // Descriptor vectors of the workgroup's centres from data that is still in LDS, one wavefront per
 // centre, round robin. G2 from r^2 (sf.py:79-119):
 __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const DeviceBatch &b,
@@ -353,11 +442,19 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
   const double beta = ch.beta[0];
+  if (b.job_count) {  // job counters and partial sums: cleared before the staging barrier
+    char *raw = reinterpret_cast<char *>(lds);
+    int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
+    if (threadIdx.x < 160) cnt[threadIdx.x] = 0;
+    double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
+    for (int k = threadIdx.x; k < NSPEC * NG * NZ * b.cap; k += blockDim.x) P0[k] = 0.0;
+  }
   stage(sf, beta, b, f, s0, M, geom);
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
-  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out) {
+  // `pacc`: job mode, the sums of this (pair, partner subset) are ADDED to P[channel][item] in LDS
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out, double *pacc = nullptr) {
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -373,6 +470,15 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       for (int ig = 0; ig < NG; ++ig)
 #pragma unroll
         for (int iz = 0; iz < NZ; ++iz) acc[sp][ig][iz] = 0.0;
+    // DEFZ: zeta = {1, 4}: every channel is a polynomial of degree <= 4 in cos(theta),
+    //   (1 + g c) and (1 + g c)^4 = sum_k C(4, k) g^k c^k,
+    // so the lane accumulates the five moments m_k = sum common c^k per partner species (8 operations
+    // per triple instead of 14) and expands them into the channels once, at the end
+    double mom[NSPEC][5];
+#pragma unroll
+    for (int sp = 0; sp < NSPEC; ++sp)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) mom[sp][k] = 0.0;
 
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
@@ -397,28 +503,48 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
         const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ra * f.inv[q];
         const double common = Ha * f.H[q] * hd_value<HD>(sf, ch, beta, u);
         const int sb = f.sp[q];
+        if constexpr (DEFZ) {
+          const double c2 = cth * cth;
+          const double t1 = common * cth, t2 = common * c2, t3 = t1 * c2, t4 = t2 * c2;
 #pragma unroll
-        for (int ig = 0; ig < NG; ++ig) {
-          const double basev = fma(ch.gamma[ig], cth, 1.0);
+          for (int sp = 0; sp < NSPEC; ++sp) {
+            const bool on = NSPEC == 1 || sb == sp;
+            mom[sp][0] += on ? common : 0.0;
+            mom[sp][1] += on ? t1 : 0.0;
+            mom[sp][2] += on ? t2 : 0.0;
+            mom[sp][3] += on ? t3 : 0.0;
+            mom[sp][4] += on ? t4 : 0.0;
+          }
+        } else {
 #pragma unroll
-          for (int iz = 0; iz < NZ; ++iz) {
-            double pw;
-            if constexpr (DEFZ) {
-              const double b2 = basev * basev;
-              pw = (iz == 0) ? basev : b2 * b2;
-            } else {
+          for (int ig = 0; ig < NG; ++ig) {
+            const double basev = fma(ch.gamma[ig], cth, 1.0);
+#pragma unroll
+            for (int iz = 0; iz < NZ; ++iz) {
+              double pw;
               if (ch.zeta_int[iz] > 0)
                 pw = pow_int_m1(basev, ch.zeta_int[iz]) * basev;
               else
                 pw = safe_pow_value(ch.safe_pow, basev, ch.zeta[iz]);
-            }
-            const double v = pw * common;
+              const double v = pw * common;
 #pragma unroll
-            for (int sp = 0; sp < NSPEC; ++sp)
-              acc[sp][ig][iz] += (NSPEC == 1 || sb == sp) ? v : 0.0;
+              for (int sp = 0; sp < NSPEC; ++sp)
+                acc[sp][ig][iz] += (NSPEC == 1 || sb == sp) ? v : 0.0;
+            }
           }
         }
       }
+    }
+    if constexpr (DEFZ) {
+#pragma unroll
+      for (int sp = 0; sp < NSPEC; ++sp)
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double g1 = ch.gamma[ig], g2 = g1 * g1;
+          acc[sp][ig][0] = fma(g1, mom[sp][1], mom[sp][0]);
+          acc[sp][ig][1] = fma(g2 * g2, mom[sp][4], fma(4.0 * g2 * g1, mom[sp][3],
+                               fma(6.0 * g2, mom[sp][2], fma(4.0 * g1, mom[sp][1], mom[sp][0]))));
+        }
     }
 #pragma unroll
     for (int sp = 0; sp < NSPEC; ++sp)
@@ -428,7 +554,9 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
         for (int iz = 0; iz < NZ; ++iz) {
           const int c = ch.chan[ig * NZ + iz];
           const double v = acc[sp][ig][iz] * ch.kz[iz];
-          if (out)
+          if (pacc) {
+            if (v != 0.0) atomicAdd(&pacc[(size_t)((sp * NG + ig) * NZ + iz) * b.cap + item], v);
+          } else if (out)
             out[(sp * NG + ig) * NZ + iz] = v;
           else
             b.part4[(size_t)(sp * sf.n_ang + c) * b.n_pairs + p] = v;
@@ -454,6 +582,39 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       if (smax > 0) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
       if (b.masks) b.masks[p] = mask;
     }
+    if (b.job_count) {
+      // job mode (see make_jobs): build the list once, leave it for the backward kernel, sweep it
+      char *raw = reinterpret_cast<char *>(lds);
+      JobLists jl = job_lists(f, v2_max_jobs(b.cap));
+      jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
+      jl.start = jl.hist + 66;
+      jl.ctl = jl.start + 66;
+      double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
+      const int n_jobs = make_jobs(jl, v2_max_jobs(b.cap), active, item, mask);
+      const size_t jbase = (size_t)blockIdx.x * b.job_stride;
+      if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
+      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x) {
+        b.job_mask[jbase + slot] = jl.mask[slot];
+        b.job_code[jbase + slot] = jl.code[slot];
+      }
+      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x)
+        run_item((int)jl.code[slot], true, jl.mask[slot], nullptr, P);
+      __syncthreads();
+      if (flags & 4) {
+        reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+        reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
+        return;
+      }
+      // several forward launches (one per beta): the sums travel through part4 as before
+      if (active) {
+        const int64_t p = (int64_t)s0 + threadIdx.x;
+#pragma unroll
+        for (int sp = 0; sp < NSPEC; ++sp)
+#pragma unroll
+          for (int gz = 0; gz < NG * NZ; ++gz)
+            b.part4[(size_t)(sp * sf.n_ang + ch.chan[gz]) * b.n_pairs + p] = P[(size_t)(sp * NG * NZ + gz) * b.cap + threadIdx.x];
+      }
+    } else {
     deal_by_popcount(f, b.cap, M, item, mask);
     // flags & 4: this launch holds every angular channel of the model: the descriptors are
     // assembled from LDS, without a round trip through part4. The partial sums of up to 9 local
@@ -485,7 +646,9 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       return;
     }
     if (active) run_item(item, true, mask, nullptr);
+    }
   } else {
+    if (b.job_count && threadIdx.x == 0) b.job_count[blockIdx.x] = -1;  // no list: the backward kernel scans itself
     for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, nullptr);
   }
 
@@ -564,6 +727,27 @@ __global__ __launch_bounds__(kBlock)
         }
     }
 
+    // DEFZ: S0 = sum_c w_c kz (1 + g c)^zeta is a polynomial P(c) of degree 4 in cos(theta) and
+    // S1 = sum_c w_c kz zeta g (1 + g c)^(zeta - 1) its derivative: coefficients once per job, then
+    // 4 + 3 fused multiply-adds per triple instead of 16 operations
+    double pc[NSPEC][5];
+    if constexpr (DEFZ) {
+#pragma unroll
+      for (int sp = 0; sp < NSPEC; ++sp) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) pc[sp][k] = 0.0;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) {
+          const double g1 = ch.gamma[ig], g2 = g1 * g1;
+          const double w1 = w[sp][ig][0], w4 = w[sp][ig][1];
+          pc[sp][0] += w1 + w4;
+          pc[sp][1] += g1 * (w1 + 4.0 * w4);
+          pc[sp][2] += 6.0 * g2 * w4;
+          pc[sp][3] += 4.0 * g2 * g1 * w4;
+          pc[sp][4] += g2 * g2 * w4;
+        }
+      }
+    }
     double gx = 0.0, gy = 0.0, gz = 0.0;
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
@@ -590,27 +774,30 @@ __global__ __launch_bounds__(kBlock)
         const double Hb = f.H[q], Gb = f.G[q];
         const int sb = f.sp[q];
         double S0 = 0.0, S1 = 0.0;
+        if constexpr (DEFZ) {
+          double p0 = pc[0][0], p1 = pc[0][1], p2 = pc[0][2], p3 = pc[0][3], p4 = pc[0][4];
 #pragma unroll
-        for (int ig = 0; ig < NG; ++ig) {
-          const double basev = fma(ch.gamma[ig], cth, 1.0);
+          for (int sp = 1; sp < NSPEC; ++sp) {
+            p0 = (sb == sp) ? pc[sp][0] : p0;
+            p1 = (sb == sp) ? pc[sp][1] : p1;
+            p2 = (sb == sp) ? pc[sp][2] : p2;
+            p3 = (sb == sp) ? pc[sp][3] : p3;
+            p4 = (sb == sp) ? pc[sp][4] : p4;
+          }
+          S0 = fma(fma(fma(fma(p4, cth, p3), cth, p2), cth, p1), cth, p0);
+          S1 = fma(fma(fma(4.0 * p4, cth, 3.0 * p3), cth, 2.0 * p2), cth, p1);
+        } else {
 #pragma unroll
-          for (int iz = 0; iz < NZ; ++iz) {
-            double ws = w[0][ig][iz], wds = wd[0][ig][iz];
+          for (int ig = 0; ig < NG; ++ig) {
+            const double basev = fma(ch.gamma[ig], cth, 1.0);
 #pragma unroll
-            for (int sp = 1; sp < NSPEC; ++sp) {
-              ws = (sb == sp) ? w[sp][ig][iz] : ws;
-              wds = (sb == sp) ? wd[sp][ig][iz] : wds;
-            }
-            if constexpr (DEFZ) {
-              if (iz == 0) {  // zeta = 1: P = base, P' = gamma
-                S0 = fma(ws, basev, S0);
-                S1 += wds;
-              } else {        // zeta = 4: P = base^4, P' = 4 gamma base^3
-                const double b2 = basev * basev;
-                S0 = fma(ws, b2 * b2, S0);
-                S1 = fma(wds, b2 * basev, S1);
+            for (int iz = 0; iz < NZ; ++iz) {
+              double ws = w[0][ig][iz], wds = wd[0][ig][iz];
+#pragma unroll
+              for (int sp = 1; sp < NSPEC; ++sp) {
+                ws = (sb == sp) ? w[sp][ig][iz] : ws;
+                wds = (sb == sp) ? wd[sp][ig][iz] : wds;
               }
-            } else {
               double pm1;
               if (ch.zeta_int[iz] > 0)
                 pm1 = pow_int_m1(basev, ch.zeta_int[iz]);
@@ -648,7 +835,12 @@ __global__ __launch_bounds__(kBlock)
       n_own = b.pair_start[i + 1] - b.pair_start[i];
     }
     const bool one_pass = M <= (int)blockDim.x && !__syncthreads_or(active && (n_own >> 1) > 64);
-    if (one_pass) {  // see deal_by_popcount
+    const int n_jobs = (one_pass && b.job_count) ? b.job_count[blockIdx.x] : -1;
+    if (n_jobs >= 0) {  // the forward kernel's job list (see make_jobs): no scan, no sort here
+      const size_t jbase = (size_t)blockIdx.x * b.job_stride;
+      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x)
+        run_item((int)b.job_code[jbase + slot], true, b.job_mask[jbase + slot]);
+    } else if (one_pass) {  // see deal_by_popcount
       unsigned long long mask = 0ull;
       if (active) {
         const int64_t p = (int64_t)s0 + item;
@@ -704,7 +896,7 @@ __global__ __launch_bounds__(kBlock)
 template <int NSPEC, int NG, int NZ>
 void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geom, hipStream_t s) {
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
-  const size_t lds = v2_lds_bytes(false, b.cap);
+  const size_t lds = v2_lds_bytes(false, b.cap, b.job_count ? NSPEC * NG * NZ : 0);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
       hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true>), grid, block, lds, s, sf, ch, b, geom);
@@ -746,10 +938,13 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 
 }  // namespace
 
-size_t v2_lds_bytes(bool backward, int cap) {
+// n_local > 0: forward launch in job mode (counters + per-pair partial sums behind the fields)
+size_t v2_lds_bytes(bool backward, int cap, int n_local) {
+  if (!backward && n_local > 0) return v2_counter_offset(cap) + 640 + (size_t)n_local * cap * sizeof(double);
   return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
          (backward ? 3 * (size_t)cap * sizeof(double) : 0);
 }
+int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 
 #define TA_DISPATCH_V2(FN, ...)                                   \
   do {                                                            \
