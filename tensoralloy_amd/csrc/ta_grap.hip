@@ -188,11 +188,40 @@ __device__ __forceinline__ void stage_pairs(const GrapParams &g, const DeviceBat
     // that axis: one multiplication per component
     double *M = L.M[t];
     M[0] = one;
-    for (int d = 1; d < g.nd; ++d) {
-      const unsigned long long w = cwl[d];
-      const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7);
-      const int parent = ex ? (int)((w >> 6) & 63) : (ey ? (int)((w >> 12) & 63) : (int)((w >> 18) & 63));
-      M[d] = M[parent] * (ex ? ux : (ey ? uy : uz));
+    if constexpr (MC <= kSmallComp) {  // moments 0..3: straight-line code
+      if (g.nd > 1) {
+        M[1] = ux;
+        M[2] = uy;
+        M[3] = uz;
+      }
+      if (g.nd > 4) {
+        const double xx = ux * ux, xy = ux * uy, xz = ux * uz, yy = uy * uy, yz = uy * uz, zz = uz * uz;
+        M[4] = xx;
+        M[5] = xy;
+        M[6] = xz;
+        M[7] = yy;
+        M[8] = yz;
+        M[9] = zz;
+        if (g.nd > 10) {
+          M[10] = xx * ux;
+          M[11] = xx * uy;
+          M[12] = xx * uz;
+          M[13] = xy * uy;
+          M[14] = xy * uz;
+          M[15] = xz * uz;
+          M[16] = yy * uy;
+          M[17] = yy * uz;
+          M[18] = yz * uz;
+          M[19] = zz * uz;
+        }
+      }
+    } else {
+      for (int d = 1; d < g.nd; ++d) {
+        const unsigned long long w = cwl[d];
+        const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7);
+        const int parent = ex ? (int)((w >> 6) & 63) : (ey ? (int)((w >> 12) & 63) : (int)((w >> 18) & 63));
+        M[d] = M[parent] * (ex ? ux : (ey ? uy : uz));
+      }
     }
   }
 }
@@ -215,6 +244,14 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
   bool d_ok[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) d_ok[t] = 16 * t + m16 < nd;
+  // multiplicities of this lane's components (one load per kernel, not per block and filter tile)
+  constexpr int kMomHere = MC <= kSmallComp ? 4 : kMaxMom;
+  double Tm[NT][kMomHere];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int m = 0; m < kMomHere; ++m)
+      Tm[ct][m] = (d_ok[ct] && m <= g.max_moment) ? g.T[(16 * ct + m16) * kMaxMom + m] : 0.0;
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     const int tb = term_block(sA, sb);
@@ -249,12 +286,6 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
         }
       }
       // accumulator register r of tile ct holds P[k' = 16 kt + q4 + 4 r][d = 16 ct + m16]
-      double Tm[NT][kMaxMom];
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int m = 0; m < kMaxMom; ++m)
-          Tm[ct][m] = (d_ok[ct] && m <= g.max_moment) ? g.T[(16 * ct + m16) * kMaxMom + m] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = kt * 16 + q4 + 4 * r;
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(kWave) void grap_forward_kernel(GrapParams g, Devic
         double feat = 0.0;
         int col = -1;
 #pragma unroll
-        for (int m = 0; m < kMaxMom; ++m) {
+        for (int m = 0; m < kMomHere; ++m) {
           if (m > g.max_moment) break;
           double part = 0.0;
 #pragma unroll
@@ -318,6 +349,8 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   // rows, and the pair's unit vector is read once. The constants of those components (table indices
   // of M_{d - e_c}, exponents) are the component words in LDS.
   for (int d = lane; d < MC; d += kWave) cwl[d] = d < nd ? g.cw[d] : 0ull;
+  __shared__ double Tl[MC * kMaxMom];  // multiplicities (read once per atom and term block below)
+  for (int t = lane; t < nd * kMaxMom; t += kWave) Tl[t] = g.T[t];
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
   for (int t = lane; t < ndim; t += kWave) wrow[t] = b.dEdG[(size_t)i * ndim + t];
   for (int sb = 0; sb < nel; ++sb) {
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
               c = c * sgn / (2.0 * sqrt(P0 * P0 + 1e-16));
             }
           }
-          s = fma(c, g.T[d * kMaxMom + m], s);
+          s = fma(c, Tl[d * kMaxMom + m], s);
         }
         val = 2.0 * P * s + lin;
       }
@@ -402,16 +435,19 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
+            if (16 * ct + 4 * rr >= MC) continue;  // compile time: no such component in this kernel
             const int d = 16 * ct + q4 + 4 * rr;
             if (d >= nd) continue;  // (accumulators of components beyond nd are zero anyway)
+            // (component words from LDS: holding them in registers costs 54 VGPRs and a wave of occupancy)
             const unsigned long long w = cwl[d];
+            const int px = (int)((w >> 6) & 63), py = (int)((w >> 12) & 63), pz = (int)((w >> 18) & 63);
+            const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7), ez = (int)((w >> 30) & 7);
             const double ad = av[ct][rr], bd = bv[ct][rr];
             const double at = ad * inv_r;
-            const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7), ez = (int)((w >> 30) & 7);
             const double rad = (bd - (double)(ex + ey + ez) * at) * M[d];  // multiplies u
-            gx = fma(rad, ux, fma(at * (double)ex, M[(w >> 6) & 63], gx));
-            gy = fma(rad, uy, fma(at * (double)ey, M[(w >> 12) & 63], gy));
-            gz = fma(rad, uz, fma(at * (double)ez, M[(w >> 18) & 63], gz));
+            gx = fma(rad, ux, fma(at * (double)ex, M[px], gx));
+            gy = fma(rad, uy, fma(at * (double)ey, M[py], gy));
+            gz = fma(rad, uz, fma(at * (double)ez, M[pz], gz));
           }
         // components live in the four 16-lane rows: lanes m16, m16 + 16, + 32, + 48
         gx += __shfl_xor(gx, 16);
