@@ -128,6 +128,84 @@ def test_neighbor_list_rejects_bad_input(lib):
         _lib.neighbor_list([0], np.full((1, 3), np.nan), np.eye(3), [1, 1, 1], 1, 3.0)
 
 
+def test_host_neighbor_list_under_address_and_ub_sanitizers(tmp_path):
+    """The threaded host list (csrc/ta_neighbor.cpp) compiled for the CPU with
+    -fsanitize=address,undefined behind a small driver (tests/native/neighbor_sanitize.cpp): the
+    cases of the tests above plus a multi-frame batch (one thread per frame) and the error paths run
+    clean, keep the list's invariants (checked inside the driver) and give the oracle's pairs."""
+    import shutil
+    import subprocess
+    from oracle.neighbors import neighbor_list
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "neighbor_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-pthread", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "tensoralloy_amd", "csrc"),
+           os.path.join(root, "tests", "native", "neighbor_sanitize.cpp"),
+           os.path.join(root, "tensoralloy_amd", "csrc", "ta_neighbor.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert built.returncode == 0, built.stderr[-3000:]
+
+    def run(frames, n_elements, rc):
+        lines = [f"{len(frames)} {n_elements} {rc!r}"]
+        for species, pos, cell, pbc in frames:
+            lines.append(f"{len(pos)} " + " ".join(str(int(bool(x))) for x in pbc) + " " +
+                         " ".join(repr(float(x)) for x in np.asarray(cell, float).ravel()))
+            for sp, r in zip(species, np.asarray(pos, float).reshape(-1, 3)):
+                lines.append(f"{int(sp)} {float(r[0])!r} {float(r[1])!r} {float(r[2])!r}")
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+        env.pop("LD_PRELOAD", None)
+        p = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, (p.stdout[-500:], p.stderr[-3000:])
+        return p.stdout.split()
+
+    def expect(frames, rc):
+        # order-independent checksums of the oracle's list, frames concatenated as the library does
+        P = si = sj = ss = trip = nnl = 0
+        base = 0
+        for species, pos, cell, pbc in frames:
+            i, j, S = neighbor_list(pos, cell, pbc, rc)
+            i, j = i + base, j + base
+            P += len(i)
+            si += int(i.sum())
+            sj += int((j * (i % 7 + 1)).sum())
+            ss += int(((S[:, 0] + 3 * S[:, 1] + 9 * S[:, 2]) * (j % 5 + 1)).sum()) if len(i) else 0
+            cnt = np.bincount(i - base, minlength=len(pos))
+            trip += int((cnt * (cnt - 1) // 2).sum())
+            nnl = max(nnl, int(cnt.max()) if len(pos) else 0)
+            base += len(pos)
+        return P, trip, nnl, si, sj, ss
+
+    rng = np.random.RandomState(0)
+    a = pd3o2()
+    lat = np.array([[2.479787, 0, 0], [-1.239893, 2.147558, 0], [0, 0, 24.294656]])
+    tri = np.array([[8, 0, 0], [2, 7, 0], [1, 1.5, 9.0]])
+    cases = [
+        ([([1, 1, 1, 0, 0], a.positions, np.asarray(a.get_cell()), a.pbc)], 2, 6.5),
+        ([([0] * 6, rng.rand(6, 3) @ lat * 1.3 - 0.5, lat, [1, 1, 1])], 1, 6.0),     # tiny cell, atoms outside
+        ([(rng.randint(0, 3, 40), rng.rand(40, 3) @ tri * 1.2, tri, [1, 0, 1])], 3, 5.0),
+        ([([0] * 28, rng.rand(28, 3) * 8, np.zeros((3, 3)), [0, 0, 0])], 1, 6.0),    # molecule, no cell
+        ([([0], np.zeros((1, 3)), np.eye(3) * 3.0, [1, 1, 1])], 1, 6.5),             # self-images only
+        ([([0], np.zeros((1, 3)), np.eye(3) * 30.0, [1, 1, 1])], 1, 6.5),            # no pairs at all
+    ]
+    many = []
+    for f in range(12):                                                              # threads: frame per thread
+        at = fcc(rep=(2, 2, 2), seed=f, jitter=0.1)
+        many.append(([0] * len(at), at.positions, np.asarray(at.get_cell()), at.pbc))
+    cases.append((many, 1, 6.0))
+    cases.append(([], 1, 6.0))                                                       # empty batch
+    for frames, nel, rc in cases:
+        out = run(frames, nel, rc)
+        assert out[0] == "pairs", out
+        got = tuple(int(out[k]) for k in (1, 3, 5, 7, 9, 11))
+        assert got == expect(frames, rc)
+    # error paths: species out of range, singular periodic cell, NaN coordinate
+    for frames in ([([0, 5], np.zeros((2, 3)), np.eye(3), [1, 1, 1])],
+                   [([0], np.zeros((1, 3)), np.ones((3, 3)), [1, 1, 1])]):
+        assert run(frames, 1, 3.0)[0] == "error"
+
+
 @pytest.mark.parametrize("which", ["pd3o2", "ni"])
 def test_feed_dict_through_dense_layout(lib, which):
     """`get_np_feed_dict` -> dense tensors (the reference's graph inputs) -> G2/G4 applied the way
