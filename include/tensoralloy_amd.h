@@ -318,6 +318,25 @@ int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int
 int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
                      double *grad, int64_t n_grad, double *dG_out);
 
+/* Constants of the analytic functions of an EAM model as trainable parameters. The reference makes
+ * every constant of its empirical potentials a tf.Variable (potentials/potentials.py:129-163;
+ * zjw04.py: shared variables per element) trained under the same loss. Layout of the vector:
+ * element e, constant k -> [20 e + k] in the order of the model description's `eam_el` rows
+ * (Zjw04: r_eq f_eq rho_e rho_s alpha beta A B kappa lamda Fn0..Fn3 F0..F3 eta Fe), then the
+ * Zjw04xcp cross terms [20 nel + 7 pt + q] (r_eq A B alpha beta kappa lamda), pt = sorted pair type.
+ *   ta_constant_count     length of the vector
+ *   ta_get_constants      current values
+ *   ta_update_constants   new values (finite); synchronises the stream first
+ *   ta_constant_gradient  d/dconstants of  sum_f frame_coeff[f] E_f + D_(dR, dh) E  on the resident
+ *                         batch, arguments as ta_loss_gradient. Plain EAM with analytic rho, phi
+ *                         and F only (TA_ERR_INVALID otherwise); forward-mode (dual numbers), one
+ *                         pass over the pairs per constant in a single launch. */
+int ta_constant_count(ta_handle h, int64_t *n_constants);
+int ta_get_constants(ta_handle h, double *constants, int64_t n_constants);
+int ta_update_constants(ta_handle h, const double *constants, int64_t n_constants);
+int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
+                         double *grad, int64_t n_grad);
+
 /* Tables of an EAM / ADP model's functions (analytic, nn or tabulated) on caller-supplied abscissae: what
  * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it
  * writes a LAMMPS setfl file. Rows: elements (sorted) for rho(r) [n_elements][n_r] and F(rho)

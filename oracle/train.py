@@ -145,3 +145,21 @@ def tangent_weight_gradients(model, symbols, G, dG, atom_coeff=None):
             kappa, nu = k_in, n_in
         out[el] = grads
     return out
+
+
+def eam_loss_functional(eam_model, frames, frame_coeff, u, Y):
+    """L = sum_f c_f E_f + sum_f (sum_i u_i . F_i + Y_f : W_f) of an oracle `EamModel` — the part of an
+    energy + forces + stress loss (reference nn/losses.py:204-437) that depends on the model, with
+    c = dL/dE, u = dL/dF, Y = dL/dW held fixed. `frames`: (symbols, positions, cell, pbc)."""
+    from .eam import evaluate
+    total = 0.0
+    for f, (symbols, positions, cell, pbc) in enumerate(frames):
+        r = evaluate(eam_model, symbols, positions, cell, pbc)
+        total += frame_coeff[f] * r["energy"] + float(np.sum(u[f] * r["forces"])) + float(np.sum(Y[f] * r["virial"]))
+    return total
+
+
+def central_difference_6(fn, x, h):
+    """d fn / dx at x with the 7-point stencil (error O(h^6))."""
+    c = (-1.0 / 60.0, 3.0 / 20.0, -3.0 / 4.0, 0.0, 3.0 / 4.0, -3.0 / 20.0, 1.0 / 60.0)
+    return sum(ck * fn(x + (k - 3) * h) for k, ck in enumerate(c) if ck != 0.0) / h

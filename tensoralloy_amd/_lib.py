@@ -42,7 +42,8 @@ EXPORTED_SYMBOLS = [
     "ta_batch_energy_device_ptr", "ta_copy_batch_energy", "ta_get_pairs", "ta_neighbor_list", "ta_free",
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
     "ta_energy_gradient", "ta_measure_hbm_copy", "ta_set_skin", "ta_update_positions", "ta_list_stats",
-    "ta_count_contributing_triples", "ta_loss_gradient",
+    "ta_count_contributing_triples", "ta_loss_gradient", "ta_constant_count", "ta_get_constants", "ta_update_constants",
+    "ta_constant_gradient",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -183,6 +184,10 @@ def load():
     lib.ta_update_weights.argtypes = [H, _dp, C.c_int64]
     lib.ta_energy_gradient.argtypes = [H, _dp, _dp, C.c_int64]
     lib.ta_loss_gradient.argtypes = [H, _dp, _dp, _dp, _dp, C.c_int64, _dp]
+    lib.ta_constant_count.argtypes = [H, C.POINTER(C.c_int64)]
+    lib.ta_get_constants.argtypes = [H, _dp, C.c_int64]
+    lib.ta_update_constants.argtypes = [H, _dp, C.c_int64]
+    lib.ta_constant_gradient.argtypes = [H, _dp, _dp, _dp, _dp, C.c_int64]
     lib.ta_get_pairs.argtypes = [H, _ip, _ip, _ip]
     lib.ta_neighbor_list.argtypes = [C.POINTER(Frame), C.c_int32, C.c_double,
                                      C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_ip),

@@ -61,6 +61,11 @@ void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test 
 bool eam_is_plain(const EamModel *);
 int64_t eam_param_count(const EamModel *);
 void eam_update_weights(EamModel *, const double *flat, int64_t n);
+int64_t eam_constant_count(const EamModel *);
+void eam_get_constants(const EamModel *, double *flat);
+void eam_update_constants(EamModel *, const double *flat, int64_t n);
+void eam_constant_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, const double *dR,
+                           const double *dh, double *grad, hipStream_t s);
 void eam_energy_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, double *grad,
                          hipStream_t s);
 }  // namespace ta
@@ -1593,6 +1598,66 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
     HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
     if (dG_out && N)
       HIP_CHECK(hipMemcpyAsync(dG_out, h->tan_dG.ptr, N * (size_t)D * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
+int ta_constant_count(ta_handle h, int64_t *n_constants) {
+  if (!h || !n_constants) return TA_ERR_INVALID;
+  if (!h->eam) return fail(h, TA_ERR_INVALID, "the model has no empirical potential");
+  *n_constants = ta::eam_constant_count(h->eam);
+  return TA_OK;
+}
+
+int ta_get_constants(ta_handle h, double *constants, int64_t n_constants) {
+  if (!h || !constants) return TA_ERR_INVALID;
+  if (!h->eam) return fail(h, TA_ERR_INVALID, "the model has no empirical potential");
+  if (n_constants != ta::eam_constant_count(h->eam)) return fail(h, TA_ERR_INVALID, "ta_get_constants: wrong length");
+  ta::eam_get_constants(h->eam, constants);
+  return TA_OK;
+}
+
+int ta_update_constants(ta_handle h, const double *constants, int64_t n_constants) {
+  if (!h || !constants) return TA_ERR_INVALID;
+  if (!h->eam) return fail(h, TA_ERR_INVALID, "the model has no empirical potential");
+  return guarded(h, [&]() {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    ta::eam_update_constants(h->eam, constants, n_constants);
+  });
+}
+
+int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh, double *grad,
+                         int64_t n_grad) {
+  if (!h || !grad) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (!h->eam) return fail(h, TA_ERR_INVALID, "the model has no empirical potential");
+  if (!frame_coeff && !dR && !dh) return fail(h, TA_ERR_INVALID, "nothing to differentiate");
+  return guarded(h, [&]() {
+    const int64_t total = ta::eam_constant_count(h->eam);
+    if (n_grad != total)
+      throw std::invalid_argument("ta_constant_gradient: expected room for " + std::to_string(total) + " values");
+    // positions, cells and the list's cutoff test as the inference kernels see them
+    compute_impl(h, TA_WANT_ENERGY, false, nullptr);
+    hipStream_t s = h->stream;
+    const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+    h->train_grad.ensure((size_t)total + 8);
+    h->train_coeff.ensure(F + 8);
+    if (frame_coeff && F)
+      HIP_CHECK(hipMemcpyAsync(h->train_coeff.ptr, frame_coeff, F * sizeof(double), hipMemcpyHostToDevice, s));
+    double *d_dR = nullptr, *d_dh = nullptr;
+    if (dR || dh) {
+      h->tan_dir.ensure(3 * N + 9 * F + 8);
+      d_dR = h->tan_dir.ptr;
+      d_dh = h->tan_dir.ptr + 3 * N;
+      if (dR) HIP_CHECK(hipMemcpyAsync(d_dR, dR, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+      else HIP_CHECK(hipMemsetAsync(d_dR, 0, 3 * N * sizeof(double), s));
+      if (dh) HIP_CHECK(hipMemcpyAsync(d_dh, dh, 9 * F * sizeof(double), hipMemcpyHostToDevice, s));
+      else HIP_CHECK(hipMemsetAsync(d_dh, 0, 9 * F * sizeof(double), s));
+    }
+    ta::eam_constant_gradient(h->eam, h->db, frame_coeff ? h->train_coeff.ptr : nullptr, d_dR, d_dh,
+                              h->train_grad.ptr, s);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
   });
 }

@@ -37,12 +37,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "ta_device.h"
+#include "ta_dual.h"
 #include "ta_math.h"
 #include "ta_mlp_tile.h"
 #include "ta_reduce.h"
@@ -124,94 +126,101 @@ __host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u
   return 2 * nel + (cls - 1) * (nel * (nel + 1) / 2) + pt;
 }
 
+// The analytic functions are templates over the scalar type of the CONSTANTS: double for inference,
+// Dual (ta_dual.h) for the gradient with respect to one seeded constant (eam_const_grad_kernel).
+// `el`: the per-element constants [nel][20], `phx`: the Zjw04xcp cross terms [pair types][7].
+
 // f(r) = a exp(-b (r/re - 1)) / (1 + (r/re - c)^20)   (generic.py:102-117)
-__device__ __forceinline__ void zhou_exp(double r, double a, double b, double c, double re,
-                                         double &f, double &df) {
-  const double x = r / re;
-  const double t = x - c;
-  const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
-  const double t20 = t16 * t4, t19 = t16 * t2 * t;
-  const double den = 1.0 / (1.0 + t20);
-  f = a * ta_exp(-b * (x - 1.0)) * den;
+template <typename T>
+__device__ __forceinline__ void zhou_exp(double r, T a, T b, T c, T re, T &f, T &df) {
+  const T x = r / re;
+  const T t = x - c;
+  const T t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+  const T t20 = t16 * t4, t19 = t16 * t2 * t;
+  const T den = 1.0 / (1.0 + t20);
+  f = a * t_exp(-b * (x - 1.0)) * den;
   df = f * (-b - 20.0 * t19 * den) / re;
 }
 
-__device__ __forceinline__ void zjw_rho(const double *p, double r, double &f, double &df) {
-  zhou_exp(r, p[F_EQ], p[BETA], p[LAMDA], p[R_EQ], f, df);
+template <typename T>
+__device__ __forceinline__ void zjw_rho(const T *p, double r, T &f, T &df) {
+  zhou_exp<T>(r, p[F_EQ], p[BETA], p[LAMDA], p[R_EQ], f, df);
 }
-__device__ __forceinline__ void zjw_phi_aa(const double *p, double r, double &f, double &df) {
-  double fa, dfa, fb, dfb;
-  zhou_exp(r, p[PA], p[ALPHA], p[KAPPA], p[R_EQ], fa, dfa);
-  zhou_exp(r, p[PB], p[BETA], p[LAMDA], p[R_EQ], fb, dfb);
+template <typename T>
+__device__ __forceinline__ void zjw_phi_aa(const T *p, double r, T &f, T &df) {
+  T fa, dfa, fb, dfb;
+  zhou_exp<T>(r, p[PA], p[ALPHA], p[KAPPA], p[R_EQ], fa, dfa);
+  zhou_exp<T>(r, p[PB], p[BETA], p[LAMDA], p[R_EQ], fb, dfb);
   f = fa - fb;
   df = dfa - dfb;
 }
 // phi_AB = 0.5 (rho_A/rho_B phi_BB + rho_B/rho_A phi_AA)   (zjw04.py:229-243)
-__device__ __forceinline__ void zjw_phi(const EamParams &P, int sa, int sb, double r, double &f,
-                                        double &df) {
+template <typename T>
+__device__ __forceinline__ void zjw_phi(const EamParams &P, const T (*el)[20], const T (*phx)[7], int sa, int sb,
+                                        double r, T &f, T &df) {
   if (sa == sb) {
-    zjw_phi_aa(P.el[sa], r, f, df);
+    zjw_phi_aa<T>(el[sa], r, f, df);
     return;
   }
   const int pt = pair_type(sa, sb, P.nel);
   if (P.phi_kind[pt] == 1) {  // zjw04.py:689-693
-    const double *q = P.phi[pt];
-    double fa, dfa, fb, dfb;
-    zhou_exp(r, q[1], q[3], q[5], q[0], fa, dfa);
-    zhou_exp(r, q[2], q[4], q[6], q[0], fb, dfb);
+    const T *q = phx[pt];
+    T fa, dfa, fb, dfb;
+    zhou_exp<T>(r, q[1], q[3], q[5], q[0], fa, dfa);
+    zhou_exp<T>(r, q[2], q[4], q[6], q[0], fb, dfb);
     f = fa - fb;
     df = dfa - dfb;
     return;
   }
-  double pha, dpha, phb, dphb, ra, dra, rb, drb;
-  zjw_phi_aa(P.el[sa], r, pha, dpha);
-  zjw_phi_aa(P.el[sb], r, phb, dphb);
-  zjw_rho(P.el[sa], r, ra, dra);
-  zjw_rho(P.el[sb], r, rb, drb);
-  const double q1 = ra / rb, q2 = rb / ra;
-  const double dq1 = (dra * rb - ra * drb) / (rb * rb);
-  const double dq2 = (drb * ra - rb * dra) / (ra * ra);
+  T pha, dpha, phb, dphb, ra, dra, rb, drb;
+  zjw_phi_aa<T>(el[sa], r, pha, dpha);
+  zjw_phi_aa<T>(el[sb], r, phb, dphb);
+  zjw_rho<T>(el[sa], r, ra, dra);
+  zjw_rho<T>(el[sb], r, rb, drb);
+  const T q1 = ra / rb, q2 = rb / ra;
+  const T dq1 = (dra * rb - ra * drb) / (rb * rb);
+  const T dq2 = (drb * ra - rb * dra) / (ra * ra);
   f = 0.5 * (q1 * phb + q2 * pha);
   df = 0.5 * (dq1 * phb + q1 * dphb + dq2 * pha + q2 * dpha);
 }
 
 // piecewise embedding energy, thresholds 0.85 rho_e and 1.15 rho_e (zjw04.py:319-386)
-__device__ __forceinline__ void zjw_embed(const double *p, int kind, double rho, double &F,
-                                          double &dF) {
-  const double rho_n = 0.85 * p[RHO_E], rho_0 = 1.15 * p[RHO_E];
+template <typename T>
+__device__ __forceinline__ void zjw_embed(const T *p, int kind, T rho, T &F, T &dF) {
+  const T rho_n = 0.85 * p[RHO_E], rho_0 = 1.15 * p[RHO_E];
   if (kind == 1) {
     // Zjw04xc: the three branches blended by sigmoids of width 1/2 (zjw04.py:482-543)
-    const double x1 = rho / rho_n - 1.0;
-    const double y1 = p[FN0] + x1 * (p[FN1] + x1 * (p[FN2] + x1 * p[FN3]));
-    const double d1 = (p[FN1] + x1 * (2.0 * p[FN2] + 3.0 * p[FN3] * x1)) / rho_n;
-    const double x2 = rho / p[RHO_E] - 1.0;
-    const double y2 = p[F0] + x2 * (p[F1] + x2 * (p[F2] + x2 * p[F3]));
-    const double d2 = (p[F1] + x2 * (2.0 * p[F2] + 3.0 * p[F3] * x2)) / p[RHO_E];
-    const double x3 = rho / p[RHO_S] + 1e-8;
-    const double lnx = log(x3);
-    const double xe = pow(x3, p[ETA]);
-    const double y3 = p[FE] * (1.0 - p[ETA] * lnx) * xe;
-    const double d3 = -p[FE] * p[ETA] * p[ETA] * lnx * xe / x3 / p[RHO_S];
-    const double c1 = 1.0 / (1.0 + ta_exp(-2.0 * (rho_n - rho)));
-    const double c3 = 1.0 / (1.0 + ta_exp(-2.0 * (rho - rho_0)));
-    const double c2 = 1.0 - (c1 + c3);
-    const double dc1 = -2.0 * c1 * (1.0 - c1), dc3 = 2.0 * c3 * (1.0 - c3);
+    const T x1 = rho / rho_n - 1.0;
+    const T y1 = p[FN0] + x1 * (p[FN1] + x1 * (p[FN2] + x1 * p[FN3]));
+    const T d1 = (p[FN1] + x1 * (2.0 * p[FN2] + 3.0 * p[FN3] * x1)) / rho_n;
+    const T x2 = rho / p[RHO_E] - 1.0;
+    const T y2 = p[F0] + x2 * (p[F1] + x2 * (p[F2] + x2 * p[F3]));
+    const T d2 = (p[F1] + x2 * (2.0 * p[F2] + 3.0 * p[F3] * x2)) / p[RHO_E];
+    const T x3 = rho / p[RHO_S] + 1e-8;
+    const T lnx = t_log(x3);
+    const T xe = t_pow(x3, p[ETA]);
+    const T y3 = p[FE] * (1.0 - p[ETA] * lnx) * xe;
+    const T d3 = -p[FE] * p[ETA] * p[ETA] * lnx * xe / x3 / p[RHO_S];
+    const T c1 = 1.0 / (1.0 + t_exp(-2.0 * (rho_n - rho)));
+    const T c3 = 1.0 / (1.0 + t_exp(-2.0 * (rho - rho_0)));
+    const T c2 = 1.0 - (c1 + c3);
+    const T dc1 = -2.0 * c1 * (1.0 - c1), dc3 = 2.0 * c3 * (1.0 - c3);
     F = c1 * y1 + c2 * y2 + c3 * y3;
     dF = c1 * d1 + c2 * d2 + c3 * d3 + dc1 * y1 - (dc1 + dc3) * y2 + dc3 * y3;
     return;
   }
-  if (rho < rho_n) {
-    const double x = rho / rho_n - 1.0;
+  if (t_val(rho) < t_val(rho_n)) {
+    const T x = rho / rho_n - 1.0;
     F = p[FN0] + x * (p[FN1] + x * (p[FN2] + x * p[FN3]));
     dF = (p[FN1] + x * (2.0 * p[FN2] + 3.0 * p[FN3] * x)) / rho_n;
-  } else if (rho < rho_0) {
-    const double x = rho / p[RHO_E] - 1.0;
+  } else if (t_val(rho) < t_val(rho_0)) {
+    const T x = rho / p[RHO_E] - 1.0;
     F = p[F0] + x * (p[F1] + x * (p[F2] + x * p[F3]));
     dF = (p[F1] + x * (2.0 * p[F2] + 3.0 * p[F3] * x)) / p[RHO_E];
   } else {
-    const double x = rho / p[RHO_S];
-    const double lnx = log(x);
-    const double xe = pow(x, p[ETA]);
+    const T x = rho / p[RHO_S];
+    const T lnx = t_log(x);
+    const T xe = t_pow(x, p[ETA]);
     F = p[FE] * (1.0 - p[ETA] * lnx) * xe;
     dF = -p[FE] * p[ETA] * p[ETA] * lnx * xe / x / p[RHO_S];
   }
@@ -229,27 +238,28 @@ __device__ __forceinline__ void zjw_embed(const double *p, int kind, double rho,
 enum { AG_A = 0, AG_B, AG_D, AG_ALPHA, AG_RE, AG_F0, AG_F1, AG_BETA, AG_GAMMA, AG_M, AG_RC };
 enum { GR_G = 0, GR_N, GR_A, GR_RHO, GR_C, GR_D, GR_GAMMA, GR_R0 };
 
-__device__ __forceinline__ void morse_fn(double r, double d, double g, double r0, double &f, double &df) {
-  const double e1 = exp(-g * (r - r0)), e2 = e1 * e1;
+template <typename T, typename R>
+__device__ __forceinline__ void morse_fn(R r, T d, T g, T r0, T &f, T &df) {
+  const T e1 = t_exp_libm(-g * (r - r0)), e2 = e1 * e1;
   f = d * (e2 - 2.0 * e1);
   df = 2.0 * d * g * (e1 - e2);
 }
 
 // OTHER = false: every analytic function of the model is of the Zjw04 family (the kind tests and the
 // pow calls of the other potentials stay out of the kernels: -9 % on the plain Zjw04 path otherwise)
-template <bool OTHER>
-__device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, double &f, double &df) {
-  const double *p = P.el[e];
+template <bool OTHER, typename T>
+__device__ __forceinline__ void el_rho(const EamParams &P, const T (*el)[20], int e, double r, T &f, T &df) {
+  const T *p = el[e];
   if (!OTHER) {
-    zjw_rho(p, r, f, df);
+    zjw_rho<T>(p, r, f, df);
   } else if (P.el_kind[e] == 1) {
-    const double t = p[0] / r, t2 = t * t;
+    const T t = p[0] / r, t2 = t * t;
     f = t2 * t2 * t2;
     df = -6.0 * f / r;
   } else if (P.el_kind[e] == 2) {
-    const double ev = p[AG_A] * exp(-p[AG_B] * (r - p[AG_RE]));
-    const double ec = p[AG_A] * exp(-p[AG_B] * (p[AG_RC] - p[AG_RE]));
-    const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
+    const T ev = p[AG_A] * t_exp_libm(-p[AG_B] * (r - p[AG_RE]));
+    const T ec = p[AG_A] * t_exp_libm(-p[AG_B] * (p[AG_RC] - p[AG_RE]));
+    const T x = r / p[AG_RC], xm1 = t_pow(x, p[AG_M] - 1.0);
     f = ev - ec - p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * p[AG_B] * ec;
     df = -p[AG_B] * ev + xm1 * p[AG_B] * ec;
   } else if (P.el_kind[e] == 3) {
@@ -257,63 +267,64 @@ __device__ __forceinline__ void el_rho(const EamParams &P, int e, double r, doub
     const double t = 20.0 * (r - 1.5);
     const double sw = 0.5 + 0.5 * erf(t);
     const double dsw = 20.0 * 0.56418958354775628 * exp(-t * t);  // 10 * 2 / sqrt(pi) * e^{-t^2}
-    f = p[GR_N] * i8 * sw;
-    df = p[GR_N] * i8 * (dsw - 8.0 * sw / r);
+    f = p[GR_N] * (i8 * sw);
+    df = p[GR_N] * (i8 * (dsw - 8.0 * sw / r));
   } else {
-    zjw_rho(p, r, f, df);
+    zjw_rho<T>(p, r, f, df);
   }
 }
 
-template <bool OTHER>
-__device__ __forceinline__ void pair_phi(const EamParams &P, int sa, int sb, double r, double &f, double &df) {
+template <bool OTHER, typename T>
+__device__ __forceinline__ void pair_phi(const EamParams &P, const T (*el)[20], const T (*phx)[7], int sa, int sb,
+                                         double r, T &f, T &df) {
   const int kind = (OTHER && sa == sb) ? P.el_kind[sa] : 0;
   if (!OTHER) {
-    zjw_phi(P, sa, sb, r, f, df);
+    zjw_phi<T>(P, el, phx, sa, sb, r, f, df);
   } else if (kind == 1) {
-    const double t = P.el[sa][1] / r, t2 = t * t, t4 = t2 * t2;
+    const T t = el[sa][1] / r, t2 = t * t, t4 = t2 * t2;
     f = t4 * t4 * t4;
     df = -12.0 * f / r;
   } else if (kind == 2) {
-    const double *p = P.el[sa];
-    double m0, dm0, mc, dmc;
-    morse_fn(r, p[AG_D], p[AG_ALPHA], p[AG_RE], m0, dm0);
-    morse_fn(p[AG_RC], p[AG_D], p[AG_ALPHA], p[AG_RE], mc, dmc);
-    const double x = r / p[AG_RC], xm1 = pow(x, p[AG_M] - 1.0);
+    const T *p = el[sa];
+    T m0, dm0, mc, dmc;
+    morse_fn<T, double>(r, p[AG_D], p[AG_ALPHA], p[AG_RE], m0, dm0);
+    morse_fn<T, T>(p[AG_RC], p[AG_D], p[AG_ALPHA], p[AG_RE], mc, dmc);
+    const T x = r / p[AG_RC], xm1 = t_pow(x, p[AG_M] - 1.0);
     f = m0 - mc + p[AG_RC] / p[AG_M] * (1.0 - xm1 * x) * dmc;
     df = dm0 - xm1 * dmc;
   } else if (kind == 3) {
-    const double *p = P.el[sa];
-    double m0, dm0;
-    morse_fn(r, p[GR_D], p[GR_GAMMA], p[GR_R0], m0, dm0);
-    const double eb = p[GR_A] * exp(-r / p[GR_RHO]);
+    const T *p = el[sa];
+    T m0, dm0;
+    morse_fn<T, double>(r, p[GR_D], p[GR_GAMMA], p[GR_R0], m0, dm0);
+    const T eb = p[GR_A] * t_exp_libm(-r / p[GR_RHO]);
     const double i2 = 1.0 / (r * r), i6 = i2 * i2 * i2;
     f = m0 + eb - p[GR_C] * i6;
-    df = dm0 - eb / p[GR_RHO] + 6.0 * p[GR_C] * i6 / r;
+    df = dm0 - eb / p[GR_RHO] + 6.0 * p[GR_C] * (i6 / r);
   } else {
-    zjw_phi(P, sa, sb, r, f, df);
+    zjw_phi<T>(P, el, phx, sa, sb, r, f, df);
   }
 }
 
-template <bool OTHER>
-__device__ __forceinline__ void el_embed(const EamParams &P, int e, double rho, double &F, double &dF) {
-  const double *p = P.el[e];
+template <bool OTHER, typename T>
+__device__ __forceinline__ void el_embed(const EamParams &P, const T (*el)[20], int e, T rho, T &F, T &dF) {
+  const T *p = el[e];
   if (!OTHER) {
-    zjw_embed(p, P.embed_kind[e], rho, F, dF);
+    zjw_embed<T>(p, P.embed_kind[e], rho, F, dF);
   } else if (P.el_kind[e] == 1) {
-    const double s = sqrt(rho);
+    const T s = t_sqrt(rho);
     F = -s;
     dF = -0.5 / s;
   } else if (P.el_kind[e] == 2) {
-    const double L = log(fmax(rho, 1e-12));
-    const double xb = pow(rho, p[AG_BETA] - 1.0), yg = pow(rho, p[AG_GAMMA] - 1.0);
+    const T L = t_log(t_floor_at(rho, 1e-12));
+    const T xb = t_pow(rho, p[AG_BETA] - 1.0), yg = t_pow(rho, p[AG_GAMMA] - 1.0);
     F = p[AG_F0] * (1.0 - p[AG_BETA] * L) * xb * rho + p[AG_F1] * yg * rho;
     dF = -p[AG_F0] * p[AG_BETA] * p[AG_BETA] * L * xb + p[AG_F1] * p[AG_GAMMA] * yg;
   } else if (P.el_kind[e] == 3) {
-    const double s = sqrt(rho);
+    const T s = t_sqrt(rho);
     F = -p[GR_G] * s;
     dF = -0.5 * p[GR_G] / s;
   } else {
-    zjw_embed(p, P.embed_kind[e], rho, F, dF);
+    zjw_embed<T>(p, P.embed_kind[e], rho, F, dF);
   }
 }
 
@@ -399,11 +410,11 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // density function of the NEIGHBOUR's element (alloy.py:176)
       if (rho_nn) f = pf[PF_RHO * ps + q];
       else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
-      else el_rho<OTHER>(P, sb, r, f, df);
+      else el_rho<OTHER, double>(P, P.el, sb, r, f, df);
       rho += f;
       if (phi_nn) f = pf[PF_PHI * ps + q];
       else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, df);
-      else pair_phi<OTHER>(P, sA, sb, r, f, df);
+      else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, f, df);
       phis += f;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     } else {
       double F, d;
       if ((P.tab_embed >> sA) & 1u) spline_eval(tabs[slot_embed(nel, sA)], rho, F, d);
-      else el_embed<OTHER>(P, sA, rho, F, d);
+      else el_embed<OTHER, double>(P, P.el, sA, rho, F, d);
       b.eatom[i] = F + 0.5 * phis + eadp;  // eam.py:353-355, :568
       dF[i] = d;
     }
@@ -756,10 +767,10 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
   const int pt = pair_type(sA, sa, nel);
   if ((P.nn_rho >> sa) & 1u) drho = pf[PF_DRHO * ps + p];
   else if ((P.tab_rho >> sa) & 1u) spline_eval(tabs[slot_rho(sa)], r, f, drho);
-  else el_rho<OTHER>(P, sa, r, f, drho);
+  else el_rho<OTHER, double>(P, P.el, sa, r, f, drho);
   if ((P.nn_phi >> pt) & 1u) dphi = pf[PF_DPHI * ps + p];
   else if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, dphi);
-  else pair_phi<OTHER>(P, sA, sa, r, f, dphi);
+  else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sa, r, f, dphi);
   // dE/dD of the directed pair: the centre's terms only; the reverse pair carries the other half
   double c = (dF[i] * drho + 0.5 * dphi) * inv_r;
   double gx = c * dx, gy = c * dy, gz = c * dz;
@@ -829,12 +840,12 @@ __global__ __launch_bounds__(1024) void eam_force_kernel(EamParams P, DeviceBatc
         const double r = sqrt(v1.y);
         double fn, drhoB, drhoA, dphi;
         if (rhoB_tab) spline_eval(tabs[slot_rho(sb)], r, fn, drhoB);
-        else el_rho<OTHER>(P, sb, r, fn, drhoB);
+        else el_rho<OTHER, double>(P, P.el, sb, r, fn, drhoB);
         if (sb == sA) drhoA = drhoB;
         else if (rhoA_tab) spline_eval(tabs[slot_rho(sA)], r, fn, drhoA);
-        else el_rho<OTHER>(P, sA, r, fn, drhoA);
+        else el_rho<OTHER, double>(P, P.el, sA, r, fn, drhoA);
         if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
-        else pair_phi<OTHER>(P, sA, sb, r, fn, dphi);
+        else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, fn, dphi);
         const double inv_r = 1.0 / r;
         const double own = (dFi * drhoB + 0.5 * dphi) * inv_r;   // g[p] = own D
         const double both = own + (dFj * drhoA + 0.5 * dphi) * inv_r;  // g[p] - g[rev p] = both D
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     double f, df;
     if (row < nel) {
       if ((P.tab_rho >> row) & 1u) spline_eval(tabs[slot_rho(row)], x, f, df);
-      else el_rho<true>(P, row, x, f, df);
+      else el_rho<true, double>(P, P.el, row, x, f, df);
       rho_of_r[(size_t)row * n_r + k] = f;
     } else {
       const int pt = row - nel;
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
       }
       const int b2 = a + rem;
       if ((P.tab_phi >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 1, pt)], x, f, df);
-      else pair_phi<true>(P, a, b2, x, f, df);
+      else pair_phi<true, double>(P, P.el, P.phi, a, b2, x, f, df);
       phi_of_r[(size_t)pt * n_r + k] = f;
       if (P.adp && u_of_r && w_of_r) {
         const double *pp = P.pair[pt];
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
     const int row = (int)(j / n_rho), k = (int)(j % n_rho);
     double F, dF;
     if ((P.tab_embed >> row) & 1u) spline_eval(tabs[slot_embed(nel, row)], rho[k], F, dF);
-    else el_embed<true>(P, row, rho[k], F, dF);
+    else el_embed<true, double>(P, P.el, row, rho[k], F, dF);
     embed_of_rho[(size_t)row * n_rho + k] = F;
   }
 }
@@ -1398,6 +1409,157 @@ void eam_energy_gradient(EamModel *m, const DeviceBatch &b, const double *frame_
     launch_mlp_grad_rows(net, m->activation, nullptr, n_pairs, rbuf, m->gcoeff, nullptr, nullptr, m->gscratch,
                          m->gpartial, g, s);
   }
+}
+
+namespace {
+// ---- gradients with respect to the constants of the analytic functions ---------------------------
+// The reference trains the constants of its empirical potentials as `tf.Variable`s
+// (potentials/potentials.py:129-163, zjw04.py: every constant a shared variable) under the same
+// energy + forces + stress loss (nn/losses.py:204-437). With the loss written as
+//   L = sum_f c_f E_f + D_(dR, dh) E
+// (train.py: the force and stress terms are the directional derivative of the energy along
+// dR = R.Y - u, dh = h.Y), the derivative with respect to ONE constant is the dual part of
+//   sum_i  c_f(i) [F(rho_i) + 1/2 sum_j phi(r_ij)] + F'(rho_i) rhodot_i + 1/2 sum_j phi'(r_ij) rdot_ij,
+//   rho_i = sum_j rho_{s_j}(r_ij),  rhodot_i = sum_j rho'_{s_j}(r_ij) rdot_ij,  rdot = D . dD / r,
+// evaluated in dual arithmetic with that constant seeded: F' of a dual rho_i brings F'' along.
+// One wavefront per atom; blockIdx.y = the seeded constant: e * 20 + k for element e (ZJW04_KEYS
+// order), then 20 nel + pt * 7 + q for the Zjw04xcp cross terms.
+template <bool OTHER>
+__global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, DeviceBatch b,
+                                                                const double *__restrict__ frame_coeff,
+                                                                const double *__restrict__ dR,
+                                                                const double *__restrict__ dh, double eps,
+                                                                double *partial) {
+  __shared__ Dual el[kMaxEamElements][20];
+  __shared__ Dual phx[kMaxPairTypes][7];
+  __shared__ double wpart[kBlock / 64];
+  const int seeded = blockIdx.y;
+  const int nel = P.nel, npt = nel * (nel + 1) / 2;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock)
+    el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20], t == seeded ? 1.0 : 0.0);
+  for (int t = threadIdx.x; t < npt * 7; t += kBlock)
+    phx[t / 7][t % 7] = make_dual(P.phi[t / 7][t % 7], 20 * nel + t == seeded ? 1.0 : 0.0);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double contrib = 0.0;
+  if (i < b.n_atoms) {
+    const int sA = b.species[i];
+    const int fr = b.frame_of_atom[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    const double *h = b.cells + 9 * (size_t)fr;
+    const double *ri = b.pos + 3 * (size_t)i;
+    Dual rho = make_dual(0.0), rhodot = make_dual(0.0), phis = make_dual(0.0), phidot = make_dual(0.0);
+    for (int sb = 0; sb < nel; ++sb)
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+        const int j = b.pair_j[q];
+        const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
+                     sz = (double)b.pair_shift[3 * (size_t)q + 2];
+        const double *rj = b.pos + 3 * (size_t)j;
+        const double dx = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+        const double dy = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+        const double dz = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+        const double r2 = dx * dx + dy * dy + dz * dz + eps;
+        if (P.list_rc2 > 0.0 && !(r2 < P.list_rc2)) continue;
+        const double r = sqrt(r2);
+        double rdot = 0.0;
+        if (dR) {
+          const double *g = dh + 9 * (size_t)fr;
+          const double *ui = dR + 3 * (size_t)i, *uj = dR + 3 * (size_t)j;
+          const double tx = (uj[0] - ui[0]) + (sx * g[0] + sy * g[3] + sz * g[6]);
+          const double ty = (uj[1] - ui[1]) + (sx * g[1] + sy * g[4] + sz * g[7]);
+          const double tz = (uj[2] - ui[2]) + (sx * g[2] + sy * g[5] + sz * g[8]);
+          rdot = (dx * tx + dy * ty + dz * tz) / r;
+        }
+        Dual f, df;
+        el_rho<OTHER, Dual>(P, el, sb, r, f, df);  // density function of the NEIGHBOUR's element
+        rho += f;
+        rhodot += df * rdot;
+        pair_phi<OTHER, Dual>(P, el, phx, sA, sb, r, f, df);
+        phis += f;
+        phidot += df * rdot;
+      }
+    rho = make_dual(wave_sum(rho.v), wave_sum(rho.d));
+    rhodot = make_dual(wave_sum(rhodot.v), wave_sum(rhodot.d));
+    phis = make_dual(wave_sum(phis.v), wave_sum(phis.d));
+    phidot = make_dual(wave_sum(phidot.v), wave_sum(phidot.d));
+    if (lane == 0) {
+      Dual F, dFd;
+      el_embed<OTHER, Dual>(P, el, sA, rho, F, dFd);
+      const double c = frame_coeff ? frame_coeff[fr] : 0.0;
+      const Dual L = c * (F + 0.5 * phis) + dFd * rhodot + 0.5 * phidot;
+      contrib = L.d;
+    }
+  }
+  if (lane == 0) wpart[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) v += wpart[w];
+    partial[(size_t)seeded * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+// grad[q] = sum over the blocks, in a fixed order (one wavefront per constant)
+__global__ __launch_bounds__(64) void eam_const_reduce_kernel(const double *partial, int n_blocks, double *grad) {
+  const int q = blockIdx.x;
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n_blocks; k += 64) v += partial[(size_t)q * n_blocks + k];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) grad[q] = v;
+}
+
+}  // namespace
+
+int64_t eam_constant_count(const EamModel *m) {
+  const int nel = m->p.nel;
+  return 20 * (int64_t)nel + 7 * (int64_t)(nel * (nel + 1) / 2);
+}
+
+void eam_get_constants(const EamModel *m, double *flat) {
+  const int nel = m->p.nel, npt = nel * (nel + 1) / 2;
+  for (int t = 0; t < nel * 20; ++t) flat[t] = m->p.el[t / 20][t % 20];
+  // pair types under the Zjw04 mixing rule have no constants of their own: reported as zeros
+  for (int t = 0; t < npt * 7; ++t) flat[20 * nel + t] = m->p.phi_kind[t / 7] == 1 ? m->p.phi[t / 7][t % 7] : 0.0;
+}
+
+// the constants travel to the kernels by value (EamParams is a kernel argument): no device copy
+void eam_update_constants(EamModel *m, const double *flat, int64_t n) {
+  if (n != eam_constant_count(m)) throw std::invalid_argument("ta_update_constants: wrong number of values");
+  const int nel = m->p.nel, npt = nel * (nel + 1) / 2;
+  for (int64_t t = 0; t < n; ++t)
+    if (!std::isfinite(flat[t])) throw std::invalid_argument("ta_update_constants: non-finite value");
+  for (int t = 0; t < nel * 20; ++t) m->p.el[t / 20][t % 20] = flat[t];
+  for (int t = 0; t < npt * 7; ++t)
+    if (m->p.phi_kind[t / 7] == 1) m->p.phi[t / 7][t % 7] = flat[20 * nel + t];
+}
+
+// grad (device, eam_constant_count values); frame_coeff / dR / dh are device pointers (dR and dh both
+// or neither). Plain EAM with analytic functions only.
+void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *frame_coeff, const double *dR,
+                           const double *dh, double *grad, hipStream_t s) {
+  const EamParams &P = m->p;
+  if (P.adp || m->pair_nets || m->embed_nets || P.nn_rho || P.nn_embed || P.nn_phi || P.tab_rho || P.tab_embed ||
+      P.tab_phi)
+    throw std::invalid_argument(
+        "ta_constant_gradient: for EAM models whose rho, phi and F are all analytic (no nn or tabulated "
+        "function, no ADP terms)");
+  const int64_t nq = eam_constant_count(m);
+  if (b.n_atoms == 0) {
+    (void)hipMemsetAsync(grad, 0, (size_t)nq * sizeof(double), s);
+    return;
+  }
+  const unsigned blocks = (unsigned)((b.n_atoms + kBlock / 64 - 1) / (kBlock / 64));
+  grow(m->gpartial, m->cap_gpartial, (size_t)nq * blocks + 8);
+  bool other = false;
+  for (int e = 0; e < P.nel; ++e) other = other || P.el_kind[e] != 0;
+  if (other)
+    hipLaunchKernelGGL(eam_const_grad_kernel<true>, dim3(blocks, (unsigned)nq), dim3(kBlock), 0, s, P, b,
+                       frame_coeff, dR, dh, m->eps, m->gpartial);
+  else
+    hipLaunchKernelGGL(eam_const_grad_kernel<false>, dim3(blocks, (unsigned)nq), dim3(kBlock), 0, s, P, b,
+                       frame_coeff, dR, dh, m->eps, m->gpartial);
+  hipLaunchKernelGGL(eam_const_reduce_kernel, dim3((unsigned)nq), dim3(64), 0, s, m->gpartial, (int)blocks, grad);
 }
 
 void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {

@@ -447,6 +447,62 @@ class EamAlloyNN:
                     out.extend(p[k] for k in PHI_KEYS)
         return np.array(out, dtype=np.float64)
 
+    # -- the constants as trainable parameters (reference potentials/potentials.py:129-163) ------
+    def constant_names(self):
+        """(section, key) of every slot of the C ABI's constants vector (`ta_get_constants`:
+        20 per element, then 7 per sorted pair type); None where the slot is unused."""
+        names = []
+        for el in self._elements:
+            kind = self._el_kind[el]
+            keys = ZJW04_KEYS if kind == "zjw" else _OTHER_TABLES[kind][1]
+            names.extend([(el, k) for k in keys] + [None] * (20 - len(keys)))
+        n = len(self._elements)
+        for i in range(n):
+            for j in range(i, n):
+                a, b = self._elements[i], self._elements[j]
+                if self.phi_parameters(a, b) is None:
+                    names.extend([None] * 7)
+                else:
+                    names.extend([("".join(sorted([a, b])), k) for k in PHI_KEYS])
+        return names
+
+    def constants(self) -> np.ndarray:
+        out = []
+        for name in self.constant_names():
+            if name is None:
+                out.append(0.0)
+                continue
+            sec, key = name
+            if sec in self._elements:
+                kind = self._el_kind[sec]
+                p = self.element_parameters(sec) if kind == "zjw" else self.other_parameters(sec)
+            else:
+                a, b = get_elements_from_kbody_term(sec)
+                p = self.phi_parameters(a, b)
+            out.append(float(p[key]))
+        return np.array(out, dtype=np.float64)
+
+    def set_constants(self, flat):
+        """Take trained values back into the model (they are written by `export`)."""
+        flat = np.asarray(flat, dtype=np.float64).ravel()
+        names = self.constant_names()
+        if len(flat) != len(names):
+            raise ValueError(f"expected {len(names)} constants")
+        for name, v in zip(names, flat):
+            if name is None:
+                continue
+            sec, key = name
+            self._parameters.setdefault(sec, {})[key] = float(v)
+            if sec in self._elements and key in self._parameters.get(sec + sec, {}):
+                self._parameters[sec + sec][key] = float(v)   # `other_parameters` reads 'AA' last
+
+    def constant_mask(self, fixed=None) -> np.ndarray:
+        """1 for trainable slots. `fixed`: {section: [names]} as the reference's potentials take it
+        (`_is_trainable`, potentials.py:119-127); unused slots are never trained."""
+        fixed = fixed or {}
+        return np.array([0.0 if (n is None or n[1] in fixed.get(n[0], ())) else 1.0
+                         for n in self.constant_names()])
+
     def to_desc(self):
         clf = self._transformer
         if clf is None:

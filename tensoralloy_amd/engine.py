@@ -281,6 +281,41 @@ class Engine:
             return grad, (tangent * scale() if scale is not None else tangent)
         return grad
 
+    # -- constants of the analytic EAM functions as parameters (potentials.py:129-163) ---------
+    def constant_count(self) -> int:
+        n = C.c_int64(0)
+        self._check(self._lib.ta_constant_count(self._handle, C.byref(n)))
+        return int(n.value)
+
+    def constants(self) -> np.ndarray:
+        """Flat vector: 20 per element (the model's `eam_el` rows), then 7 per sorted pair type
+        (Zjw04xcp cross terms)."""
+        out = np.zeros(self.constant_count())
+        self._check(self._lib.ta_get_constants(self._handle, _lib.as_dp(out), len(out)))
+        return out
+
+    def update_constants(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float64).ravel()
+        self._check(self._lib.ta_update_constants(self._handle, _lib.as_dp(flat), len(flat)))
+
+    def constant_gradient(self, frame_coeff=None, dR=None, dh=None) -> np.ndarray:
+        """d/dconstants (sum_f frame_coeff[f] E_f + D_delta E) for the resident batch
+        (`ta_constant_gradient`), arguments as `loss_gradient`."""
+        null = C.POINTER(C.c_double)()
+        N, F = int(self.info.n_atoms), int(self.info.n_frames)
+
+        def arr(a, shape):
+            if a is None:
+                return None, null
+            a = np.ascontiguousarray(a, dtype=np.float64).reshape(shape)
+            return a, _lib.as_dp(a)
+        c, cp = arr(frame_coeff, (F,))
+        r, rp = arr(dR, (N, 3))
+        hh, hp = arr(dh, (F, 9))
+        grad = np.zeros(self.constant_count())
+        self._check(self._lib.ta_constant_gradient(self._handle, cp, rp, hp, _lib.as_dp(grad), len(grad)))
+        return grad
+
     def energies(self, reuse_descriptors=True) -> np.ndarray:
         """Frame energies of the resident batch; with `reuse_descriptors` only the MLP is re-run."""
         want = _lib.TA_WANT_ENERGY | (_lib.TA_WANT_REUSE_DESCRIPTORS if reuse_descriptors else 0)

@@ -266,14 +266,17 @@ class Trainer:
     the directional derivative of the energy; for the per-atom MLP models the descriptors do not
     depend on the weights, so d/dtheta of it is ONE analytic second-order pass through the MLP
     (`ta_loss_gradient`: descriptor Jacobian once per resident batch, then a pair sweep + the MLP
-    pass per step, energy term included). The nn functions of EAM / ADP models, whose pair networks
-    see r itself, keep the central difference of g = dE/dtheta on two displaced copies of every
+    pass per step, energy term included). An EAM model whose functions are all analytic trains their
+    CONSTANTS instead (potentials/potentials.py:129-163): `ta_constant_gradient` differentiates the
+    same functional in dual arithmetic, one seeded constant per grid row. The nn functions of EAM / ADP
+    models, whose pair networks see r itself, keep the central difference of g = dE/dtheta on two displaced copies of every
     frame (`analytic=False` forces it everywhere; step `fd_step` Angstrom, error O(step^2)).
     """
 
     def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
                  energy_weight=1.0, forces_weight=1.0, stress_weight=1.0, method="rmse",
-                 per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, analytic=None, **adam_kwargs):
+                 per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, analytic=None, fixed=None,
+                 **adam_kwargs):
         from .engine import Engine
         rank, local_rank, world = world_from_env()
         lo, hi = shard_range(len(frames), rank, world)
@@ -281,8 +284,15 @@ class Trainer:
         self.rank, self.world = rank, world
         self.device = local_rank if device is None else device
         self.engine = Engine(nn, device=self.device)
-        # the analytic second-order pass exists for the per-atom MLP models
-        self.analytic = (not hasattr(nn, "nn_functions")) if analytic is None else bool(analytic)
+        # an EAM model without nn functions trains the constants of its analytic functions
+        # (reference potentials/potentials.py:129-163), `fixed` = {section: [names]} stay put
+        self.constants_mode = hasattr(nn, "nn_functions") and not any(s is not None for s in nn.nn_functions())
+        # the analytic second-order pass exists for the per-atom MLP models (and, in dual arithmetic,
+        # for the constants)
+        self.analytic = (not hasattr(nn, "nn_functions") or self.constants_mode) if analytic is None \
+            else bool(analytic)
+        if self.constants_mode and not self.analytic:
+            raise ValueError("the constants have no finite-difference path")
         self._resident = False
         self.frames = list(frames[lo:hi])
         self.e_ref = np.asarray(energies, dtype=np.float64)[lo:hi]
@@ -291,8 +301,12 @@ class Trainer:
         self.n_atoms = np.array([len(a) for a in self.frames], dtype=np.float64)
         self.weights = (energy_weight, forces_weight, stress_weight)
         self.method, self.per_atom_loss, self.fd_step = method, per_atom_loss, fd_step
-        self.theta = flatten_weights(nn)
-        self.mask = trainable_mask(nn)
+        if self.constants_mode:
+            self.theta = nn.constants()
+            self.mask = nn.constant_mask(fixed)
+        else:
+            self.theta = flatten_weights(nn)
+            self.mask = trainable_mask(nn)
         self.opt = Adam(len(self.theta), learning_rate=learning_rate, **adam_kwargs)
         self.history: List[dict] = []
 
@@ -335,7 +349,8 @@ class Trainer:
                 if self.frames else np.zeros((0, 3))
             dh = np.array([np.asarray(a.get_cell(complete=True), dtype=np.float64) @ Y[k]
                            for k, a in enumerate(self.frames)])
-            grad = eng.loss_gradient(c, dR if second else None, dh if second else None)
+            gradient = eng.constant_gradient if self.constants_mode else eng.loss_gradient
+            grad = gradient(c, dR if second else None, dh if second else None)
         elif second:
             disp, coeff = [], []
             for k, a in enumerate(self.frames):
@@ -363,14 +378,20 @@ class Trainer:
             pass
         grad = allreduce_mean(grad, torch_dev)
         self.theta = self.opt.step(self.theta, grad)
-        self.engine.update_weights(self.theta)
+        if self.constants_mode:
+            self.engine.update_constants(self.theta)
+        else:
+            self.engine.update_weights(self.theta)
         self.history.append(dict(terms, total=total))
         return total, terms
 
     def fit(self, steps: int):
         for _ in range(steps):
             self.step()
-        self.nn.weights = unflatten_weights(self.nn, self.theta)
+        if self.constants_mode:
+            self.nn.set_constants(self.theta)
+        else:
+            self.nn.weights = unflatten_weights(self.nn, self.theta)
         return self.history
 
     def close(self):

@@ -109,7 +109,15 @@ def _adp_pots(elements):
 
 def oracle_eam_eval(nn, atoms):
     """Oracle counterpart of an EamAlloyNN / AdpNN (test infrastructure only)."""
-    from oracle.eam import EamModel, evaluate
+    from oracle.eam import evaluate
+    m = oracle_eam_model(nn)
+    eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
+    return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
+                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)
+
+
+def oracle_eam_model(nn):
+    from oracle.eam import EamModel
     from tensoralloy_amd.eam import AdpNN, ADP_KEYS
     adp = None
     if isinstance(nn, AdpNN):
@@ -138,13 +146,10 @@ def oracle_eam_eval(nn, atoms):
     if isinstance(nn, AdpNN) and not adp:
         adp = {}
     other = {el: (nn._el_kind[el], nn.other_parameters(el)) for el in nn.elements if nn._el_kind[el] != "zjw"}
-    m = EamModel(nn.elements, nn.transformer.rcut, other=other,
-                 params={el: nn.element_parameters(el) for el in nn.elements if el not in other}, adp=adp,
-                 blended_embed=nn.family != "zjw04", phi_pairs=phi_pairs, nets=nets,
-                 activation=nn._activation, tables=tables)
-    eps = 1e-8 if getattr(nn, "precision", "high") == "medium" else 1e-14
-    return evaluate(m, atoms.get_chemical_symbols(), atoms.positions,
-                    np.asarray(atoms.get_cell(complete=True)), atoms.pbc, eps=eps)
+    return EamModel(nn.elements, nn.transformer.rcut, other=other,
+                    params={el: nn.element_parameters(el) for el in nn.elements if el not in other}, adp=adp,
+                    blended_embed=nn.family != "zjw04", phi_pairs=phi_pairs, nets=nets,
+                    activation=nn._activation, tables=tables)
 
 
 PEXP = {"rl": [1.0, 1.15, 1.3, 1.45, 1.6, 1.75, 1.9, 2.05, 2.2, 2.35],

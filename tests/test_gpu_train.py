@@ -265,3 +265,120 @@ def test_analytic_loss_gradient_matches_oracle(lib, kind):
         ref = part if ref is None else ref + part
         a0 += len(a)
     assert np.abs(g - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("kind", ["zjw04", "alloy", "zjw04xc", "zjw04xcp", "sutton90", "be/1", "grimes"])
+def test_empirical_constant_gradient(lib, kind):
+    """The reference trains the constants of its empirical potentials (potentials.py:129-163).
+    `ta_constant_gradient` = d/dconstants of  sum_f c_f E_f + sum u.F + sum Y:W  (the model-dependent
+    part of the energy + forces + stress loss) in dual arithmetic; checked slot by slot against the
+    7-point central difference of the same functional built from the ORACLE's energies, forces
+    and virials at displaced constants."""
+    import copy
+    from tensoralloy_amd import Engine
+    from tests.helpers import hcp, make_eam, oracle_eam_model
+    from oracle.train import eam_loss_functional, central_difference_6
+    rng = np.random.RandomState(11)
+    if kind == "zjw04":
+        nn, frames = make_eam(["Ni"], 6.0), [fcc(rep=(2, 2, 2), jitter=0.1), fcc(rep=(2, 2, 2), a=3.4, seed=3, jitter=0.05)]
+    elif kind == "alloy":
+        nn, frames = make_eam(["Mo", "Ni"], 6.0), [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 2))]
+    elif kind == "zjw04xc":
+        nn, frames = make_eam(["Ni"], 6.0, potential="zjw04xc"), [fcc(rep=(2, 2, 2), jitter=0.1)]
+    elif kind == "zjw04xcp":
+        nn, frames = make_eam(["Mo", "Ni"], 6.0, potential="zjw04xcp"), [_alloy(["Ni", "Ni", "Mo", "Mo"], rep=(2, 2, 2))]
+    elif kind == "sutton90":
+        nn, frames = make_eam(["Ag"], 7.0, potential="sutton90"), [fcc("Ag", a=4.09, rep=(2, 2, 2), jitter=0.08)]
+    elif kind == "be/1":
+        nn, frames = make_eam(["Be"], 5.0, potential="Be/1"), [hcp(rep=(3, 3, 3), jitter=0.05, seed=4)]
+    else:
+        nn, frames = make_eam(["Pu"], 6.0, potential="grimes"), [fcc("Pu", a=4.6, rep=(2, 2, 2), jitter=0.08)]
+    F = len(frames)
+    c = rng.normal(0, 1, F)
+    u = [rng.normal(0, 0.3, (len(a), 3)) for a in frames]
+    Y = []
+    for _ in frames:
+        y = rng.normal(0, 0.05, (3, 3))
+        Y.append(0.5 * (y + y.T))
+    dR = np.concatenate([a.positions @ Y[k] - u[k] for k, a in enumerate(frames)])
+    dh = np.array([np.asarray(a.get_cell(complete=True)) @ Y[k] for k, a in enumerate(frames)])
+    names = nn.constant_names()
+    with Engine(nn) as eng:
+        eng.set_frames(frames)
+        flat = eng.constants()
+        assert np.abs(flat - nn.constants()).max() == 0.0
+        grad = eng.constant_gradient(c, dR, dh)
+        grad_e = eng.constant_gradient(c, None, None)          # energy term alone
+        # new constants reach the kernels: the energy moves by grad_e . delta to first order
+        e0 = np.dot(c, eng.energies(reuse_descriptors=False))
+        live = np.array([n is not None for n in names])
+        delta = np.where(live, 1e-6 * rng.normal(0, 1, len(flat)) * np.maximum(np.abs(flat), 1e-2), 0.0)
+        eng.update_constants(flat + delta)
+        e1 = np.dot(c, eng.energies(reuse_descriptors=False))
+        assert abs((e1 - e0) - np.dot(grad_e, delta)) < 1e-3 * abs(np.dot(grad_e, delta)) + 1e-12
+    oframes = [(a.get_chemical_symbols(), a.positions, np.asarray(a.get_cell(complete=True)), a.pbc) for a in frames]
+
+    def functional(slot, value, energy_only=False):
+        trial = copy.deepcopy(nn)
+        v = flat.copy()
+        v[slot] = value
+        trial.set_constants(v)
+        zero_u = [np.zeros_like(x) for x in u]
+        zero_Y = [np.zeros((3, 3)) for _ in Y]
+        return eam_loss_functional(oracle_eam_model(trial), oframes, c, zero_u if energy_only else u,
+                                   zero_Y if energy_only else Y)
+    scale = max(np.abs(grad).max(), 1e-30)
+    L0 = functional(0, flat[0])
+    checked = 0
+    for slot, name in enumerate(names):
+        if name is None:
+            assert grad[slot] == 0.0 and grad_e[slot] == 0.0
+            continue
+        # small step: the piecewise Zjw04 embedding is only piecewise smooth in the constants (an atom
+        # whose rho crosses 0.85 / 1.15 rho_e inside the stencil spoils the difference, not the kernel)
+        h = 1e-4 * max(abs(flat[slot]), 0.05)
+        fd = central_difference_6(lambda x: functional(slot, x), flat[slot], h)
+        tol = 2e-8 * max(abs(fd), 1e-3 * scale) + 1e-9 + 1e-13 * abs(L0) / h    # last: round-off of the stencil
+        assert abs(grad[slot] - fd) < tol, (name, grad[slot], fd)
+        if slot % 5 == 0:
+            fd_e = central_difference_6(lambda x: functional(slot, x, True), flat[slot], h)
+            assert abs(grad_e[slot] - fd_e) < 2e-8 * max(abs(fd_e), 1e-3 * scale) + 1e-9, (name, grad_e[slot], fd_e)
+        checked += 1
+    assert checked >= 2
+    # models with nn or tabulated functions, or ADP terms, are refused
+    with Engine(make_eam(["Ni"], 6.0, adp=True)) as eng:
+        eng.set_frames(frames[:1]) if kind == "zjw04" else eng.set_frames([fcc(rep=(2, 2, 2))])
+        with pytest.raises(ValueError):
+            eng.constant_gradient(np.ones(1), None, None)
+
+
+def test_fit_of_empirical_constants_recovers_a_teacher(lib):
+    """Trainer on an all-analytic EAM model: the constants are the parameters (as the reference's
+    potentials are trained, potentials.py:129-163); `fixed` entries and unused slots do not move."""
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import Trainer
+    from tests.helpers import make_eam
+    teacher = make_eam(["Ni"], 6.0)
+    frames = [fcc(rep=(2, 2, 2), a=3.4 + 0.04 * k, seed=k, jitter=0.08) for k in range(6)]
+    with Engine(teacher) as eng:
+        ref = eng.evaluate(frames)
+    student = make_eam(["Ni"], 6.0)
+    start = student.constants()
+    names = student.constant_names()
+    off = start.copy()
+    for k, n in enumerate(names):
+        if n is not None and n[1] in ("f_eq", "A", "B", "F0", "F1", "F2"):
+            off[k] *= 1.04
+    student.set_constants(off)
+    tr = Trainer(student, frames, [r["energy"] for r in ref], [r["forces"] for r in ref],
+                 [r["stress"] for r in ref], learning_rate=2e-3, fixed={"Ni": ["r_eq", "rho_e", "rho_s"]})
+    assert tr.constants_mode and tr.analytic
+    first = tr.step()[0]
+    hist = tr.fit(150)
+    tr.close()
+    assert hist[-1]["total"] < 0.2 * first
+    end = student.constants()
+    for k, n in enumerate(names):
+        if n is None or n[1] in ("r_eq", "rho_e", "rho_s"):
+            assert end[k] == off[k]
+    assert np.abs(end - off).max() > 0
