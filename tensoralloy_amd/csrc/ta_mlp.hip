@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <stdexcept>
 
 #include "ta_device.h"
 #include "ta_mlp_tile.h"
@@ -75,6 +78,303 @@ __global__ __launch_bounds__(THREADS) void mlp_all_kernel(const MlpDev *__restri
       [&](int row, int k, double d) { dEdG[(size_t)el_atoms[a0 + row] * ndim + k] = d; });
 }
 
+// ---- one wavefront per 16 atoms, the whole network in registers ---------------------------------
+// For the usual shapes (1 to 3 hidden layers of at most 64 units, scalar output, no skip
+// connections) the GEMMs are run TRANSPOSED: Z^T[unit][atom] = W^T . X^T, with the weights as the A
+// operand (lane (n', kq) reads W[4 kk + kq][16 nt + n'], 16 consecutive doubles) and the activations
+// as the B operand (lane (m, kq) supplies X^T[4 kk + kq][atom m]). The f64 accumulator of tile nt
+// then holds Z^T[16 nt + kq + 4 r][atom m] in register r -- which IS the B operand of k-step
+// 4 nt + r of the next layer. So activations never leave the registers: no barrier and no
+// transposition between the layers, forward or backward (delta^T = W . dz^T uses the transposed
+// weight copy as A operand and the dz registers as B). The first layer reads the descriptors
+// straight from G (k-steps beyond the true D are skipped, not padded to 16); the scalar output
+// layer is a per-lane dot product and two cross-row adds instead of a 16-column tile.
+// The weights (both orientations) are staged ONCE per workgroup in LDS, row stride = 16 mod 32
+// doubles (the four kq rows of an A-operand read fall in disjoint banks); the 8 wavefronts of a
+// workgroup then walk 16-atom tiles independently. A wavefront that fetched its A operands from
+// L2 instead paid a round trip per 16 MFMAs: 49 us for one 4000-atom frame against 18 us for the
+// 16-row tile kernel it replaces.
+constexpr int kWaveNT = 4;       // hidden widths up to 64
+constexpr int kWaveThreads = 512;
+constexpr int kWaveMaxHidden = 3;
+
+// LDS row strides. Everything up to 64 columns wide uses ONE compile-time stride, 80 doubles (= 16
+// mod 32), so that the A-operand reads carry immediate offsets: with run-time strides the compiler
+// hoists every read address out of the tile loop and spills (95 VGPRs for two hidden layers). Only
+// the transposed first layer, whose rows are as long as the padded descriptor, has its own stride.
+constexpr int kWaveStride = 80;
+__host__ __device__ inline int wave_stride(int x) { return (x % 32 == 0) ? x + 16 : x; }
+
+struct WaveLds {
+  const double *w[kWaveMaxHidden], *wt[kWaveMaxHidden], *b[kWaveMaxHidden];
+  int swt0;  // row stride of wt[0]
+  const double *wout;
+  double bout;
+};
+
+// doubles of LDS the staged network needs
+__host__ __device__ inline size_t wave_lds_doubles(const MlpDev &mlp, int lh) {
+  size_t n = 0;
+  for (int l = 0; l < lh; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    n += (size_t)ly.kp * kWaveStride + (size_t)ly.np * (l == 0 ? wave_stride(ly.kp) : kWaveStride) + ly.np;
+  }
+  return n + mlp.layer[lh].kp;
+}
+
+// dst[row * stride + col] = src[row * cols + col]: eight independent loads in flight per thread (a
+// plain strided loop waits for every load before it issues the next one: 16 round trips to L2 for
+// one 64 x 64 layer, 11 us)
+__device__ __forceinline__ void wave_copy_rows(double *dst, int stride, const double *__restrict__ src, int rows,
+                                               int cols) {
+  const int n = rows * cols;
+  for (int base = 0; base < n; base += 8 * kWaveThreads) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kWaveThreads + (int)threadIdx.x;
+      v[u] = idx < n ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kWaveThreads + (int)threadIdx.x;
+      if (idx < n) {
+        const int row = idx / cols;
+        dst[row * stride + (idx - row * cols)] = v[u];
+      }
+    }
+  }
+}
+
+template <int LH>
+__device__ __forceinline__ void wave_stage(const MlpDev &mlp, double *lds, WaveLds &L) {
+  double *p = lds;
+#pragma unroll
+  for (int l = 0; l < LH; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    const int sw = kWaveStride, swt = l == 0 ? wave_stride(ly.kp) : kWaveStride;
+    double *w = p, *wt = w + (size_t)ly.kp * sw, *bb = wt + (size_t)ly.np * swt;
+    wave_copy_rows(w, sw, ly.w, ly.kp, ly.np);
+    wave_copy_rows(wt, swt, ly.wt, ly.np, ly.kp);
+    wave_copy_rows(bb, ly.np, ly.b, 1, ly.np);
+    L.w[l] = w;
+    L.wt[l] = wt;
+    L.b[l] = bb;
+    if (l == 0) L.swt0 = swt;
+    p = bb + ly.np;
+  }
+  const MlpLayerDev &lo = mlp.layer[LH];
+  for (int idx = threadIdx.x; idx < lo.kp; idx += kWaveThreads) p[idx] = lo.w[(size_t)idx * lo.np];  // column 0
+  L.wout = p;
+  L.bout = lo.b[0];
+}
+
+// activation of one accumulator tile. NOT inlined: the one-wavefront kernel applies it to 8 tiles per
+// hidden layer, and 32 inlined copies of the activation switch per layer made the kernel 112 KB of
+// code -- more than the instruction cache, which a lone wavefront per SIMD then misses all the way
+// (42 us for one 4000-atom frame; this call brings the code to a fifth of that).
+struct WaveAct {
+  mlp_f64x4 h, d;
+};
+__device__ __attribute__((noinline)) WaveAct wave_activate(int act, mlp_f64x4 z) {  // by value: registers
+  WaveAct o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double hv, dv;
+    activation_fn(act, z[r], hv, dv);
+    o.h[r] = hv;
+    o.d[r] = dv;
+  }
+  return o;
+}
+
+template <int LH>
+__device__ __forceinline__ void mlp_wave_tile(const MlpDev &mlp, const WaveLds &L, int act, int ndim,
+                                              const int32_t *atoms, int n_atoms, int a0,
+                                              const double *__restrict__ G, double *__restrict__ dEdG,
+                                              double *__restrict__ eatom) {
+  const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+  const bool valid = a0 + m < n_atoms;
+  const int atom = atoms[valid ? a0 + m : a0];
+  mlp_f64x4 h[LH][kWaveNT], dh[LH][kWaveNT];
+  // ---- forward ----
+  {
+    const MlpLayerDev &ly = mlp.layer[0];
+    const int nt0 = ly.np / 16;
+    constexpr int sw = kWaveStride;
+#pragma unroll
+    for (int nt = 0; nt < kWaveNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[0][nt][r] = nt < nt0 ? L.b[0][16 * nt + kq + 4 * r] : 0.0;
+    const double *g = G + (size_t)atom * ndim;
+    for (int k0 = 0; k0 < ndim; k0 += 4) {
+      const int k = k0 + kq;
+      double x = 0.0;
+      if (k < ndim) {
+        x = g[k];
+        if (mlp.xlo) {
+          const double den = mlp.xhi[k] - mlp.xlo[k];
+          x = (den != 0.0) ? (mlp.xhi[k] - x) / den : 0.0;  // div_no_nan, atomic.py:195
+        }
+      }
+      const double *wrow = L.w[0] + k * sw + m;  // k < kp: rows beyond ndim are zero padding
+#pragma unroll
+      for (int nt = 0; nt < kWaveNT; ++nt)
+        if (nt < nt0) h[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[16 * nt], x, h[0][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < kWaveNT; ++nt)
+      if (nt < nt0) {
+        const WaveAct o = wave_activate(act, h[0][nt]);
+        h[0][nt] = o.h;
+        dh[0][nt] = o.d;
+      }
+  }
+#pragma unroll
+  for (int l = 1; l < LH; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    const int ntl = ly.np / 16, ntp = ly.kp / 16;
+    constexpr int sw = kWaveStride;
+    // the four output tiles advance together: four independent accumulator chains per k-step
+    mlp_f64x4 acc[kWaveNT];
+#pragma unroll
+    for (int nt = 0; nt < kWaveNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt][r] = nt < ntl ? L.b[l][16 * nt + kq + 4 * r] : 0.0;
+    const double *wcol = L.w[l] + kq * sw + m;
+#pragma unroll
+    for (int t = 0; t < kWaveNT; ++t) {
+      if (t >= ntp) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double a[kWaveNT];
+#pragma unroll
+        for (int nt = 0; nt < kWaveNT; ++nt) a[nt] = nt < ntl ? wcol[(16 * t + 4 * r) * sw + 16 * nt] : 0.0;
+#pragma unroll
+        for (int nt = 0; nt < kWaveNT; ++nt)
+          if (nt < ntl) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[nt], h[l - 1][t][r], acc[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < kWaveNT; ++nt) {
+      if (nt >= ntl) continue;
+      const WaveAct o = wave_activate(act, acc[nt]);
+      h[l][nt] = o.h;
+      dh[l][nt] = o.d;
+    }
+  }
+  // scalar output layer: y = b + sum_k h[k] w[k][0]; its backward seed dE/dh[k] = w[k][0]
+  {
+    const int ntp = mlp.layer[LH].kp / 16;
+    double y = 0.0;
+#pragma unroll
+    for (int t = 0; t < kWaveNT; ++t)
+      if (t < ntp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double wo = L.wout[16 * t + kq + 4 * r];
+          y = fma(h[LH - 1][t][r], wo, y);
+          dh[LH - 1][t][r] *= wo;  // dz of the last hidden layer
+        }
+      }
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    if (kq == 0 && valid) eatom[atom] = y + L.bout;
+  }
+  // ---- backward: delta_{l-1}^T = W_l . dz_l^T, dz_{l-1} = delta_{l-1} * act'(z_{l-1}) ----
+#pragma unroll
+  for (int l = LH - 1; l >= 1; --l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    const int ntl = ly.np / 16, ntp = ly.kp / 16;
+    constexpr int swt = kWaveStride;
+    mlp_f64x4 acc[kWaveNT];
+#pragma unroll
+    for (int t = 0; t < kWaveNT; ++t) acc[t] = {0.0, 0.0, 0.0, 0.0};
+    const double *wcol = L.wt[l] + kq * swt + m;
+#pragma unroll
+    for (int nt = 0; nt < kWaveNT; ++nt) {
+      if (nt >= ntl) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double a[kWaveNT];
+#pragma unroll
+        for (int t = 0; t < kWaveNT; ++t) a[t] = t < ntp ? wcol[(16 * nt + 4 * r) * swt + 16 * t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < kWaveNT; ++t)
+          if (t < ntp) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], dh[l][nt][r], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kWaveNT; ++t)
+      if (t < ntp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[l - 1][t][r] *= acc[t][r];
+      }
+  }
+  {
+    const MlpLayerDev &ly = mlp.layer[0];
+    const int nt0 = ly.np / 16, swt = L.swt0;
+    for (int j0 = 0; j0 < ndim; j0 += 16) {
+      mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      // wt rows: hidden unit n, columns: input channel (kp columns, zero beyond ndim)
+      const double *wcol = L.wt[0] + kq * swt + j0 + m;
+#pragma unroll
+      for (int nt = 0; nt < kWaveNT; ++nt) {
+        if (nt >= nt0) continue;
+        double a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = wcol[(16 * nt + 4 * r) * swt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], dh[0][nt][r], acc, 0, 0, 0);
+      }
+      // acc[r] = dE/dG[atom m][j0 + kq + 4 r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + kq + 4 * r;
+        if (valid && j < ndim) {
+          double d = acc[r];
+          if (mlp.xlo) {
+            const double den = mlp.xhi[j] - mlp.xlo[j];
+            d = (den != 0.0) ? -d / den : 0.0;
+          }
+          dEdG[(size_t)atom * ndim + j] = d;
+        }
+      }
+    }
+  }
+}
+
+template <int LH>
+__global__ __launch_bounds__(kWaveThreads) void mlp_wave_kernel(MlpDev mlp, int act, int ndim, const int32_t *atoms,
+                                                                int n_atoms, const double *G, double *dEdG,
+                                                                double *eatom) {
+  extern __shared__ double lds[];
+  WaveLds L;
+  wave_stage<LH>(mlp, lds, L);
+  __syncthreads();
+  const int ntiles = (n_atoms + kMlpRows - 1) / kMlpRows, nw = kWaveThreads / 64;
+  for (int tile = (int)blockIdx.x * nw + (int)(threadIdx.x >> 6); tile < ntiles; tile += (int)gridDim.x * nw)
+    mlp_wave_tile<LH>(mlp, L, act, ndim, atoms, n_atoms, tile * kMlpRows, G, dEdG, eatom);
+}
+
+// all elements in one launch: blockIdx.y = element
+template <int LH>
+__global__ __launch_bounds__(kWaveThreads) void mlp_wave_all_kernel(const MlpDev *__restrict__ mlps, MlpTiles tiles,
+                                                                    int act, int ndim, const int32_t *atoms,
+                                                                    const double *G, double *dEdG, double *eatom) {
+  extern __shared__ double lds[];
+  const int e = blockIdx.y;
+  const int n_atoms = tiles.elem_start[e + 1] - tiles.elem_start[e];
+  const int ntiles = (n_atoms + kMlpRows - 1) / kMlpRows, nw = kWaveThreads / 64;
+  if ((int)blockIdx.x * nw >= ntiles) return;  // nothing for this workgroup (uniform)
+  const MlpDev &mlp = mlps[e];
+  WaveLds L;
+  wave_stage<LH>(mlp, lds, L);
+  __syncthreads();
+  for (int tile = (int)blockIdx.x * nw + (int)(threadIdx.x >> 6); tile < ntiles; tile += (int)gridDim.x * nw)
+    mlp_wave_tile<LH>(mlp, L, act, ndim, atoms + tiles.elem_start[e], n_atoms, tile * kMlpRows, G, dEdG, eatom);
+}
+
 }  // namespace
 
 // scratch doubles needed per 16-row tile
@@ -82,9 +382,65 @@ size_t mlp_scratch_doubles(const MlpDev &mlp) {
   return (size_t)mlp.n_layers * kMlpRows * mlp_stride(mlp);
 }
 
+constexpr size_t kWaveLdsLimit = 150 * 1024;
+
+// The one-wavefront kernel is the THROUGHPUT kernel: 4000 tiles (16 frames of 4000 atoms) take 66 us
+// against 98 us with the 16-row tile kernel. For one frame it loses (35 us against 18 us): 250 tiles
+// are fewer than the 1024 SIMDs, and a tile's 152 MFMAs (64 cycles each on gfx950) and 32 activations
+// per lane are serial in one wavefront where the tile kernel spreads them over the four SIMDs of a CU.
+constexpr int kWaveMinTiles = 1024;
+
+// number of hidden layers when the one-wavefront kernel applies to `n_tiles` tiles, else 0
+int mlp_wave_shape(const MlpDev &mlp, int n_tiles) {
+  const int lh = mlp.n_layers - 1;
+  if (lh < 1 || lh > kWaveMaxHidden || getenv("TA_MLP_TILE_KERNEL")) return 0;
+  if (n_tiles < kWaveMinTiles && !getenv("TA_MLP_WAVE_KERNEL")) return 0;
+  for (int l = 0; l < lh; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    if (ly.np > 16 * kWaveNT || ly.res || !ly.act) return 0;
+    if (l > 0 && ly.kp != mlp.layer[l - 1].np) return 0;
+  }
+  const MlpLayerDev &lo = mlp.layer[lh];
+  if (lo.n != 1 || lo.act || lo.res || lo.kp != mlp.layer[lh - 1].np) return 0;
+  if (wave_lds_doubles(mlp, lh) * sizeof(double) > kWaveLdsLimit) return 0;  // wide descriptors
+  return lh;
+}
+
+// more than 64 KB of dynamic LDS needs the attribute; set once per kernel and device (the call is
+// host-side work of tens of microseconds -- per launch it would stall the queue behind the host)
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> allowed;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_pair(reinterpret_cast<const void *>(kernel), dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = allowed.find(key);
+  if (it != allowed.end() && it->second >= bytes) return;
+  if (hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWaveLdsLimit) != hipSuccess)
+    throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  allowed[key] = kWaveLdsLimit;
+}
+
 void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                      const DeviceBatch &b, double *scratch, hipStream_t s) {
   if (n_atoms == 0) return;
+  if (const int lh = mlp_wave_shape(mlp, (n_atoms + kMlpRows - 1) / kMlpRows)) {
+    const int ntiles = (n_atoms + kMlpRows - 1) / kMlpRows, nw = kWaveThreads / 64;
+    const unsigned wblocks = (unsigned)std::min((ntiles + nw - 1) / nw, 256);
+    const size_t lds = wave_lds_doubles(mlp, lh) * sizeof(double);
+    auto go = [&](auto kernel) {
+      allow_lds(kernel, lds);
+      hipLaunchKernelGGL(kernel, dim3(wblocks), dim3(kWaveThreads), lds, s, mlp, activation, ndim, atoms, n_atoms,
+                         b.G, b.dEdG, b.eatom);
+    };
+    if (lh == 1) go(mlp_wave_kernel<1>);
+    else if (lh == 2) go(mlp_wave_kernel<2>);
+    else go(mlp_wave_kernel<3>);
+    return;
+  }
   const int stride = mlp_stride(mlp);
   size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
   const unsigned blocks = (unsigned)((n_atoms + kMlpRows - 1) / kMlpRows);
@@ -136,6 +492,28 @@ void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, in
   t.elem_start[nel] = b.elem_start[nel];
   for (int e = nel + 1; e <= kMaxElements; ++e) t.tile_start[e] = t.elem_start[e] = 0;
   if (blocks == 0) return;
+  // every element's network has the same one-wavefront shape: one grid row per element
+  int lh = mlp_wave_shape(mlps_host[0], blocks);
+  size_t wlds = 0;
+  int max_tiles = 0;
+  for (int e = 0; e < nel; ++e) {
+    if (mlp_wave_shape(mlps_host[e], blocks) != lh) lh = 0;
+    if (lh) wlds = std::max(wlds, wave_lds_doubles(mlps_host[e], lh) * sizeof(double));
+    max_tiles = std::max(max_tiles, (b.elem_start[e + 1] - b.elem_start[e] + kMlpRows - 1) / kMlpRows);
+  }
+  if (lh) {
+    const int nw = kWaveThreads / 64;
+    const unsigned wblocks = (unsigned)std::min((max_tiles + nw - 1) / nw, std::max(256 / nel, 1));
+    auto go = [&](auto kernel) {
+      allow_lds(kernel, wlds);
+      hipLaunchKernelGGL(kernel, dim3(wblocks, (unsigned)nel), dim3(kWaveThreads), wlds, s, mlps_dev, t, activation,
+                         ndim, b.elem_atoms, b.G, b.dEdG, b.eatom);
+    };
+    if (lh == 1) go(mlp_wave_all_kernel<1>);
+    else if (lh == 2) go(mlp_wave_all_kernel<2>);
+    else go(mlp_wave_all_kernel<3>);
+    return;
+  }
   size_t lds = 2 * (size_t)kMlpRows * stride * sizeof(double);
   const size_t lds_da = (size_t)layers * kMlpRows * stride * sizeof(double);
   if (lds + lds_da <= 64 * 1024 && !getenv("TA_MLP_DA_GLOBAL")) {  // act' slab in LDS, see mlp_kernel

@@ -272,3 +272,29 @@ def test_failed_set_frames_leaves_no_batch_behind(lib):
         assert eng._lib.ta_get_results(eng._handle, null, null, null, null, null) == L.TA_ERR_INVALID
         r = eng.evaluate([atoms])[0]  # and the handle is still usable
         assert abs(r["energy"] - oracle_eval(nn, atoms)["energy"]) < E_TOL
+
+
+@pytest.mark.parametrize("hidden,activation,minmax", [
+    ([64, 64], "softplus", False), ([64, 32], "tanh", True), ([48], "softplus", False),
+    ([16, 32, 64], "squareplus", False), ([20, 50], "elu", True)])
+def test_one_wavefront_mlp_kernel(lib, monkeypatch, hidden, activation, minmax):
+    """Batches of 1024+ tiles run the MLP in `mlp_wave_kernel` (transposed GEMMs, activations in
+    registers, weights staged in LDS); forced here for small inputs. Same results as the oracle
+    and, to round-off, as the 16-row tile kernel: single element, alloy (one grid row per
+    element), ragged last tile, widths that pad to 16 / 32 / 48 / 64, one to three hidden layers."""
+    from tensoralloy_amd import Engine
+    frames = [fcc(rep=(2, 2, 2), jitter=0.05), fcc(rep=(3, 2, 2), a=3.4, seed=2, jitter=0.08)]   # 32 + 48 atoms
+    alloy = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 3))]
+    for nn, fr in ((make_nn(["Ni"], 6.0, True, hidden, activation=activation, minmax=minmax), frames),
+                   (make_nn(["Mo", "Ni"], 5.5, True, hidden, activation=activation, minmax=minmax), alloy)):
+        monkeypatch.setenv("TA_MLP_TILE_KERNEL", "1")
+        with Engine(nn) as eng:
+            tile = eng.evaluate(fr)
+        monkeypatch.delenv("TA_MLP_TILE_KERNEL")
+        monkeypatch.setenv("TA_MLP_WAVE_KERNEL", "1")
+        wave = _compare(nn, fr)
+        monkeypatch.delenv("TA_MLP_WAVE_KERNEL")
+        for a, b in zip(tile, wave):
+            assert abs(a["energy"] - b["energy"]) < 1e-10
+            assert np.abs(a["forces"] - b["forces"]).max() < 1e-10
+            assert np.abs(a["atomic"] - b["atomic"]).max() < 1e-11
