@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One BASELINE config on the resident batch, N evaluations (for rocprofv3: scripts/profile_configs.sh).
-  python scripts/run_config.py <eam|adp|grap|nn_eam> [frames] [steps]"""
+  python scripts/run_config.py <sf|eam|adp|grap|nn_eam> [frames] [steps]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import ni_frame
@@ -11,7 +11,10 @@ kind = sys.argv[1]
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
-if kind == "eam":
+if kind == "sf":
+    from bench import ni_model
+    nn = ni_model()
+elif kind == "eam":
     nn = make_eam(["Ni"], 6.5)
 elif kind == "adp":
     nn = make_eam(["Ni"], 6.5, adp=True)

@@ -162,7 +162,9 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    lib = C.CDLL(str(LIB_PATH))
+    # TA_LIB_AB=<path of another build of the same ABI>: kernel A/B runs inside one GPU session
+    # (box-to-box differences of ~5 % otherwise hide a 2 % kernel change)
+    lib = C.CDLL(os.environ.get("TA_LIB_AB") or str(LIB_PATH))
     H = C.c_void_p
     lib.ta_device_count.restype = C.c_int
     lib.ta_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(H)]

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
     for (int sc = 1; sc <= smax; sc += 64) {
       unsigned long long mask;
       if (have_mask) {
-        mask = mask0;
+        mask = (flags & (1 << 24)) ? 0ull : mask0;  // bit 24: measurement switch, triple bodies off
       } else {
         mask = partner_mask(sf, f, base, n, a, sc, smax);
         // the candidate mask is geometry only: keep it for the backward kernel
@@ -754,6 +754,7 @@ __global__ __launch_bounds__(kBlock)
       unsigned long long mask = have_mask ? mask0
                                 : (b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
                                            : partner_mask(sf, f, base, n, a, sc, smax));
+      if (flags & (1 << 24)) mask = 0ull;  // measurement switch: triple bodies off
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -972,6 +973,7 @@ int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 // stagger flags for a launch: "<count>[,<shift>]" from the environment (experiment switch)
 static int stagger_bits(const DeviceBatch &b, const char *var) {
   const char *e = getenv(var);
+  if (getenv("TA_DEBUG_NO_TRIPLES")) return 1 << 24;  // instruction accounting (wrong results)
   if (!e) return 0;
   int n = 0, shift = 3;
   if (sscanf(e, "%d,%d", &n, &shift) < 1) return 0;
