@@ -323,14 +323,16 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
  * zjw04.py: shared variables per element) trained under the same loss. Layout of the vector:
  * element e, constant k -> [20 e + k] in the order of the model description's `eam_el` rows
  * (Zjw04: r_eq f_eq rho_e rho_s alpha beta A B kappa lamda Fn0..Fn3 F0..F3 eta Fe), then the
- * Zjw04xcp cross terms [20 nel + 7 pt + q] (r_eq A B alpha beta kappa lamda), pt = sorted pair type.
+ * Zjw04xcp cross terms [20 nel + 7 pt + q] (r_eq A B alpha beta kappa lamda), pt = sorted pair type,
+ * then for ADP models the dipole / quadrupole constants [20 nel + 7 npt + 8 pt + k]
+ * (d1 d2 d3 q1 q2 q3 h rc; mishin.py:62-66).
  *   ta_constant_count     length of the vector
  *   ta_get_constants      current values
  *   ta_update_constants   new values (finite); synchronises the stream first
  *   ta_constant_gradient  d/dconstants of  sum_f frame_coeff[f] E_f + D_(dR, dh) E  on the resident
- *                         batch, arguments as ta_loss_gradient. Plain EAM with analytic rho, phi
- *                         and F only (TA_ERR_INVALID otherwise); forward-mode (dual numbers), one
- *                         pass over the pairs per constant in a single launch. */
+ *                         batch, arguments as ta_loss_gradient. EAM / ADP models whose functions
+ *                         are all analytic (TA_ERR_INVALID otherwise); forward-mode (dual
+ *                         numbers), one pass over the pairs per constant in a single launch. */
 int ta_constant_count(ta_handle h, int64_t *n_constants);
 int ta_get_constants(ta_handle h, double *constants, int64_t n_constants);
 int ta_update_constants(ta_handle h, const double *constants, int64_t n_constants);

@@ -330,20 +330,20 @@ __device__ __forceinline__ void el_embed(const EamParams &P, const T (*el)[20], 
 
 
 // (p1 exp(-p2 r) + p3) psi((r - rc)/h), psi(x) = x^4/(1+x^4) for x < 0  (generic.py:52-84)
-__device__ __forceinline__ void mishin_polar(double r, double p1, double p2, double p3, double rc,
-                                             double h, double &f, double &df) {
-  const double z = (r - rc) / h;
-  if (z >= 0.0) {
-    f = 0.0;
-    df = 0.0;
+template <typename T>
+__device__ __forceinline__ void mishin_polar(double r, T p1, T p2, T p3, T rc, T h, T &f, T &df) {
+  const T z = (r - rc) / h;
+  if (t_val(z) >= 0.0) {
+    f = T{};
+    df = T{};
     return;
   }
-  const double zz = -z, z2 = zz * zz, z4 = z2 * z2;
-  const double den = 1.0 / (1.0 + z4);
-  const double psi = z4 * den;
-  const double dpsi = -4.0 * z2 * zz * den * den / h;
-  const double e = ta_exp(-p2 * r);
-  const double left = fma(p1, e, p3);
+  const T zz = -z, z2 = zz * zz, z4 = z2 * z2;
+  const T den = 1.0 / (1.0 + z4);
+  const T psi = z4 * den;
+  const T dpsi = -4.0 * z2 * zz * den * den / h;
+  const T e = t_exp(-p2 * r);
+  const T left = p1 * e + p3;
   f = left * psi;
   df = -p1 * p2 * e * psi + left * dpsi;
 }
@@ -421,10 +421,10 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
         double u, du, w, dw;
         if (u_nn) u = pf[PF_U * ps + q];
         else if (u_tab) spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
-        else mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        else mishin_polar<double>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
         if (w_nn) w = pf[PF_W * ps + q];
         else if (w_tab) spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
-        else mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        else mishin_polar<double>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
         m[0] = fma(u, dx, m[0]);
         m[1] = fma(u, dy, m[1]);
         m[2] = fma(u, dz, m[2]);
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
     } else if ((P.tab_u >> pt) & 1u) {
       spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
     } else {
-      mishin_polar(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+      mishin_polar<double>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
     }
     if ((P.nn_w >> pt) & 1u) {
       w = pf[PF_W * ps + p];
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
     } else if ((P.tab_w >> pt) & 1u) {
       spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
     } else {
-      mishin_polar(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+      mishin_polar<double>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
     }
     const double muD = m[0] * dx + m[1] * dy + m[2] * dz;
     const double lx = m[3] * dx + m[8] * dy + m[7] * dz;
@@ -904,9 +904,9 @@ __global__ __launch_bounds__(kBlock) void eam_tabulate_kernel(EamParams P, int n
         const double *pp = P.pair[pt];
         double u, du, w, dw;
         if ((P.tab_u >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 2, pt)], x, u, du);
-        else mishin_polar(x, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        else mishin_polar<double>(x, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
         if ((P.tab_w >> pt) & 1u) spline_eval(tabs[slot_pair(nel, 3, pt)], x, w, dw);
-        else mishin_polar(x, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        else mishin_polar<double>(x, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
         u_of_r[(size_t)pt * n_r + k] = u;
         w_of_r[(size_t)pt * n_r + k] = w;
       }
@@ -1422,8 +1422,14 @@ namespace {
 //   sum_i  c_f(i) [F(rho_i) + 1/2 sum_j phi(r_ij)] + F'(rho_i) rhodot_i + 1/2 sum_j phi'(r_ij) rdot_ij,
 //   rho_i = sum_j rho_{s_j}(r_ij),  rhodot_i = sum_j rho'_{s_j}(r_ij) rdot_ij,  rdot = D . dD / r,
 // evaluated in dual arithmetic with that constant seeded: F' of a dual rho_i brings F'' along.
+// ADP models add, per neighbour species, mu = sum_j u(r) D, lambda = sum_j w(r) D (x) D and the energy
+// 1/2 |mu|^2 + 1/2 sum lambda_ab^2 - (tr lambda)^2 / 6 (adp.py:371-392, :458-492); their directional
+// derivatives mudot = sum_j (u' rdot D + u dD), lambdadot = sum_j (w' rdot D (x) D + w (dD (x) D + D (x) dD))
+// enter as mu . mudot + sum lambda_ab lambdadot_ab - tr lambda tr lambdadot / 3, all in duals, so the
+// constants of the MishinH dipole / quadrupole functions (mishin.py:62-66, :269-315) are covered too.
 // One wavefront per atom; blockIdx.y = the seeded constant: e * 20 + k for element e (ZJW04_KEYS
-// order), then 20 nel + pt * 7 + q for the Zjw04xcp cross terms.
+// order), then 20 nel + pt * 7 + q for the Zjw04xcp cross terms, then (ADP) 20 nel + 7 npt + pt * 8 + k
+// for d1 d2 d3 q1 q2 q3 h rc of pair type pt.
 template <bool OTHER>
 __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, DeviceBatch b,
                                                                 const double *__restrict__ frame_coeff,
@@ -1432,6 +1438,7 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
                                                                 double *partial) {
   __shared__ Dual el[kMaxEamElements][20];
   __shared__ Dual phx[kMaxPairTypes][7];
+  __shared__ Dual prs[kMaxPairTypes][8];
   __shared__ double wpart[kBlock / 64];
   const int seeded = blockIdx.y;
   const int nel = P.nel, npt = nel * (nel + 1) / 2;
@@ -1439,6 +1446,8 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
     el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20], t == seeded ? 1.0 : 0.0);
   for (int t = threadIdx.x; t < npt * 7; t += kBlock)
     phx[t / 7][t % 7] = make_dual(P.phi[t / 7][t % 7], 20 * nel + t == seeded ? 1.0 : 0.0);
+  for (int t = threadIdx.x; t < npt * 8; t += kBlock)
+    prs[t / 8][t % 8] = make_dual(P.pair[t / 8][t % 8], 20 * nel + 7 * npt + t == seeded ? 1.0 : 0.0);
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1450,7 +1459,15 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
     const double *h = b.cells + 9 * (size_t)fr;
     const double *ri = b.pos + 3 * (size_t)i;
     Dual rho = make_dual(0.0), rhodot = make_dual(0.0), phis = make_dual(0.0), phidot = make_dual(0.0);
-    for (int sb = 0; sb < nel; ++sb)
+    Dual eadp = make_dual(0.0);  // c E_adp + D_delta E_adp of this atom (lane 0)
+    const double cf = frame_coeff ? frame_coeff[fr] : 0.0;
+    for (int sb = 0; sb < nel; ++sb) {
+      // ADP moments of this neighbour species and their directional derivatives:
+      // m[0..2] = mu, m[3..8] = lambda (xx yy zz yz xz xy); md = the same for the tangent
+      Dual m[9], md[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) m[k] = md[k] = make_dual(0.0);
+      const Dual *pp = prs[pair_type(sA, sb, nel)];
       for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
         const int j = b.pair_j[q];
         const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
@@ -1462,13 +1479,13 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
         const double r2 = dx * dx + dy * dy + dz * dz + eps;
         if (P.list_rc2 > 0.0 && !(r2 < P.list_rc2)) continue;
         const double r = sqrt(r2);
-        double rdot = 0.0;
+        double rdot = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
         if (dR) {
           const double *g = dh + 9 * (size_t)fr;
           const double *ui = dR + 3 * (size_t)i, *uj = dR + 3 * (size_t)j;
-          const double tx = (uj[0] - ui[0]) + (sx * g[0] + sy * g[3] + sz * g[6]);
-          const double ty = (uj[1] - ui[1]) + (sx * g[1] + sy * g[4] + sz * g[7]);
-          const double tz = (uj[2] - ui[2]) + (sx * g[2] + sy * g[5] + sz * g[8]);
+          tx = (uj[0] - ui[0]) + (sx * g[0] + sy * g[3] + sz * g[6]);
+          ty = (uj[1] - ui[1]) + (sx * g[1] + sy * g[4] + sz * g[7]);
+          tz = (uj[2] - ui[2]) + (sx * g[2] + sy * g[5] + sz * g[8]);
           rdot = (dx * tx + dy * ty + dz * tz) / r;
         }
         Dual f, df;
@@ -1478,7 +1495,42 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
         pair_phi<OTHER, Dual>(P, el, phx, sA, sb, r, f, df);
         phis += f;
         phidot += df * rdot;
+        if (P.adp) {
+          Dual u, du, w, dw;
+          mishin_polar<Dual>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+          mishin_polar<Dual>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+          const double D[3] = {dx, dy, dz}, Td[3] = {tx, ty, tz};
+          const Dual ud = du * rdot, wd = dw * rdot;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            m[c] += u * D[c];
+            md[c] += ud * D[c] + u * Td[c];
+          }
+          // xx yy zz yz xz xy
+          const int ia[6] = {0, 1, 2, 1, 0, 0}, ib[6] = {0, 1, 2, 2, 2, 1};
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double dd = D[ia[c]] * D[ib[c]];
+            m[3 + c] += w * dd;
+            md[3 + c] += wd * dd + w * (Td[ia[c]] * D[ib[c]] + D[ia[c]] * Td[ib[c]]);
+          }
+        }
       }
+      if (P.adp) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          m[k] = make_dual(wave_sum(m[k].v), wave_sum(m[k].d));
+          md[k] = make_dual(wave_sum(md[k].v), wave_sum(md[k].d));
+        }
+        const Dual nu = m[3] + m[4] + m[5], nud = md[3] + md[4] + md[5];
+        const Dual e = 0.5 * (m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) +
+                       0.5 * (m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + 2.0 * (m[6] * m[6] + m[7] * m[7] + m[8] * m[8])) -
+                       nu * nu / 6.0;
+        const Dual ed = m[0] * md[0] + m[1] * md[1] + m[2] * md[2] + m[3] * md[3] + m[4] * md[4] + m[5] * md[5] +
+                        2.0 * (m[6] * md[6] + m[7] * md[7] + m[8] * md[8]) - nu * nud / 3.0;
+        eadp += cf * e + ed;
+      }
+    }
     rho = make_dual(wave_sum(rho.v), wave_sum(rho.d));
     rhodot = make_dual(wave_sum(rhodot.v), wave_sum(rhodot.d));
     phis = make_dual(wave_sum(phis.v), wave_sum(phis.d));
@@ -1486,8 +1538,7 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
     if (lane == 0) {
       Dual F, dFd;
       el_embed<OTHER, Dual>(P, el, sA, rho, F, dFd);
-      const double c = frame_coeff ? frame_coeff[fr] : 0.0;
-      const Dual L = c * (F + 0.5 * phis) + dFd * rhodot + 0.5 * phidot;
+      const Dual L = cf * (F + 0.5 * phis) + dFd * rhodot + 0.5 * phidot + eadp;
       contrib = L.d;
     }
   }
@@ -1512,8 +1563,8 @@ __global__ __launch_bounds__(64) void eam_const_reduce_kernel(const double *part
 }  // namespace
 
 int64_t eam_constant_count(const EamModel *m) {
-  const int nel = m->p.nel;
-  return 20 * (int64_t)nel + 7 * (int64_t)(nel * (nel + 1) / 2);
+  const int nel = m->p.nel, npt = nel * (nel + 1) / 2;
+  return 20 * (int64_t)nel + 7 * (int64_t)npt + (m->p.adp ? 8 * (int64_t)npt : 0);
 }
 
 void eam_get_constants(const EamModel *m, double *flat) {
@@ -1521,6 +1572,8 @@ void eam_get_constants(const EamModel *m, double *flat) {
   for (int t = 0; t < nel * 20; ++t) flat[t] = m->p.el[t / 20][t % 20];
   // pair types under the Zjw04 mixing rule have no constants of their own: reported as zeros
   for (int t = 0; t < npt * 7; ++t) flat[20 * nel + t] = m->p.phi_kind[t / 7] == 1 ? m->p.phi[t / 7][t % 7] : 0.0;
+  if (m->p.adp)
+    for (int t = 0; t < npt * 8; ++t) flat[20 * nel + 7 * npt + t] = m->p.pair[t / 8][t % 8];
 }
 
 // the constants travel to the kernels by value (EamParams is a kernel argument): no device copy
@@ -1532,18 +1585,24 @@ void eam_update_constants(EamModel *m, const double *flat, int64_t n) {
   for (int t = 0; t < nel * 20; ++t) m->p.el[t / 20][t % 20] = flat[t];
   for (int t = 0; t < npt * 7; ++t)
     if (m->p.phi_kind[t / 7] == 1) m->p.phi[t / 7][t % 7] = flat[20 * nel + t];
+  if (m->p.adp) {
+    for (int pt = 0; pt < npt; ++pt)
+      if (!(flat[20 * nel + 7 * npt + 8 * pt + 6] != 0.0))
+        throw std::invalid_argument("ta_update_constants: the width h of a dipole / quadrupole cutoff must not be 0");
+    for (int t = 0; t < npt * 8; ++t) m->p.pair[t / 8][t % 8] = flat[20 * nel + 7 * npt + t];
+  }
 }
 
 // grad (device, eam_constant_count values); frame_coeff / dR / dh are device pointers (dR and dh both
-// or neither). Plain EAM with analytic functions only.
+// or neither). EAM / ADP with analytic functions only.
 void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *frame_coeff, const double *dR,
                            const double *dh, double *grad, hipStream_t s) {
   const EamParams &P = m->p;
-  if (P.adp || m->pair_nets || m->embed_nets || P.nn_rho || P.nn_embed || P.nn_phi || P.tab_rho || P.tab_embed ||
-      P.tab_phi)
+  if (m->pair_nets || m->embed_nets || P.nn_rho || P.nn_embed || P.nn_phi || P.nn_u || P.nn_w || P.tab_rho ||
+      P.tab_embed || P.tab_phi || P.tab_u || P.tab_w)
     throw std::invalid_argument(
-        "ta_constant_gradient: for EAM models whose rho, phi and F are all analytic (no nn or tabulated "
-        "function, no ADP terms)");
+        "ta_constant_gradient: for EAM / ADP models whose functions are all analytic (no nn or tabulated "
+        "function)");
   const int64_t nq = eam_constant_count(m);
   if (b.n_atoms == 0) {
     (void)hipMemsetAsync(grad, 0, (size_t)nq * sizeof(double), s);

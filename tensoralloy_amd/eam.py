@@ -468,7 +468,7 @@ class EamAlloyNN:
 
     def constants(self) -> np.ndarray:
         out = []
-        for name in self.constant_names():
+        for name in EamAlloyNN.constant_names(self):
             if name is None:
                 out.append(0.0)
                 continue
@@ -693,6 +693,26 @@ class AdpNN(EamAlloyNN):
         p = dict(zip(ADP_KEYS, base if base is not None else [0.0] * 6 + [1.0, 0.0]))
         p.update(over)
         return p
+
+    def constant_names(self):
+        """The EAM slots, then 8 per sorted pair type: the MishinH dipole / quadrupole constants."""
+        names = list(EamAlloyNN.constant_names(self))
+        n = len(self._elements)
+        for i in range(n):
+            for j in range(i, n):
+                key = "".join(sorted([self._elements[i], self._elements[j]]))
+                if self.pair_parameters(key) is None:
+                    names.extend([None] * 8)
+                else:
+                    names.extend([(key, k) for k in ADP_KEYS])
+        return names
+
+    def constants(self) -> np.ndarray:
+        n_eam = len(EamAlloyNN.constant_names(self))
+        out = list(EamAlloyNN.constants(self))
+        for name in self.constant_names()[n_eam:]:
+            out.append(0.0 if name is None else float(self.pair_parameters(name[0])[name[1]]))
+        return np.array(out, dtype=np.float64)
 
     def flat_parameters(self) -> np.ndarray:
         out = list(EamAlloyNN.flat_parameters(self))

@@ -267,7 +267,7 @@ def test_analytic_loss_gradient_matches_oracle(lib, kind):
     assert np.abs(g - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kind", ["zjw04", "alloy", "zjw04xc", "zjw04xcp", "sutton90", "be/1", "grimes"])
+@pytest.mark.parametrize("kind", ["zjw04", "alloy", "zjw04xc", "zjw04xcp", "sutton90", "be/1", "grimes", "adp", "adp_alloy"])
 def test_empirical_constant_gradient(lib, kind):
     """The reference trains the constants of its empirical potentials (potentials.py:129-163).
     `ta_constant_gradient` = d/dconstants of  sum_f c_f E_f + sum u.F + sum Y:W  (the model-dependent
@@ -291,6 +291,12 @@ def test_empirical_constant_gradient(lib, kind):
         nn, frames = make_eam(["Ag"], 7.0, potential="sutton90"), [fcc("Ag", a=4.09, rep=(2, 2, 2), jitter=0.08)]
     elif kind == "be/1":
         nn, frames = make_eam(["Be"], 5.0, potential="Be/1"), [hcp(rep=(3, 3, 3), jitter=0.05, seed=4)]
+    elif kind == "adp":       # Zjw04 rho / phi / F + MishinH dipole and quadrupole functions (mishin.py:62-66)
+        nn, frames = make_eam(["Ni"], 6.0, adp=True), [fcc(rep=(2, 2, 2), jitter=0.1), fcc(rep=(2, 2, 2), a=3.4, seed=3, jitter=0.05)]
+    elif kind == "adp_alloy":
+        # (a frame whose densities stay clear of the embedding thresholds: with Ni2Mo one Mo atom sits at
+        # rho / rho_e = 1.15 + 6e-5 and any usable stencil straddles the branch)
+        nn, frames = make_eam(["Mo", "Ni"], 6.0, adp=True), [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 2))]
     else:
         nn, frames = make_eam(["Pu"], 6.0, potential="grimes"), [fcc("Pu", a=4.6, rep=(2, 2, 2), jitter=0.08)]
     F = len(frames)
@@ -315,7 +321,8 @@ def test_empirical_constant_gradient(lib, kind):
         delta = np.where(live, 1e-6 * rng.normal(0, 1, len(flat)) * np.maximum(np.abs(flat), 1e-2), 0.0)
         eng.update_constants(flat + delta)
         e1 = np.dot(c, eng.energies(reuse_descriptors=False))
-        assert abs((e1 - e0) - np.dot(grad_e, delta)) < 1e-3 * abs(np.dot(grad_e, delta)) + 1e-12
+        # (tolerance against the size of the individual terms: their sum may cancel, the second order does not)
+        assert abs((e1 - e0) - np.dot(grad_e, delta)) < 1e-3 * np.sum(np.abs(grad_e * delta)) + 1e-12
     oframes = [(a.get_chemical_symbols(), a.positions, np.asarray(a.get_cell(complete=True)), a.pbc) for a in frames]
 
     def functional(slot, value, energy_only=False):
@@ -345,11 +352,13 @@ def test_empirical_constant_gradient(lib, kind):
             assert abs(grad_e[slot] - fd_e) < 2e-8 * max(abs(fd_e), 1e-3 * scale) + 1e-9, (name, grad_e[slot], fd_e)
         checked += 1
     assert checked >= 2
-    # models with nn or tabulated functions, or ADP terms, are refused
-    with Engine(make_eam(["Ni"], 6.0, adp=True)) as eng:
-        eng.set_frames(frames[:1]) if kind == "zjw04" else eng.set_frames([fcc(rep=(2, 2, 2))])
-        with pytest.raises(ValueError):
-            eng.constant_gradient(np.ones(1), None, None)
+    # models with nn (or tabulated) functions are refused, not approximated
+    if kind == "zjw04":
+        mixed = {"Ni": {"rho": "zjw04", "embed": "nn"}, "NiNi": {"phi": "zjw04"}}
+        with Engine(make_eam(["Ni"], 6.0, potential=mixed, hidden_sizes=[8])) as eng:
+            eng.set_frames(frames[:1])
+            with pytest.raises(ValueError):
+                eng.constant_gradient(np.ones(1), None, None)
 
 
 def test_fit_of_empirical_constants_recovers_a_teacher(lib):
