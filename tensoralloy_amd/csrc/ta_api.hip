@@ -179,8 +179,8 @@ struct ta_context {
   DevBuf<double> results;
   size_t o_blk = 0;  // byte offset of blk_center in the packed input
   DevBuf<double> rec, part4, G, dEdG, g, wat, bpart, benergy, mlp_scratch;
-  DevBuf<unsigned long long> masks, job_mask;
-  DevBuf<unsigned short> job_code;
+  DevBuf<unsigned long long> masks;
+  DevBuf<uint32_t> job_word;
   DevBuf<int32_t> job_count;
   DevBuf<int32_t> pair_start, seg_start, pair_i, pair_j, pair_shift, pair_rev;
   ta::NlGrid *d_grids = nullptr;  // view into inbuf
@@ -825,7 +825,7 @@ int ta_destroy(ta_handle h) {
   for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start,
                   &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk})
     b->release();
-  h->masks.release(); h->job_mask.release(); h->job_code.release(); h->job_count.release();
+  h->masks.release(); h->job_word.release(); h->job_count.release();
   for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
                   &h->nl_bin_atoms, &h->nl_counts})
     b->release();
@@ -850,11 +850,9 @@ void ensure_job_lists(ta_context *h, size_t n_blk) {
     return;
   }
   const int stride = ta::v2_job_stride(h->db.cap);
-  h->job_mask.ensure(n_blk * (size_t)stride + 8);
-  h->job_code.ensure(n_blk * (size_t)stride + 8);
+  h->job_word.ensure(n_blk * (size_t)stride + 8);
   h->job_count.ensure(n_blk + 8);
-  h->db.job_mask = h->job_mask.ptr;
-  h->db.job_code = h->job_code.ptr;
+  h->db.job_word = h->job_word.ptr;
   h->db.job_count = h->job_count.ptr;
   h->db.job_stride = stride;
 }

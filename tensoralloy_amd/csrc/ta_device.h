@@ -77,12 +77,12 @@ struct DeviceBatch {
                             // of the forward, backward and gather kernels; 1/r is recomputed)
   double *part4 = nullptr;  // [nel*n_ang][P] per-pair partial angular sums
   unsigned long long *masks = nullptr;  // [ceil(nnl_max/128)][P] candidate masks, forward -> backward
-  // Lane balance of the angular kernels: the forward kernel cuts every lane's surviving partners
-  // into jobs of <= K set bits, sorts them by size and leaves the list here for the backward
-  // kernel: per workgroup `job_count[blk]` jobs at [blk * job_stride ..): 64-bit partner mask and
-  // 16-bit code (item of the workgroup). null: the per-lane masks above are used.
-  unsigned long long *job_mask = nullptr;
-  unsigned short *job_code = nullptr;
+  // Lane balance of the angular kernels: the forward kernel cuts every lane's 64 candidate positions
+  // into four windows of 16, makes every non-empty window a job, sorts the jobs by size and leaves
+  // the list here for the backward kernel: per workgroup `job_count[blk]` words at
+  // [blk * job_stride ..): bits 0-7 the pair (item of the workgroup), bits 8-9 the window, bits
+  // 16-31 the window's candidate bits. null: the per-lane masks above are used.
+  uint32_t *job_word = nullptr;
   int32_t *job_count = nullptr;
   int job_stride = 0;
   double *G = nullptr;      // [N][D]

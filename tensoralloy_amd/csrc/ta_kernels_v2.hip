@@ -199,15 +199,21 @@ __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, c
   const float lim = (float)(sf.acut * sf.acut) * 1.0001f;
   unsigned long long mask = 0ull;
   const int count = smax - sc + 1;  // candidates wanted in this block of 64 (may exceed 64)
+  // two candidates per instruction: gfx950 has packed fp32 add / mul / fma (v_pk_*_f32), so the
+  // difference vectors and the squared distances of candidates k, k + 1 are formed together
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
   for (int g = 0; g < 4 && 16 * g < count; ++g) {
     const float *px = f.xf + ring + sc + 16 * g, *py = f.yf + ring + sc + 16 * g,
                 *pz = f.zf + ring + sc + 16 * g;
     unsigned m = 0u;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float ex = px[k] - ax, ey = py[k] - ay, ez = pz[k] - az;
-      const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
-      m |= (d2 < lim) ? (1u << k) : 0u;
+    for (int k = 0; k < 16; k += 2) {
+      const f32x2 vx = {px[k], px[k + 1]}, vy = {py[k], py[k + 1]}, vz = {pz[k], pz[k + 1]};
+      const f32x2 ex = vx - ax2, ey = vy - ay2, ez = vz - az2;
+      const f32x2 d2 = __builtin_elementwise_fma(ex, ex, __builtin_elementwise_fma(ey, ey, ez * ez));
+      m |= (d2.x < lim) ? (1u << k) : 0u;
+      m |= (d2.y < lim) ? (2u << k) : 0u;
     }
     mask |= (unsigned long long)m << (16 * g);
   }
@@ -258,33 +264,23 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
   }
 }
 
-// Finer lane balance than the re-dealing above: the surviving partners of every lane are cut into
-// JOBS of at most K set bits; full jobs (exactly K bits) are laid out by a prefix sum over the
-// lanes, the remainders (one per lane, 1 .. K-1 bits) follow sorted by size, largest first
-// (counting sort: one LDS atomic per remainder over K - 1 buckets); lane t then takes jobs t,
-// t + T, ... CPU simulation on the benchmark frame: 73 % (re-dealing) -> 91-94 % busy lanes in the
-// triple loops (K = 12 / 8). The list aliases the fp32 rings (dead once the masks exist), is written
-// to HBM by the forward kernel and read back by the backward kernel: one construction serves both
-// sweeps.
-__device__ __forceinline__ unsigned long long peel_bits(unsigned long long &m, int K) {
-  unsigned long long rest = m;
-  for (int k = 0; k < K && rest; ++k) rest &= rest - 1;
-  const unsigned long long sub = m ^ rest;
-  m = rest;
-  return sub;
-}
-
+// Finer lane balance than the re-dealing above: JOBS (see make_jobs). CPU simulation on the benchmark
+// frame: 73 % (re-dealing) -> 91-94 % busy lanes in the triple loops. The list aliases the fp32 rings
+// (dead once the masks exist), is written to HBM by the forward kernel and read back by the backward
+// kernel: one construction serves both sweeps.
 struct JobLists {
-  unsigned long long *mask;  // [max_items]
-  unsigned short *code;      // [max_items]
+  uint32_t *word;            // [4 * lanes]: pair | window << 8 | bits << 16
   int *hist, *start, *ctl;   // [66], [66], [8]
 };
 
-__device__ __forceinline__ JobLists job_lists(const Fields &f, int max_items) {
+__device__ __forceinline__ JobLists job_lists(const Fields &f) {
   JobLists j;
-  j.mask = reinterpret_cast<unsigned long long *>(f.xf);
-  j.code = reinterpret_cast<unsigned short *>(j.mask + max_items);
+  j.word = reinterpret_cast<uint32_t *>(f.xf);  // the fp32 rings are dead once the masks exist
   return j;
+}
+__device__ __forceinline__ int job_item(uint32_t w) { return (int)(w & 255u); }
+__device__ __forceinline__ unsigned long long job_bits(uint32_t w) {
+  return (unsigned long long)(w >> 16) << (16 * ((w >> 8) & 3u));
 }
 
 // byte offset of the job counters (hist[66], start[66], ctl[8] ints: 640 bytes reserved) and, behind
@@ -293,59 +289,56 @@ __host__ __device__ inline size_t v2_counter_offset(int cap) {
   const size_t end = (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap;
   return (end + 15) & ~(size_t)15;
 }
-__host__ __device__ inline int v2_max_jobs(int cap) { return (int)(3 * (size_t)(2 * cap + kRingPad) * sizeof(float) / 10); }
+// four jobs per lane at most; the words fit the rings: 4 * 4 cap <= 3 * 4 (2 cap + 64) bytes
+__host__ __device__ inline int v2_max_jobs(int cap) { return 4 * cap; }
 
-// `j.hist` must be zero on entry (the kernel clears it before staging). Three barriers per attempt;
-// K = 8 unless the list would overflow (then 16, 32, 64: at most one job per lane).
-__device__ __forceinline__ int make_jobs(JobLists &j, int max_items, bool active, int item,
-                                         unsigned long long m0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
-  const int p0 = active ? __popcll(m0) : 0;
-  for (int K = 8;; K *= 2) {
-    const int f0 = p0 / K, r0 = p0 - f0 * K;
-    int incl = f0;
+// `j.hist` must be zero on entry (the kernel clears it before staging).
+// Jobs by POSITION: a lane's 64-bit candidate mask is cut into four windows of 16 positions; every
+// non-empty window is one job (a 32-bit word). Sorted by size, largest first (counting sort over
+// the popcounts: one LDS atomic per job, one wavefront scans the 16 buckets); the sweep deals them
+// to the lanes in serpentine rounds (job_slot), so a wavefront holds jobs of nearly equal size in
+// every round and the wavefronts of a workgroup get large and small rounds alike. Replaces the cut
+// into jobs of exactly K = 8 set bits, whose bit-peeling loops and prefix sums were 2.5 M of the
+// forward kernel's 17.4 M VALU instructions, and its 10-byte (mask, code) records.
+__device__ __forceinline__ int make_jobs(JobLists &j, bool active, int item, unsigned long long m0) {
+  const int tid = threadIdx.x;
+  int cnt[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
+  if (active) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
+    for (int w = 0; w < 4; ++w) {
+      const int c = __popc((unsigned)((m0 >> (16 * w)) & 0xffffull));
+      cnt[w] = c;
+      if (c) rank[w] = atomicAdd(&j.hist[16 - c], 1);
     }
-    if (lane == 63) j.ctl[wave] = incl;  // wave totals of the full jobs
-    int rank0 = 0;
-    if (r0) rank0 = atomicAdd(&j.hist[K - r0], 1);
-    __syncthreads();  // also: every lane is done with the rings (its mask exists)
-    int base = incl - f0, n_full = 0;
-    for (int w = 0; w < nwaves; ++w) {
-      const int t = j.ctl[w];
-      if (w < wave) base += t;
-      n_full += t;
-    }
-    int before = 0, n_rem = 0;  // remainders larger than this lane's, and all of them
-    for (int k = 1; k < K; ++k) {
-      const int c = j.hist[k];
-      before += (k < K - r0) ? c : 0;
-      n_rem += c;
-    }
-    if (n_full + n_rem <= max_items || K >= 64) {
-      if (active) {
-        unsigned long long w = m0;
-        for (int q = 0; q < f0; ++q) {
-          j.mask[base] = peel_bits(w, K);
-          j.code[base++] = (unsigned short)item;
-        }
-        if (r0) {
-          const int slot = n_full + before + rank0;
-          j.mask[slot] = w;
-          j.code[slot] = (unsigned short)item;
-        }
-      }
-      __syncthreads();
-      return n_full + n_rem;
-    }
-    __syncthreads();  // overflow: clear the histogram and try a coarser cut
-    if (tid < 66) j.hist[tid] = 0;
-    __syncthreads();
   }
+  __syncthreads();  // also: every lane is done with the rings (its mask exists)
+  if (tid < 64) {
+    const int v = tid < 16 ? j.hist[tid] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int u = __shfl_up(incl, off);
+      if (tid >= off) incl += u;
+    }
+    if (tid < 16) j.start[tid] = incl - v;
+    if (tid == 15) j.start[16] = incl;
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (cnt[w]) {
+        const int slot = j.start[16 - cnt[w]] + rank[w];
+        j.word[slot] = (uint32_t)item | ((uint32_t)w << 8) | ((uint32_t)((m0 >> (16 * w)) & 0xffffull) << 16);
+      }
+  }
+  const int n = j.start[16];
+  __syncthreads();
+  return n;
 }
+
+// job of lane `tid` in round `r` (T lanes): serpentine over the size-sorted list
+__device__ __forceinline__ int job_slot(int r, int tid, int T) { return r * T + ((r & 1) ? T - 1 - tid : tid); }
 
 // Descriptor vectors of the workgroup's centres from data that is still in LDS, one wavefront per
 // centre, round robin. G2 from r^2 (sf.py:79-119):
@@ -579,29 +572,32 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       const int i = b.pair_i[p];
       const int base = b.pair_start[i] - s0;
       const int smax = (f.H[item] != 0.0) ? n_own / 2 : 0;
-      if (smax > 0) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
+      if (smax > 0 && !(flags & (1 << 25))) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
       if (b.masks) b.masks[p] = mask;
     }
     if (b.job_count) {
       // job mode (see make_jobs): build the list once, leave it for the backward kernel, sweep it
       char *raw = reinterpret_cast<char *>(lds);
-      JobLists jl = job_lists(f, v2_max_jobs(b.cap));
+      JobLists jl = job_lists(f);
       jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
       jl.start = jl.hist + 66;
       jl.ctl = jl.start + 66;
       double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
-      const int n_jobs = make_jobs(jl, v2_max_jobs(b.cap), active, item, mask);
+      const int n_jobs = make_jobs(jl, active, item, mask);
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
       if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
-      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x) {
-        b.job_mask[jbase + slot] = jl.mask[slot];
-        b.job_code[jbase + slot] = jl.code[slot];
-      }
-      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x)
-        run_item((int)jl.code[slot], true, jl.mask[slot], nullptr, P);
+      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x) b.job_word[jbase + slot] = jl.word[slot];
+      if (!(flags & (1 << 27)))
+        for (int r = 0; r * (int)blockDim.x < n_jobs; ++r) {
+          const int slot = job_slot(r, threadIdx.x, blockDim.x);
+          if (slot < n_jobs) {
+            const uint32_t jw = jl.word[slot];
+            run_item(job_item(jw), true, job_bits(jw), nullptr, P);
+          }
+        }
       __syncthreads();
       if (flags & 4) {
-        reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
         reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
         return;
       }
@@ -839,8 +835,13 @@ __global__ __launch_bounds__(kBlock)
     const int n_jobs = (one_pass && b.job_count) ? b.job_count[blockIdx.x] : -1;
     if (n_jobs >= 0) {  // the forward kernel's job list (see make_jobs): no scan, no sort here
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
-      for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x)
-        run_item((int)b.job_code[jbase + slot], true, b.job_mask[jbase + slot]);
+      for (int r = 0; r * (int)blockDim.x < n_jobs; ++r) {
+        const int slot = job_slot(r, threadIdx.x, blockDim.x);
+        if (slot < n_jobs) {
+          const uint32_t jw = b.job_word[jbase + slot];
+          run_item(job_item(jw), true, job_bits(jw));
+        }
+      }
     } else if (one_pass) {  // see deal_by_popcount
       unsigned long long mask = 0ull;
       if (active) {
@@ -974,6 +975,8 @@ int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 static int stagger_bits(const DeviceBatch &b, const char *var) {
   const char *e = getenv(var);
   if (getenv("TA_DEBUG_NO_TRIPLES")) return 1 << 24;  // instruction accounting (wrong results)
+  // more accounting switches (wrong results): bit 0 triple bodies, 1 candidate scan, 2 G2 sums, 3 job sweep
+  if (const char *d = getenv("TA_DEBUG_SKIP")) return (atoi(d) & 15) << 24;
   if (!e) return 0;
   int n = 0, shift = 3;
   if (sscanf(e, "%d,%d", &n, &shift) < 1) return 0;
