@@ -117,8 +117,10 @@ __device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &c
 // `geom` != 0: the pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps, 1/r
 // (reference calculate_rij, transformer/universal.py:448-474) is computed here
 // and the pair record written for the later kernels; otherwise it is read.
+// `fc_in_G`: the forward kernel has no use for G = (dH/dr)/r and keeps the cutoff value fc(r; acut)
+// there instead, for its G2 sums (same cutoff whenever rcut == acut).
 __device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
-                                      const Fields &f, int s0, int M, int geom = 0) {
+                                      const Fields &f, int s0, int M, int geom = 0, bool fc_in_G = false) {
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
     double2 v0, v1, v2;
     if (geom) {
@@ -177,7 +179,7 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       cutoff_u(sf.cutoff, u, fc, dfdu);
       const double e = ta_exp(-beta * u);
       H = e * fc;
-      G = e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
+      G = fc_in_G ? fc : e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
     }
     f.H[item] = H;
     f.G[item] = G;
@@ -346,6 +348,11 @@ __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const
                                                        const Fields &f, int c0, int c1, int s0) {
   const int nel = sf.n_elements;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  // the usual grid has omega = 0 for every channel: exp(-eta r^2 / rc^2), no square root; and with
+  // rcut == acut the staging phase has left fc(r) in Fields::G (uniform tests, scalar unit)
+  bool no_shift = true;
+  for (int c = 0; c < sf.n_rad; ++c) no_shift = no_shift && sf.omega[c] == 0.0;
+  const bool fc_staged = sf.rcut == sf.acut && sf.angular;
   for (int64_t i = c0 + w; i < c1; i += nwaves) {
     const int sA = b.species[i];
     const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
@@ -358,13 +365,21 @@ __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const
         for (int q = q0 + l; q < q1; q += 64) {
           const double r2 = f.r2[q];
           const double u = r2 * sf.inv_rc2;
-          const double r = sqrt(r2);
-          const double fc = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
+          const double fc = fc_staged ? f.G[q] : ((u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0);
+          if (no_shift) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = (cc + k < sf.n_rad) ? cc + k : cc;
-            const double dr = r - sf.omega[c];
-            acc[k] += ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2) * fc;  // sf.py:101-108
+            for (int k = 0; k < 4; ++k) {
+              const int c = (cc + k < sf.n_rad) ? cc + k : cc;
+              acc[k] += ta_exp(-sf.eta[c] * u) * fc;  // sf.py:101-108 with omega = 0
+            }
+          } else {
+            const double r = sqrt(r2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int c = (cc + k < sf.n_rad) ? cc + k : cc;
+              const double dr = r - sf.omega[c];
+              acc[k] += ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2) * fc;  // sf.py:101-108
+            }
           }
         }
 #pragma unroll
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * b.cap; k += blockDim.x) P0[k] = 0.0;
   }
-  stage(sf, beta, b, f, s0, M, geom);
+  stage(sf, beta, b, f, s0, M, geom, true);
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
