@@ -178,7 +178,7 @@ struct ta_context {
   DevBuf<char> inbuf;
   DevBuf<double> results;
   size_t o_blk = 0;  // byte offset of blk_center in the packed input
-  DevBuf<double> rec, part4, G, dEdG, g, wat, bpart, benergy, mlp_scratch;
+  DevBuf<double> rec, part4, G, dEdG, g, wat, bpart, fown, benergy, mlp_scratch;
   DevBuf<unsigned long long> masks;
   DevBuf<uint32_t> job_word;
   DevBuf<int32_t> job_count;
@@ -494,6 +494,7 @@ void upload_batch(ta_context *h) {
   h->g.ensure(4 * P);
   h->wat.ensure(9 * N);
   h->bpart.ensure(10 * ((N + 15) / 16) + 10);
+  h->fown.ensure(12 * N + 12);
   h->results.ensure(10 * F + 4 * N);
   h->benergy.ensure(1);
 
@@ -511,6 +512,7 @@ void upload_batch(ta_context *h) {
   db.g = h->g.ptr;
   db.wat = h->wat.ptr;
   db.bpart = h->bpart.ptr;
+  db.fown = h->fown.ptr;
   db.energy = h->results.ptr;
   db.virial = h->results.ptr + F;
   db.eatom = h->results.ptr + 10 * F;
@@ -583,6 +585,7 @@ void fill_pairs_on_device(ta_context *h) {
 void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   using namespace ta;
   h->db.rec4 = nullptr;  // only the second-generation angular path below sets it
+  h->db.own_sums = 0;    // likewise
   const DeviceBatch &db = h->db;
   hipStream_t s = h->stream;
   const bool need_forces = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
@@ -647,11 +650,15 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       begin(TA_K_BACKWARD);
       if (h->sf.angular) {
         bool first = true;
-        if (h->use_v2)
-          for (const ChunkPlan &cp : h->chunks_v2) {
-            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+        if (h->use_v2) {
+          // the last launch leaves the per-atom own-side sums for force_gather
+          h->db.own_sums = getenv("TA_NO_OWN_SUMS") ? 0 : 1;
+          for (size_t k = 0; k < h->chunks_v2.size(); ++k) {
+            const ChunkPlan &cp = h->chunks_v2[k];
+            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, h->db.own_sums && k + 1 == h->chunks_v2.size(), db, s);
             first = false;
           }
+        }
         else
           for (const ChunkPlan &cp : h->chunks) {
             launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
@@ -816,7 +823,7 @@ int ta_destroy(ta_handle h) {
   if (h->grap) ta::grap_destroy(h->grap);
   h->stage_in.release(); h->stage_out.release(); h->inbuf.release(); h->results.release();
   h->rec.release(); h->part4.release(); h->G.release();
-  h->dEdG.release(); h->g.release(); h->wat.release(); h->bpart.release();
+  h->dEdG.release(); h->g.release(); h->wat.release(); h->bpart.release(); h->fown.release();
   h->benergy.release(); h->mlp_scratch.release();
   h->train_scratch.release(); h->train_partial.release(); h->train_grad.release(); h->train_coeff.release();
   h->jvp_J.release(); h->tan_dD.release(); h->tan_dG.release(); h->tan_dir.release();
@@ -1509,7 +1516,7 @@ void backward_only(ta_context *h) {
       bool first = true;
       if (h->use_v2)
         for (const ChunkPlan &cp : h->chunks_v2) {
-          launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
+          launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, false, db, s);
           first = false;
         }
       else

@@ -348,6 +348,45 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
   const bool active = i < b.n_atoms;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int q0 = active ? b.pair_start[i] : 0, q1 = active ? b.pair_start[i + 1] : 0;
+  if (b.own_sums) {
+    // the backward kernel left sum_p g[p] and the virial rows per atom: only g[rev p] is gathered
+    // (36 bytes per pair instead of 100)
+    for (int qb = q0 + lane; qb < q1; qb += 64) {
+      int r[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = qb + 16 * k;
+        ok[k] = q < q1;
+        r[k] = ok[k] ? b.pair_rev[q] : 0;
+      }
+      double gr[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double2 *grp = reinterpret_cast<const double2 *>(b.g + 4 * (size_t)r[k]);
+        const double2 c0 = grp[0], c1 = grp[1];
+        gr[k][0] = c0.x;
+        gr[k][1] = c0.y;
+        gr[k][2] = c1.x;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) {
+          f[0] -= gr[k][0];
+          f[1] -= gr[k][1];
+          f[2] -= gr[k][2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = row16_sum(f[k]);
+    if (lane == 0 && active) {
+      const double *own = b.fown + 12 * (size_t)i;
+      for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k] + own[k];
+      for (int k = 0; k < 9; ++k) w[k] = own[3 + k];
+    }
+    block_partials(b, blockIdx.x, i, active, lane == 0, w);
+    return;
+  }
   // batches of 4 strided pairs: the 4 reverse indices, then all 4 x 9 operands, are in flight
   // together, so a batch costs two memory latencies instead of eight
   for (int qb = q0 + lane; qb < q1; qb += 64) {
