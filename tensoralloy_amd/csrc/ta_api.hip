@@ -691,6 +691,7 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
     used[TA_K_MLP] = true;
     if (need_forces) {
       begin(TA_K_BACKWARD);
+      h->db.own_sums = getenv("TA_NO_OWN_SUMS") ? 0 : 1;  // one wavefront per centre: the sums are nearly free there
       launch_grap_backward(h->grap, db, s);
       end(TA_K_BACKWARD);
       used[TA_K_BACKWARD] = true;

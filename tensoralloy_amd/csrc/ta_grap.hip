@@ -353,6 +353,9 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
   for (int t = lane; t < nd * kMaxMom; t += kWave) Tl[t] = g.T[t];
   for (int t = lane; t < 4 * K; t += kWave) FP[t] = g.fp[t];
   for (int t = lane; t < ndim; t += kWave) wrow[t] = b.dEdG[(size_t)i * ndim + t];
+  // own-side sums of this centre for force_gather (DeviceBatch::fown): after the row exchange below all
+  // four 16-lane rows hold a pair's dE/dD, so row 0 sums g and row c + 1 sums g_c D (the virial row)
+  double own[3] = {0.0, 0.0, 0.0};
   for (int sb = 0; sb < nel; ++sb) {
     const int lo = seg[sb], hi = seg[sb + 1];
     if (lo == hi) continue;
@@ -462,7 +465,20 @@ __global__ __launch_bounds__(kWave) void grap_backward_kernel(GrapParams g, Devi
           dst[1] = gy;
           dst[2] = gz;
         }
+        if (ta < n) {
+          const double gc = q4 == 1 ? gx : (q4 == 2 ? gy : gz);
+          own[0] += q4 == 0 ? gx : gc * (r * ux);
+          own[1] += q4 == 0 ? gy : gc * (r * uy);
+          own[2] += q4 == 0 ? gz : gc * (r * uz);
+        }
       }
+    }
+  }
+  if (b.own_sums) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const double v = row16_sum(own[e]);
+      if (m16 == 0) b.fown[12 * (size_t)i + 3 * q4 + e] = v;
     }
   }
 }
