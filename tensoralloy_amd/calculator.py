@@ -322,9 +322,11 @@ class TensorAlloyCalculator(BaseCalculator):
                 results[target] = np.array([[v[0], v[5], v[4]], [v[5], v[1], v[3]], [v[4], v[3], v[2]]])
             elif target in ("energy/atom", "atomic"):
                 # GSL order, virtual row stripped (atomic.py:289-299)
-                results[target] = vap.map_array(res["atomic"].reshape(-1, 1))[1:, 0]
+                results[target] = res["atomic"] if vap.is_identity else \
+                    vap.map_array(res["atomic"].reshape(-1, 1))[1:, 0]
             elif target == "forces":
-                results[target] = vap.map_forces(res["forces"])[1:]
+                # (identity map: GSL order is the caller's order, no gather through a padded copy)
+                results[target] = res["forces"] if vap.is_identity else vap.map_forces(res["forces"])[1:]
                 local_forces = res["forces"]
             elif target in ("stress", "virial", "total_pressure"):
                 if target not in res:

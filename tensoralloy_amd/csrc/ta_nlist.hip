@@ -311,6 +311,72 @@ __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, 
   }
 }
 
+// Workgroup packing of the angular kernels on the device: runs of whole centres with <= cap pairs and
+// <= kMaxCentersPerBlock centres, greedy inside chunks of 32 consecutive centres (a chunk end closes
+// a run), one lane per chunk walking the chunk's offsets in LDS; the runs of all chunks are laid
+// out by a prefix sum. One workgroup, rounds of 8192 centres.
+constexpr int kPackChunk = 32, kPackRound = 8192;
+
+struct PackArgs {
+  int cap;
+  const int32_t *pair_start;
+  int32_t *blk_center, *n_blk_out;
+  int max_blk;
+};
+
+// body: one workgroup of 256 or 1024 lanes (lane t walks centres [32 t, 32 t + 32) of a round)
+__device__ __forceinline__ void pack_blocks_body(int n_atoms, const PackArgs &pk) {
+  __shared__ int ps[kPackRound + 1];
+  __shared__ int cnt[16];
+  __shared__ int total;
+  const int t = threadIdx.x, T = blockDim.x;
+  const int cap = pk.cap, max_blk = pk.max_blk;
+  const int32_t *pair_start = pk.pair_start;
+  int32_t *blk_center = pk.blk_center;
+  int base = 0;
+  for (int r0 = 0; r0 < n_atoms; r0 += kPackRound) {
+    const int nr = min(kPackRound, n_atoms - r0);
+    for (int idx = t; idx <= nr; idx += T) ps[idx] = pair_start[r0 + idx];
+    __syncthreads();
+    const int lo = min(nr, t * kPackChunk), hi = min(nr, lo + kPackChunk);
+    int nb = 0, load = 0, nc = 0;
+    for (int i = lo; i < hi; ++i) {
+      const int k = ps[i + 1] - ps[i];
+      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
+        ++nb;
+        load = 0;
+        nc = 0;
+      }
+      load += k;
+      ++nc;
+    }
+    const int incl = block_scan_1024(nb, cnt);
+    int slot = base + incl - nb;
+    load = 0;
+    nc = 0;
+    for (int i = lo; i < hi; ++i) {
+      const int k = ps[i + 1] - ps[i];
+      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
+        if (slot < max_blk) blk_center[slot] = r0 + i;
+        ++slot;
+        load = 0;
+        nc = 0;
+      }
+      load += k;
+      ++nc;
+    }
+    if (t == T - 1) total = base + incl;
+    __syncthreads();
+    base = total;
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int nb = min(base, max_blk);
+    blk_center[nb] = n_atoms;
+    *pk.n_blk_out = nb;
+  }
+}
+
 // ---- MD loop: the exact list of a step from the resident skin list ------------------------------
 // The resident list covers rmax + skin (ta_set_skin); while it is valid, the pairs inside rmax at the
 // CURRENT positions are a subset of it. These kernels extract that subset, in the same order and
@@ -323,7 +389,16 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(int n_atoms, int nel, do
                                                         const int32_t *seg_super, const int32_t *pj_super,
                                                         const int32_t *ps_super, int32_t *counts,
                                                         const int32_t *seg_exact, int32_t *pi_out,
-                                                        int32_t *pj_out, int32_t *ps_out, int32_t *map) {
+                                                        int32_t *pj_out, int32_t *ps_out, int32_t *map,
+                                                        unsigned long long *stats_zero, PackArgs pk) {
+  // side jobs that saved two launches on the MD step: the counting pass clears the statistics words
+  // the scan / finish_starts kernels behind it accumulate into; the filling pass has one extra
+  // workgroup (the last) that packs the angular kernels' workgroups from the new pair_start
+  if (MODE == 0 && stats_zero && blockIdx.x == 0 && threadIdx.x < 8) stats_zero[threadIdx.x] = 0ull;
+  if (MODE == 1 && pk.blk_center && blockIdx.x == gridDim.x - 1) {
+    pack_blocks_body(n_atoms, pk);
+    return;
+  }
   const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= n_atoms) return;
@@ -374,63 +449,6 @@ __global__ __launch_bounds__(kBlock) void filter_rev_kernel(int64_t n_super, con
   if (q >= n_super) return;
   const int slot = map[q];
   if (slot >= 0) rev_out[slot] = map[rev_super[q]];
-}
-
-// Workgroup packing of the angular kernels on the device: runs of whole centres with <= cap pairs and
-// <= kMaxCentersPerBlock centres, greedy inside chunks of 32 consecutive centres (a chunk end closes
-// a run), one lane per chunk walking the chunk's offsets in LDS; the runs of all chunks are laid
-// out by a prefix sum. One workgroup, rounds of 8192 centres.
-constexpr int kPackChunk = 32, kPackRound = 8192;
-
-__global__ __launch_bounds__(1024) void pack_blocks_kernel(int n_atoms, int cap, const int32_t *pair_start,
-                                                           int32_t *blk_center, int32_t *n_blk_out,
-                                                           int max_blk) {
-  __shared__ int ps[kPackRound + 1];
-  __shared__ int cnt[16];
-  __shared__ int total;
-  const int t = threadIdx.x;
-  int base = 0;
-  for (int r0 = 0; r0 < n_atoms; r0 += kPackRound) {
-    const int nr = min(kPackRound, n_atoms - r0);
-    for (int idx = t; idx <= nr; idx += 1024) ps[idx] = pair_start[r0 + idx];
-    __syncthreads();
-    const int lo = min(nr, t * kPackChunk), hi = min(nr, lo + kPackChunk);
-    int nb = 0, load = 0, nc = 0;
-    for (int i = lo; i < hi; ++i) {
-      const int k = ps[i + 1] - ps[i];
-      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
-        ++nb;
-        load = 0;
-        nc = 0;
-      }
-      load += k;
-      ++nc;
-    }
-    const int incl = block_scan_1024(nb, cnt);
-    int slot = base + incl - nb;
-    load = 0;
-    nc = 0;
-    for (int i = lo; i < hi; ++i) {
-      const int k = ps[i + 1] - ps[i];
-      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
-        if (slot < max_blk) blk_center[slot] = r0 + i;
-        ++slot;
-        load = 0;
-        nc = 0;
-      }
-      load += k;
-      ++nc;
-    }
-    if (t == 1023) total = base + incl;
-    __syncthreads();
-    base = total;
-    __syncthreads();
-  }
-  if (t == 0) {
-    const int nb = min(base, max_blk);
-    blk_center[nb] = n_atoms;
-    *n_blk_out = nb;
-  }
 }
 
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -549,23 +567,23 @@ void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double 
                int32_t *rev_out, unsigned long long *stats, int cap, int32_t *blk_center, int32_t *n_blk_dev,
                int max_blk, hipStream_t s) {
   if (n_atoms == 0) return;
-  (void)hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), s);
   const dim3 agrid(nblk((int64_t)n_atoms * 64, kBlock));
+  PackArgs none{};
   hipLaunchKernelGGL(filter_kernel<0>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
                      seg_super, pj_super, ps_super, counts, (const int32_t *)nullptr, (int32_t *)nullptr,
-                     (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                     (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, stats, none);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), counts, seg_exact,
                      reinterpret_cast<int32_t *>(stats) + 4);
   hipLaunchKernelGGL(finish_starts_kernel, dim3(nblk(n_atoms + 1, kBlock)), dim3(kBlock), 0, s, n_atoms, nel,
                      seg_exact, counts, pair_start, stats, reinterpret_cast<int32_t *>(stats) + 2, stats + 4);
-  hipLaunchKernelGGL(filter_kernel<1>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
-                     seg_super, pj_super, ps_super, (int32_t *)nullptr, seg_exact, pi_out, pj_out, ps_out, map);
+  const PackArgs pk{cap, pair_start, blk_center, n_blk_dev, max_blk};
+  const dim3 fgrid(agrid.x + (blk_center ? 1u : 0u));
+  hipLaunchKernelGGL(filter_kernel<1>, fgrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
+                     seg_super, pj_super, ps_super, (int32_t *)nullptr, seg_exact, pi_out, pj_out, ps_out, map,
+                     (unsigned long long *)nullptr, pk);
   if (n_super > 0)
     hipLaunchKernelGGL(filter_rev_kernel, dim3(nblk(n_super, kBlock)), dim3(kBlock), 0, s, n_super, rev_super,
                        map, rev_out);
-  if (blk_center)
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3(1), dim3(1024), 0, s, n_atoms, cap, pair_start, blk_center,
-                       n_blk_dev, max_blk);
 }
 
 }  // namespace ta

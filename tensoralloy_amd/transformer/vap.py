@@ -41,6 +41,11 @@ class VirtualAtomMap:
 
         self._mask = np.zeros(self._max_vap_natoms, dtype=bool)
         self._mask[self.local_to_gsl] = True
+        # local order == GSL order (one element, or atoms already sorted by element, no padding):
+        # the maps are a shift by the virtual row and callers may skip the gather / scatter
+        n = len(self.local_to_gsl)
+        self.is_identity = bool(self._max_vap_natoms == n + self.REAL_ATOM_START and
+                                np.array_equal(self.local_to_gsl, np.arange(n) + self.REAL_ATOM_START))
         self._vap_symbols = ["X"] + [e for e, c in zip(elements, capacity) for _ in range(int(c))]
         # dictionary views with the reference's keys: 1-based local index -> GSL row, and back
         self.local_to_gsl_map = {0: 0}
