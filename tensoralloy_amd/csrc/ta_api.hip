@@ -650,15 +650,11 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
       begin(TA_K_BACKWARD);
       if (h->sf.angular) {
         bool first = true;
-        if (h->use_v2) {
-          // the last launch leaves the per-atom own-side sums for force_gather
-          h->db.own_sums = getenv("TA_NO_OWN_SUMS") ? 0 : 1;
-          for (size_t k = 0; k < h->chunks_v2.size(); ++k) {
-            const ChunkPlan &cp = h->chunks_v2[k];
-            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, h->db.own_sums && k + 1 == h->chunks_v2.size(), db, s);
+        if (h->use_v2)
+          for (const ChunkPlan &cp : h->chunks_v2) {
+            launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
             first = false;
           }
-        }
         else
           for (const ChunkPlan &cp : h->chunks) {
             launch_backward(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first, false, db, s);
@@ -1517,7 +1513,7 @@ void backward_only(ta_context *h) {
       bool first = true;
       if (h->use_v2)
         for (const ChunkPlan &cp : h->chunks_v2) {
-          launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, false, db, s);
+          launch_backward_v2(h->sf, cp.ch, cp.ng, cp.nz, first, db, s);
           first = false;
         }
       else

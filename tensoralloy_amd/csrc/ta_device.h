@@ -92,8 +92,9 @@ struct DeviceBatch {
   double *forces = nullptr; // [N][3]
   double *wat = nullptr;    // [N][9] per-atom virial (only atoms of groups that straddle two frames)
   // Per-atom own-side sums {sum_p g[p] (3), sum_p g[p] (x) D[p] (9)} over the atom's pairs, left by the
-  // last second-generation backward launch (its workgroups own whole centres); force_gather then only
-  // gathers g[rev p]. `own_sums` != 0: valid for this evaluation.
+  // GRAP backward kernel (one wavefront per centre: nearly free there); force_gather then only gathers
+  // g[rev p]. `own_sums` != 0: valid for this evaluation. (The angular backward kernel does not: its
+  // per-centre reduction cost what the gather saved, profiles/r02_tuning_notes.md.)
   double *fown = nullptr;
   int own_sums = 0;
   double *bpart = nullptr;  // [ceil(N / 16)][10] {E, W[9]} of every group of 16 consecutive atoms
@@ -145,7 +146,7 @@ int v2_job_stride(int cap);
 // `reduce`: last forward launch of an evaluation, also assembles the descriptor vectors
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,
                           bool reduce, const DeviceBatch &b, hipStream_t s);
-void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first, bool last,
+void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s);
 
 // device-side neighbour list (ta_nlist.hip)

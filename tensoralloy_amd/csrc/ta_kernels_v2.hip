@@ -907,41 +907,6 @@ __global__ __launch_bounds__(kBlock)
     b.g[4 * (size_t)p] = gx;
     b.g[4 * (size_t)p + 1] = gy;
     b.g[4 * (size_t)p + 2] = gz;
-    if (flags & 2) {  // last backward launch: the final dE/dD stays in LDS for the per-centre sums
-      gacc[item] = gx;
-      gacc[kCap + item] = gy;
-      gacc[2 * kCap + item] = gz;
-    }
-  }
-  // Own-side sums per centre, sum_p g[p] and sum_p g[p] (x) D[p] (basic.py:277-331): this workgroup
-  // holds every pair of its centres, so they cost no HBM traffic here and force_gather no longer
-  // reads g[p] and the pair record (100 -> 36 bytes per pair there). One wavefront per centre.
-  if ((flags & 2) && b.fown) {
-    __syncthreads();
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (int i = c0 + w; i < c1; i += nwaves) {
-      const int q0 = b.pair_start[i] - s0, q1 = b.pair_start[i + 1] - s0;
-      double acc[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) acc[k] = 0.0;
-      for (int q = q0 + l; q < q1; q += 64) {
-        const double g3[3] = {gacc[q], gacc[kCap + q], gacc[2 * kCap + q]};
-        const double d3[3] = {f.x[q], f.y[q], f.z[q]};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          acc[c] += g3[c];
-#pragma unroll
-          for (int e = 0; e < 3; ++e) acc[3 + 3 * c + e] = fma(g3[c], d3[e], acc[3 + 3 * c + e]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
-      if (l == 0) {
-        double *dst = b.fown + 12 * (size_t)i;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) dst[k] = acc[k];
-      }
-    }
   }
 }
 
@@ -1046,12 +1011,11 @@ void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz
   TA_DISPATCH_V2(fwd_t, sf, ch, b, geom, s);
 }
 
-void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first, bool last,
+void launch_backward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool first,
                         const DeviceBatch &b, hipStream_t s) {
   if (b.n_blk == 0) return;
   const int nspec = sf.n_elements;
-  // bit 0: first launch (adds the G2 share), bit 1: last launch (leaves the per-centre sums for force_gather)
-  const int f = (first ? 1 : 0) | (last ? 2 : 0) | stagger_bits(b, "TA_STAGGER_BWD");
+  const int f = (first ? 1 : 0) | stagger_bits(b, "TA_STAGGER_BWD");
   TA_DISPATCH_V2(bwd_t, sf, ch, b, f, s);
 }
 
