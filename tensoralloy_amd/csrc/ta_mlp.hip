@@ -384,6 +384,191 @@ size_t mlp_scratch_doubles(const MlpDev &mlp) {
 
 constexpr size_t kWaveLdsLimit = 150 * 1024;
 
+// hidden layers when the four-wavefront latency kernel applies (same shapes as the one-wavefront
+// kernel, launches BELOW its tile threshold), else 0
+int mlp_quad_shape(const MlpDev &mlp, int n_tiles);
+
+// ---- four wavefronts per 16 atoms, transposed GEMMs, one barrier per layer ------------------------
+// The LATENCY kernel for launches of few tiles (one frame: 250 tiles on 256 CUs). Same transposed
+// formulation as the one-wavefront kernel, but the four 16-unit output tiles of a layer belong to the
+// four wavefronts of the workgroup, so a tile's MFMAs (64 cycles each on gfx950) and activations run
+// on the four SIMDs of a CU side by side, as in the generic tile kernel -- and because a wavefront's
+// accumulator tile Z^T[16 nt + kq + 4 r][atom m] is stored to LDS exactly where the next layer's B
+// operand is read ([unit][atom], 512 contiguous bytes per k-step), a layer costs ONE barrier instead
+// of the generic kernel's elementwise passes (14 barriers for two hidden layers there, 4 here).
+// Activation derivatives of a wavefront's own tile stay in its registers for the backward sweep.
+// Weights are A operands read from global memory (L2 hits), first layer from G directly, scalar
+// output layer on the VALU. Shapes as for the one-wavefront kernel; one model per launch.
+struct QuadLds {
+  double h[2][16 * kWaveNT * kMlpRows];   // activations / dz, ping-pong: [unit][atom]
+  double ypart[4][kMlpRows];
+};
+
+// A operands of one GEMM phase of a wavefront's tile (at most 16 k-steps), fetched BEFORE the barrier
+// that precedes the phase: the L2 round trip overlaps the previous phase's tail and the barrier wait
+__device__ __forceinline__ void quad_fetch(double (&w)[16], const double *wcol, size_t stride, int n_tiles) {
+#pragma unroll
+  for (int t = 0; t < kWaveNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[4 * t + r] = t < n_tiles ? wcol[(size_t)(16 * t + 4 * r) * stride] : 0.0;
+}
+__device__ __forceinline__ mlp_f64x4 quad_gemm(const double (&w)[16], const double *bin, int n_tiles, mlp_f64x4 acc) {
+#pragma unroll
+  for (int t = 0; t < kWaveNT; ++t)
+    if (t < n_tiles) {
+      double bq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bq[r] = bin[(16 * t + 4 * r) * kMlpRows];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * t + r], bq[r], acc, 0, 0, 0);
+    }
+  return acc;
+}
+
+template <int LH>
+__global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int ndim, const int32_t *atoms,
+                                                       int n_atoms, const double *__restrict__ G,
+                                                       double *__restrict__ dEdG, double *__restrict__ eatom) {
+  __shared__ QuadLds L;
+  const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+  const int a0 = (int)blockIdx.x * kMlpRows;
+  const bool valid = a0 + m < n_atoms;
+  const int atom = atoms[valid ? a0 + m : a0];
+  mlp_f64x4 dh[LH];  // act'(z) of this wavefront's tile in every hidden layer
+  int cur = 0;
+  // ---- forward ----
+  {
+    const MlpLayerDev &ly = mlp.layer[0];
+    if (nt < ly.np / 16) {
+      mlp_f64x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = ly.b[16 * nt + kq + 4 * r];
+      const double *g = G + (size_t)atom * ndim;
+      for (int k0 = 0; k0 < ndim; k0 += 4) {
+        const int k = k0 + kq;
+        double x = 0.0;
+        if (k < ndim) {
+          x = g[k];
+          if (mlp.xlo) {
+            const double den = mlp.xhi[k] - mlp.xlo[k];
+            x = (den != 0.0) ? (mlp.xhi[k] - x) / den : 0.0;  // div_no_nan, atomic.py:195
+          }
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ly.w[(size_t)k * ly.np + 16 * nt + m], x, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double hv, dv;
+        activation_fn(act, acc[r], hv, dv);
+        dh[0][r] = dv;
+        L.h[cur][(16 * nt + kq + 4 * r) * kMlpRows + m] = hv;
+      }
+    }
+  }
+  double wnext[16];  // A operands of the next GEMM phase, in flight across the barrier
+  mlp_f64x4 bnext = {0.0, 0.0, 0.0, 0.0};
+  if (LH > 1) {
+    const MlpLayerDev &nx = mlp.layer[1];
+    const int tile = nt < nx.np / 16 ? nt : 0;
+    quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
+  } else {
+    const MlpLayerDev &l0 = mlp.layer[0];
+    quad_fetch(wnext, l0.wt + (size_t)kq * l0.kp + (16 * nt < ndim ? 16 * nt : 0) + m, l0.kp, l0.np / 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 1; l < LH; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    mlp_f64x4 acc = bnext;
+    if (nt < ly.np / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.kp / 16, acc);
+    // weights of the phase after this one: the next forward layer, or the first backward GEMM
+    if (l + 1 < LH) {
+      const MlpLayerDev &nx = mlp.layer[l + 1];
+      const int tile = nt < nx.np / 16 ? nt : 0;
+      quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
+    } else {
+      const int tile = nt < ly.kp / 16 ? nt : 0;
+      quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + 16 * tile + m, ly.kp, ly.np / 16);
+    }
+    if (nt < ly.np / 16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double hv, dv;
+        activation_fn(act, acc[r], hv, dv);
+        dh[l][r] = dv;
+        L.h[cur ^ 1][(16 * nt + kq + 4 * r) * kMlpRows + m] = hv;
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // scalar output layer: y = b + sum_k h[k] w[k][0]; dz of the last hidden layer = act' * w[k][0]
+  {
+    const MlpLayerDev &lo = mlp.layer[LH];
+    double y = 0.0;
+    if (nt < lo.kp / 16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * nt + kq + 4 * r;
+        const double wo = lo.w[(size_t)k * lo.np];
+        y = fma(L.h[cur][k * kMlpRows + m], wo, y);
+        L.h[cur ^ 1][k * kMlpRows + m] = dh[LH - 1][r] * wo;
+      }
+    }
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    if (kq == 0) L.ypart[nt][m] = y;
+    cur ^= 1;  // h[cur] now holds dz of the last hidden layer
+    __syncthreads();
+    if (nt == 0 && kq == 0 && valid)
+      eatom[atom] = ((L.ypart[0][m] + L.ypart[1][m]) + (L.ypart[2][m] + L.ypart[3][m])) + lo.b[0];
+  }
+  // ---- backward: delta_{l-1}^T = W_l . dz_l^T, dz_{l-1} = delta_{l-1} * act'(z_{l-1}) ----
+#pragma unroll
+  for (int l = LH - 1; l >= 1; --l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (nt < ly.kp / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
+    {  // weights of the next backward GEMM (layer l - 1, or the final dE/dG tiles of layer 0)
+      const MlpLayerDev &nx = mlp.layer[l - 1];
+      const int col = l > 1 ? (nt < nx.kp / 16 ? 16 * nt : 0) : (16 * nt < ndim ? 16 * nt : 0);
+      quad_fetch(wnext, nx.wt + (size_t)kq * nx.kp + col + m, nx.kp, nx.np / 16);
+    }
+    if (nt < ly.kp / 16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L.h[cur ^ 1][(16 * nt + kq + 4 * r) * kMlpRows + m] = acc[r] * dh[l - 1][r];
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  {
+    const MlpLayerDev &ly = mlp.layer[0];
+    // dE/dG: 16 input channels per tile, tiles dealt to the wavefronts
+    for (int j0 = 16 * nt; j0 < ndim; j0 += 64) {
+      mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      // (the first tile's operands were fetched before the barrier; further tiles, D > 64, stream)
+      if (j0 != 16 * nt) quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + j0 + m, ly.kp, ly.np / 16);
+      acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + kq + 4 * r;
+        if (valid && j < ndim) {
+          double d = acc[r];
+          if (mlp.xlo) {
+            const double den = mlp.xhi[j] - mlp.xlo[j];
+            d = (den != 0.0) ? -d / den : 0.0;
+          }
+          dEdG[(size_t)atom * ndim + j] = d;
+        }
+      }
+    }
+  }
+}
+
 // The one-wavefront kernel is the THROUGHPUT kernel: 4000 tiles (16 frames of 4000 atoms) take 66 us
 // against 98 us with the 16-row tile kernel. For one frame it loses (35 us against 18 us): 250 tiles
 // are fewer than the 1024 SIMDs, and a tile's 152 MFMAs (64 cycles each on gfx950) and 32 activations
@@ -403,6 +588,21 @@ int mlp_wave_shape(const MlpDev &mlp, int n_tiles) {
   const MlpLayerDev &lo = mlp.layer[lh];
   if (lo.n != 1 || lo.act || lo.res || lo.kp != mlp.layer[lh - 1].np) return 0;
   if (wave_lds_doubles(mlp, lh) * sizeof(double) > kWaveLdsLimit) return 0;  // wide descriptors
+  return lh;
+}
+
+int mlp_quad_shape(const MlpDev &mlp, int n_tiles) {
+  if (getenv("TA_MLP_TILE_KERNEL") || getenv("TA_MLP_WAVE_KERNEL")) return 0;
+  if (n_tiles >= kWaveMinTiles && !getenv("TA_MLP_QUAD_KERNEL")) return 0;
+  const int lh = mlp.n_layers - 1;
+  if (lh < 1 || lh > kWaveMaxHidden) return 0;
+  for (int l = 0; l < lh; ++l) {
+    const MlpLayerDev &ly = mlp.layer[l];
+    if (ly.np > 16 * kWaveNT || ly.res || !ly.act) return 0;
+    if (l > 0 && ly.kp != mlp.layer[l - 1].np) return 0;
+  }
+  const MlpLayerDev &lo = mlp.layer[lh];
+  if (lo.n != 1 || lo.act || lo.res || lo.kp != mlp.layer[lh - 1].np) return 0;
   return lh;
 }
 
@@ -427,6 +627,19 @@ void allow_lds(K kernel, size_t bytes) {
 void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                      const DeviceBatch &b, double *scratch, hipStream_t s) {
   if (n_atoms == 0) return;
+  if (const int lh = mlp_quad_shape(mlp, (n_atoms + kMlpRows - 1) / kMlpRows)) {
+    const unsigned qblocks = (unsigned)((n_atoms + kMlpRows - 1) / kMlpRows);
+    if (lh == 1)
+      hipLaunchKernelGGL(mlp_quad_kernel<1>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
+                         b.G, b.dEdG, b.eatom);
+    else if (lh == 2)
+      hipLaunchKernelGGL(mlp_quad_kernel<2>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
+                         b.G, b.dEdG, b.eatom);
+    else
+      hipLaunchKernelGGL(mlp_quad_kernel<3>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
+                         b.G, b.dEdG, b.eatom);
+    return;
+  }
   if (const int lh = mlp_wave_shape(mlp, (n_atoms + kMlpRows - 1) / kMlpRows)) {
     const int ntiles = (n_atoms + kMlpRows - 1) / kMlpRows, nw = kWaveThreads / 64;
     const unsigned wblocks = (unsigned)std::min((ntiles + nw - 1) / nw, 256);
