@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
   }
   double wnext[16];  // A operands of the next GEMM phase, in flight across the barrier
   mlp_f64x4 bnext = {0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
   if (LH > 1) {
     const MlpLayerDev &nx = mlp.layer[1];
     const int tile = nt < nx.np / 16 ? nt : 0;
@@ -477,23 +478,11 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     const MlpLayerDev &l0 = mlp.layer[0];
     quad_fetch(wnext, l0.wt + (size_t)kq * l0.kp + (16 * nt < ndim ? 16 * nt : 0) + m, l0.kp, l0.np / 16);
   }
-  __syncthreads();
 #pragma unroll
   for (int l = 1; l < LH; ++l) {
     const MlpLayerDev &ly = mlp.layer[l];
     mlp_f64x4 acc = bnext;
     if (nt < ly.np / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.kp / 16, acc);
-    // weights of the phase after this one: the next forward layer, or the first backward GEMM
-    if (l + 1 < LH) {
-      const MlpLayerDev &nx = mlp.layer[l + 1];
-      const int tile = nt < nx.np / 16 ? nt : 0;
-      quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
-    } else {
-      const int tile = nt < ly.kp / 16 ? nt : 0;
-      quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + 16 * tile + m, ly.kp, ly.np / 16);
-    }
     if (nt < ly.np / 16) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -505,6 +494,17 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     }
     cur ^= 1;
     __syncthreads();
+    // weights of the phase after this one: the next forward layer, or the first backward GEMM
+    if (l + 1 < LH) {
+      const MlpLayerDev &nx = mlp.layer[l + 1];
+      const int tile = nt < nx.np / 16 ? nt : 0;
+      quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
+    } else {
+      const int tile = nt < ly.kp / 16 ? nt : 0;
+      quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + 16 * tile + m, ly.kp, ly.np / 16);
+    }
   }
   // scalar output layer: y = b + sum_k h[k] w[k][0]; dz of the last hidden layer = act' * w[k][0]
   {
@@ -533,17 +533,17 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     const MlpLayerDev &ly = mlp.layer[l];
     mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     if (nt < ly.kp / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
-    {  // weights of the next backward GEMM (layer l - 1, or the final dE/dG tiles of layer 0)
-      const MlpLayerDev &nx = mlp.layer[l - 1];
-      const int col = l > 1 ? (nt < nx.kp / 16 ? 16 * nt : 0) : (16 * nt < ndim ? 16 * nt : 0);
-      quad_fetch(wnext, nx.wt + (size_t)kq * nx.kp + col + m, nx.kp, nx.np / 16);
-    }
     if (nt < ly.kp / 16) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) L.h[cur ^ 1][(16 * nt + kq + 4 * r) * kMlpRows + m] = acc[r] * dh[l - 1][r];
     }
     cur ^= 1;
     __syncthreads();
+    {  // weights of the next backward GEMM (layer l - 1, or the final dE/dG tiles of layer 0)
+      const MlpLayerDev &nx = mlp.layer[l - 1];
+      const int col = l > 1 ? (nt < nx.kp / 16 ? 16 * nt : 0) : (16 * nt < ndim ? 16 * nt : 0);
+      quad_fetch(wnext, nx.wt + (size_t)kq * nx.kp + col + m, nx.kp, nx.np / 16);
+    }
   }
   {
     const MlpLayerDev &ly = mlp.layer[0];
