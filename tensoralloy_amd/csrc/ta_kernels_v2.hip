@@ -344,15 +344,17 @@ __device__ __forceinline__ int job_slot(int r, int tid, int T) { return r * T + 
 
 // Descriptor vectors of the workgroup's centres from data that is still in LDS, one wavefront per
 // centre, round robin. G2 from r^2 (sf.py:79-119):
+// `fc_in_G`: Fields::G still holds the staged cutoff values (job path); the path without job lists
+// reuses x .. G for the lanes' partial sums before it gets here.
 __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const DeviceBatch &b,
-                                                       const Fields &f, int c0, int c1, int s0) {
+                                                       const Fields &f, int c0, int c1, int s0, bool fc_in_G) {
   const int nel = sf.n_elements;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   // the usual grid has omega = 0 for every channel: exp(-eta r^2 / rc^2), no square root; and with
   // rcut == acut the staging phase has left fc(r) in Fields::G (uniform tests, scalar unit)
   bool no_shift = true;
   for (int c = 0; c < sf.n_rad; ++c) no_shift = no_shift && sf.omega[c] == 0.0;
-  const bool fc_staged = sf.rcut == sf.acut && sf.angular;
+  const bool fc_staged = fc_in_G && sf.rcut == sf.acut && sf.angular;
   for (int64_t i = c0 + w; i < c1; i += nwaves) {
     const int sA = b.species[i];
     const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
         }
       __syncthreads();
       if (flags & 4) {
-        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0, true);
         reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
         return;
       }
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
             if (sp_lo * kGZ + k < kLocal) red[(size_t)k * b.cap + item] = mine[sp_lo * kGZ + k];
         }
         __syncthreads();
-        if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+        if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0, false);
         reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, red, b.cap, c0, c1, s0, sp_lo, sp_hi);
         __syncthreads();
       }

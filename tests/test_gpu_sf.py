@@ -303,3 +303,12 @@ def test_one_wavefront_mlp_kernel(lib, monkeypatch, hidden, activation, minmax):
                 assert abs(a["energy"] - other["energy"]) < 1e-10
                 assert np.abs(a["forces"] - other["forces"]).max() < 1e-10
                 assert np.abs(a["atomic"] - other["atomic"]).max() < 1e-11
+
+
+def test_angular_kernels_without_job_lists(lib, monkeypatch):
+    """`TA_NO_JOBS=1`: the second-generation kernels without the forward -> backward job list (lanes
+    re-dealt by popcount, descriptors assembled from the lanes' partial sums in LDS). The path batches
+    fall back to when the list buffers are switched off; same parity gate."""
+    monkeypatch.setenv("TA_NO_JOBS", "1")
+    _compare(make_nn(["Ni"], 6.5, True, [16, 16]), [fcc(rep=(3, 3, 3), jitter=0.05), fcc(rep=(2, 2, 2), a=3.4, seed=4)])
+    _compare(make_nn(["Mo", "Ni"], 6.0, True, [16]), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
