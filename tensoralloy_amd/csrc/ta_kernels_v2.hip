@@ -42,7 +42,7 @@ namespace ta {
 namespace {
 
 constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
-constexpr int kNF = 7;  // x y z r2 inv_r H G
+constexpr int kNF = 8;  // {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
@@ -53,29 +53,27 @@ __device__ __forceinline__ int radial_term2(int center, int other) {
   return other == center ? 0 : (other < center ? other + 1 : other);
 }
 
+// The fields of a pair as four arrays of 16-byte records: the triple bodies read a random partner's
+// geometry with four 128-bit LDS reads ({x y}, {z r2}, {1/r H}, {G species}) instead of eight 64-bit
+// and one byte read (LDS instructions, not arithmetic, bound the backward body).
 struct Fields {
-  double *x, *y, *z, *r2, *inv, *H, *G;
+  double2 *zr, *xy, *ih, *gs;  // {z, r^2}, {x, y}, {1/r, H}, {G, species of the neighbour as a double}
   float *xf, *yf, *zf;  // single-precision ring copies for the candidate scan: the n neighbours of
                         // a centre are stored twice in a row (2 * base + k and + n), so partner
                         // a + s needs no wrap-around arithmetic
-  unsigned char *sp;
 };
 
 __device__ __forceinline__ Fields carve(double *lds, int cap) {
   Fields f;
-  // r2 first: x .. G and the rings behind them are one contiguous region that is dead once the
-  // triple body is done (the descriptor assembly reuses it, see reduce_from_lds)
-  f.r2 = lds;
-  f.x = f.r2 + cap;
-  f.y = f.x + cap;
-  f.z = f.y + cap;
-  f.inv = f.z + cap;
-  f.H = f.inv + cap;
-  f.G = f.H + cap;
-  f.xf = reinterpret_cast<float *>(f.G + cap);
+  // {z r2} first: xy .. gs (6 cap doubles) and the rings behind them are one contiguous region that
+  // is dead once the triple body is done (the descriptor assembly reuses it, see reduce_from_lds)
+  f.zr = reinterpret_cast<double2 *>(lds);
+  f.xy = f.zr + cap;
+  f.ih = f.xy + cap;
+  f.gs = f.ih + cap;
+  f.xf = reinterpret_cast<float *>(f.gs + cap);
   f.yf = f.xf + (2 * cap + kRingPad);
   f.zf = f.yf + (2 * cap + kRingPad);
-  f.sp = reinterpret_cast<unsigned char *>(f.zf + (2 * cap + kRingPad));
   return f;
 }
 
@@ -159,9 +157,8 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       v1 = src[1];
       v2 = src[2];
     }
-    f.x[item] = v0.x;
-    f.y[item] = v0.y;
-    f.z[item] = v1.x;
+    f.xy[item] = v0;
+    f.zr[item] = v1;
     {
       const int ci = b.pair_i[s0 + item];
       const int cbase = b.pair_start[ci] - s0, cn = b.pair_start[ci + 1] - b.pair_start[ci];
@@ -170,8 +167,6 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       f.yf[k0] = f.yf[k0 + cn] = (float)v0.y;
       f.zf[k0] = f.zf[k0 + cn] = (float)v1.x;
     }
-    f.r2[item] = v1.y;
-    f.inv[item] = v2.x;
     const double u = v1.y * sf.inv_ac2;
     double H = 0.0, G = 0.0;
     if (u < 1.0) {
@@ -181,9 +176,8 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       H = e * fc;
       G = fc_in_G ? fc : e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
     }
-    f.H[item] = H;
-    f.G[item] = G;
-    f.sp[item] = (unsigned char)b.species[b.pair_j[s0 + item]];
+    f.ih[item] = make_double2(v2.x, H);
+    f.gs[item] = make_double2(G, (double)b.species[b.pair_j[s0 + item]]);
   }
   __syncthreads();
 }
@@ -365,9 +359,9 @@ __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const
       for (int cc = 0; cc < sf.n_rad; cc += 4) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int q = q0 + l; q < q1; q += 64) {
-          const double r2 = f.r2[q];
+          const double r2 = f.zr[q].y;
           const double u = r2 * sf.inv_rc2;
-          const double fc = fc_staged ? f.G[q] : ((u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0);
+          const double fc = fc_staged ? f.gs[q].x : ((u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0);
           if (no_shift) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -470,8 +464,9 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
     const int base = b.pair_start[i] - s0;
     const int n = b.pair_start[i + 1] - b.pair_start[i];
     const int a = item - base;
-    const double ax = f.x[item], ay = f.y[item], az = f.z[item];
-    const double ra2 = f.r2[item], inv_ra = f.inv[item], Ha = f.H[item];
+    const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item];
+    const double ax = axy.x, ay = axy.y, az = azr.x;
+    const double ra2 = azr.y, inv_ra = aih.x, Ha = aih.y;
 
     double acc[NSPEC][NG][NZ];
 #pragma unroll
@@ -506,13 +501,15 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
         int bl = a + sc + k;
         if (bl >= n) bl -= n;
         const int q = base + bl;
-        const double ex = f.x[q] - ax, ey = f.y[q] - ay, ez = f.z[q] - az;
+        const double2 bxy = f.xy[q], bzr = f.zr[q];
+        const double ex = bxy.x - ax, ey = bxy.y - ay, ez = bzr.x - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
         if (!(u < 1.0)) continue;  // exact test (the mask is a superset); H_b = 0 adds nothing
-        const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ra * f.inv[q];
-        const double common = Ha * f.H[q] * hd_value<HD>(sf, ch, beta, u);
-        const int sb = f.sp[q];
+        const double2 bih = f.ih[q];
+        const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ra * bih.x;
+        const double common = Ha * bih.y * hd_value<HD>(sf, ch, beta, u);
+        const int sb = NSPEC == 1 ? 0 : (int)f.gs[q].y;
         if constexpr (DEFZ) {
           const double c2 = cth * cth;
           const double t1 = common * cth, t2 = common * c2, t3 = t1 * c2, t4 = t2 * c2;
@@ -588,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       const int64_t p = (int64_t)s0 + item;
       const int i = b.pair_i[p];
       const int base = b.pair_start[i] - s0;
-      const int smax = (f.H[item] != 0.0) ? n_own / 2 : 0;
+      const int smax = (f.ih[item].y != 0.0) ? n_own / 2 : 0;
       if (smax > 0 && !(flags & (1 << 25))) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
       if (b.masks) b.masks[p] = mask;
     }
@@ -642,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngC
       for (int k = 0; k < kLocal; ++k) mine[k] = 0.0;
       if (active) run_item(item, true, mask, mine);
       __syncthreads();  // nobody reads x .. G or the sort scratch any more
-      double *red = f.x;
+      double *red = reinterpret_cast<double *>(f.xy);
 #pragma unroll
       for (int sp_lo = 0; sp_lo < NSPEC; sp_lo += kSpPerPass) {
         const int sp_hi = sp_lo + kSpPerPass < NSPEC ? sp_lo + kSpPerPass : NSPEC;
@@ -719,10 +716,11 @@ __global__ __launch_bounds__(kBlock)
     const int base = b.pair_start[i] - s0;
     const int n = b.pair_start[i + 1] - b.pair_start[i];
     const int a = item - base;
-    const double ax = f.x[item], ay = f.y[item], az = f.z[item];
-    const double ra2 = f.r2[item], inv_ra = f.inv[item], Ha = f.H[item], Ga = f.G[item];
+    const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item], ags = f.gs[item];
+    const double ax = axy.x, ay = axy.y, az = azr.x;
+    const double ra2 = azr.y, inv_ra = aih.x, Ha = aih.y, Ga = ags.x;
     const double inv_ra2 = inv_ra * inv_ra;
-    const int sa = f.sp[item];
+    const int sa = (int)ags.y;
 
     // dE/dG of the channels of term (sa, sp) for every partner species sp
     // w = dE/dG 2^(1-zeta); wd = w zeta gamma (factor of the derivative of (1 + gamma c)^zeta)
@@ -774,19 +772,21 @@ __global__ __launch_bounds__(kBlock)
         int bl = a + sc + k;
         if (bl >= n) bl -= n;
         const int q = base + bl;
-        const double bx = f.x[q], by = f.y[q], bz = f.z[q];
+        const double2 bxy = f.xy[q], bzr = f.zr[q];
+        const double bx = bxy.x, by = bxy.y, bz = bzr.x;
         const double ex = bx - ax, ey = by - ay, ez = bz - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
         if (!(u < 1.0)) continue;  // exact test (the mask is a superset)
-        const double inv_rb = f.inv[q];
+        const double2 bih = f.ih[q], bgs = f.gs[q];
+        const double inv_rb = bih.x;
         const double inv_ab = inv_ra * inv_rb;
-        const double cth = (ra2 + f.r2[q] - d2) * 0.5 * inv_ab;
+        const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ab;
         double Hd, dHd;
         hd_eval<HD>(sf, ch, beta, u, Hd, dHd);
         const double Hd2 = 2.0 * sf.inv_ac2 * dHd;
-        const double Hb = f.H[q], Gb = f.G[q];
-        const int sb = f.sp[q];
+        const double Hb = bih.y, Gb = bgs.x;
+        const int sb = NSPEC == 1 ? 0 : (int)bgs.y;
         double S0 = 0.0, S1 = 0.0;
         if constexpr (DEFZ) {
           double p0 = pc[0][0], p1 = pc[0][1], p2 = pc[0][2], p3 = pc[0][3], p4 = pc[0][4];
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(kBlock)
         const int64_t p = (int64_t)s0 + item;
         const int i = b.pair_i[p];
         const int base = b.pair_start[i] - s0;
-        const int smax = (f.H[item] != 0.0) ? n_own / 2 : 0;
+        const int smax = (f.ih[item].y != 0.0) ? n_own / 2 : 0;
         if (smax > 0)
           mask = b.masks ? b.masks[p] : partner_mask(sf, f, base, n_own, item - base, 1, smax);
       }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kBlock)
     if (first) {
       // radial (G2) share: s_p D / r  (sf.py:101-108 differentiated)
       const int i = b.pair_i[p];
-      const double r2 = f.r2[item], inv_r = f.inv[item];
+      const double r2 = f.zr[item].y, inv_r = f.ih[item].x;
       const double ur = r2 * sf.inv_rc2;
       double s = 0.0;
       if (ur < 1.0) {
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kBlock)
         cutoff_u(sf.cutoff, ur, fc, dfdu);
         const double r = sqrt(r2);
         const double dfdr = dfdu * 2.0 * r * sf.inv_rc2;
-        const double *wr = b.dEdG + (size_t)i * sf.ndim + radial_term2(b.species[i], f.sp[item]) * sf.n_rad;
+        const double *wr = b.dEdG + (size_t)i * sf.ndim + radial_term2(b.species[i], (int)f.gs[item].y) * sf.n_rad;
         for (int c = 0; c < sf.n_rad; ++c) {
           const double dr = r - sf.omega[c];
           const double e = ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2);
@@ -898,9 +898,9 @@ __global__ __launch_bounds__(kBlock)
         }
       }
       s *= inv_r;
-      gx = fma(s, f.x[item], gx);
-      gy = fma(s, f.y[item], gy);
-      gz = fma(s, f.z[item], gz);
+      gx = fma(s, f.xy[item].x, gx);
+      gy = fma(s, f.xy[item].y, gy);
+      gz = fma(s, f.zr[item].x, gz);
     } else {
       gx += b.g[4 * (size_t)p];
       gy += b.g[4 * (size_t)p + 1];
