@@ -379,19 +379,37 @@ def main():
         # MFMA utilisation of the batched per-atom MLP (north_star): v_mfma_f64_16x16x4_f64 count of
         # one launch (forward + backward-to-inputs, padded tiles) x 2048 flop, over the kernel's
         # HIP-event duration, against the dense fp64 matrix peak
-        sizes = [D] + list(nn.hidden_sizes[nn.elements[0]]) + [1]
+        # One-element models of the usual shapes run the transposed kernels (mlp_quad_kernel below 1024
+        # tiles, mlp_wave_kernel from there): per 16-atom tile the first layer takes ceil(D / 4)
+        # k-steps per output tile, hidden-to-hidden layers their full K, the scalar output layer is
+        # VALU work, and the backward sweep mirrors the hidden layers plus one tile row of dE/dG.
+        hidden = list(nn.hidden_sizes[nn.elements[0]])
         pad = lambda v: (v + 15) // 16 * 16
-        per_tile = 2 * sum((pad(sizes[l]) // 4) * (pad(sizes[l + 1]) // 16) for l in range(len(sizes) - 1))
-        n_mfma = per_tile * ((n_atoms // fpg + 15) // 16) * fpg
+        tiles = lambda v: pad(v) // 16
+        per_tile = tiles(hidden[0]) * ((D + 3) // 4)                                   # forward, first layer
+        per_tile += sum(tiles(hidden[l]) * (pad(hidden[l - 1]) // 4) for l in range(1, len(hidden)))
+        per_tile += sum(tiles(hidden[l - 1]) * (pad(hidden[l]) // 4) for l in range(1, len(hidden)))  # backward
+        per_tile += tiles(D) * (pad(hidden[0]) // 4)                                   # dE/dG
+        n_tiles = ((n_atoms // fpg + 15) // 16) * fpg
+        n_mfma = per_tile * n_tiles
         mlp_ms = slots.get("mlp", 0.0)
         mlp_mfma = None
         if mlp_ms > 0:
             tf = n_mfma * 2048.0 / (mlp_ms * 1e-3) / 1e12
-            mlp_mfma = {"kernel": "mlp_all_kernel", "mfma_insts_per_launch": n_mfma,
+            transposed = n_tiles > 256       # below: the generic 16-row tile kernel (padded K and N)
+            if not transposed:
+                sizes = [D] + hidden + [1]
+                n_mfma = n_tiles * 2 * sum((pad(sizes[l]) // 4) * tiles(sizes[l + 1]) for l in range(len(sizes) - 1))
+                tf = n_mfma * 2048.0 / (mlp_ms * 1e-3) / 1e12
+            mlp_mfma = {"kernel": "mlp_kernel (16-row tiles)" if not transposed else
+                        ("mlp_quad_kernel" if n_tiles < 1024 else "mlp_wave_kernel"),
+                        "mfma_insts_per_launch": n_mfma,
                         "flop_per_launch": n_mfma * 2048.0, "kernel_ms": mlp_ms, "achieved": tf,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                        "note": "16-row tiles: one frame is 250 workgroups on 256 CUs, the kernel is "
-                                "bound by the latency of its dependent GEMM phases, not by the matrix pipe"}
+                        "note": "16-atom tiles; one frame is 250 workgroups on 256 CUs: bound by launch and "
+                                "the latency of the dependent GEMM phases of a tile, not by the matrix pipe (a "
+                                "v_mfma_f64_16x16x4 is 64 cycles); launches of more than 256 tiles run the "
+                                "transposed kernels (no padding of K = D and N = 1)"}
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "peak_measured_copy": copy_gbs,

@@ -591,9 +591,15 @@ int mlp_wave_shape(const MlpDev &mlp, int n_tiles) {
   return lh;
 }
 
+// Below one tile per CU the generic tile kernel is still the faster one in the angular pipeline
+// (4000-atom frame, 250 tiles: 18.2-18.9 us against 19.7-20.3 us for this kernel, same session),
+// although this kernel wins the isolated comparison on G2-only models (13.8 against 17.7 us); from
+// three frames on it is ahead in both (7.1 against 7.7 us per frame).
+constexpr int kQuadMinTiles = 257;
+
 int mlp_quad_shape(const MlpDev &mlp, int n_tiles) {
   if (getenv("TA_MLP_TILE_KERNEL") || getenv("TA_MLP_WAVE_KERNEL")) return 0;
-  if (n_tiles >= kWaveMinTiles && !getenv("TA_MLP_QUAD_KERNEL")) return 0;
+  if ((n_tiles >= kWaveMinTiles || n_tiles < kQuadMinTiles) && !getenv("TA_MLP_QUAD_KERNEL")) return 0;
   const int lh = mlp.n_layers - 1;
   if (lh < 1 || lh > kWaveMaxHidden) return 0;
   for (int l = 0; l < lh; ++l) {

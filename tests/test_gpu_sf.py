@@ -295,9 +295,11 @@ def test_one_wavefront_mlp_kernel(lib, monkeypatch, hidden, activation, minmax):
         monkeypatch.setenv("TA_MLP_WAVE_KERNEL", "1")
         wave = _compare(nn, fr)
         monkeypatch.delenv("TA_MLP_WAVE_KERNEL")
-        # no switch: single-element models of these shapes take the four-wavefront latency kernel
-        # (`mlp_quad_kernel`), alloys the generic tile kernel
+        # forced: single-element models of these shapes take the four-wavefront kernel
+        # (`mlp_quad_kernel`; by itself from 257 tiles on), alloys the generic tile kernel
+        monkeypatch.setenv("TA_MLP_QUAD_KERNEL", "1")
         quad = _compare(nn, fr)
+        monkeypatch.delenv("TA_MLP_QUAD_KERNEL")
         for a, b, c in zip(tile, wave, quad):
             for other in (b, c):
                 assert abs(a["energy"] - other["energy"]) < 1e-10
