@@ -434,7 +434,8 @@ __device__ __forceinline__ void stagger(int flags) {
 // DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
 template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
-__global__ __launch_bounds__(kBlock) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
+__global__ __launch_bounds__(kBlock)
+    __attribute__((amdgpu_waves_per_eu(DEFZ && NSPEC == 1 ? 5 : 1, 8))) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
                                                                DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int geom = flags & 1;
