@@ -42,7 +42,10 @@ namespace ta {
 namespace {
 
 constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
-constexpr int kNF = 8;  // {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
+constexpr int kNF = 8;   // backward: {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
+constexpr int kNFf = 7;  // forward: the last record is the species alone (8 bytes): 1.5 KB of LDS less,
+                         // which with the trimmed job counters lets 7 workgroups share a CU instead of 6
+constexpr int kJobCtlBytes = 160;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
@@ -58,20 +61,22 @@ __device__ __forceinline__ int radial_term2(int center, int other) {
 // and one byte read (LDS instructions, not arithmetic, bound the backward body).
 struct Fields {
   double2 *zr, *xy, *ih, *gs;  // {z, r^2}, {x, y}, {1/r, H}, {G, species of the neighbour as a double}
+  double *sp1;                 // forward kernel: species alone (gs is null there)
   float *xf, *yf, *zf;  // single-precision ring copies for the candidate scan: the n neighbours of
                         // a centre are stored twice in a row (2 * base + k and + n), so partner
                         // a + s needs no wrap-around arithmetic
 };
 
-__device__ __forceinline__ Fields carve(double *lds, int cap) {
+__device__ __forceinline__ Fields carve(double *lds, int cap, bool forward = false) {
   Fields f;
-  // {z r2} first: xy .. gs (6 cap doubles) and the rings behind them are one contiguous region that
+  // {z r2} first: xy .. gs / sp1 (6 or 5 cap doubles) and the rings behind them are one contiguous region that
   // is dead once the triple body is done (the descriptor assembly reuses it, see reduce_from_lds)
   f.zr = reinterpret_cast<double2 *>(lds);
   f.xy = f.zr + cap;
   f.ih = f.xy + cap;
-  f.gs = f.ih + cap;
-  f.xf = reinterpret_cast<float *>(f.gs + cap);
+  f.gs = forward ? nullptr : f.ih + cap;
+  f.sp1 = forward ? reinterpret_cast<double *>(f.ih + cap) : nullptr;
+  f.xf = forward ? reinterpret_cast<float *>(f.sp1 + cap) : reinterpret_cast<float *>(f.gs + cap);
   f.yf = f.xf + (2 * cap + kRingPad);
   f.zf = f.yf + (2 * cap + kRingPad);
   return f;
@@ -115,10 +120,9 @@ __device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &c
 // `geom` != 0: the pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps, 1/r
 // (reference calculate_rij, transformer/universal.py:448-474) is computed here
 // and the pair record written for the later kernels; otherwise it is read.
-// `fc_in_G`: the forward kernel has no use for G = (dH/dr)/r and keeps the cutoff value fc(r; acut)
-// there instead, for its G2 sums (same cutoff whenever rcut == acut).
+// `forward`: the forward kernel has no use for G = (dH/dr)/r (Fields::sp1 instead of Fields::gs).
 __device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
-                                      const Fields &f, int s0, int M, int geom = 0, bool fc_in_G = false) {
+                                      const Fields &f, int s0, int M, int geom = 0, bool forward = false) {
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
     double2 v0, v1, v2;
     if (geom) {
@@ -174,10 +178,11 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       cutoff_u(sf.cutoff, u, fc, dfdu);
       const double e = ta_exp(-beta * u);
       H = e * fc;
-      G = fc_in_G ? fc : e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
+      G = e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
     }
     f.ih[item] = make_double2(v2.x, H);
-    f.gs[item] = make_double2(G, (double)b.species[b.pair_j[s0 + item]]);
+    if (forward) f.sp1[item] = (double)b.species[b.pair_j[s0 + item]];
+    else f.gs[item] = make_double2(G, (double)b.species[b.pair_j[s0 + item]]);
   }
   __syncthreads();
 }
@@ -266,7 +271,7 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
 // kernel: one construction serves both sweeps.
 struct JobLists {
   uint32_t *word;            // [4 * lanes]: pair | window << 8 | bits << 16
-  int *hist, *start, *ctl;   // [66], [66], [8]
+  int *hist, *start;         // [20], [20] (17 used: job sizes 16 .. 1, total)
 };
 
 __device__ __forceinline__ JobLists job_lists(const Fields &f) {
@@ -279,10 +284,10 @@ __device__ __forceinline__ unsigned long long job_bits(uint32_t w) {
   return (unsigned long long)(w >> 16) << (16 * ((w >> 8) & 3u));
 }
 
-// byte offset of the job counters (hist[66], start[66], ctl[8] ints: 640 bytes reserved) and, behind
+// byte offset of the job counters (kJobCtlBytes) and, behind
 // them, of the forward kernel's per-pair partial sums P[n_local][cap]
 __host__ __device__ inline size_t v2_counter_offset(int cap) {
-  const size_t end = (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap;
+  const size_t end = (size_t)cap * kNFf * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float);
   return (end + 15) & ~(size_t)15;
 }
 // four jobs per lane at most; the words fit the rings: 4 * 4 cap <= 3 * 4 (2 cap + 64) bytes
@@ -338,17 +343,13 @@ __device__ __forceinline__ int job_slot(int r, int tid, int T) { return r * T + 
 
 // Descriptor vectors of the workgroup's centres from data that is still in LDS, one wavefront per
 // centre, round robin. G2 from r^2 (sf.py:79-119):
-// `fc_in_G`: Fields::G still holds the staged cutoff values (job path); the path without job lists
-// reuses x .. G for the lanes' partial sums before it gets here.
 __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const DeviceBatch &b,
-                                                       const Fields &f, int c0, int c1, int s0, bool fc_in_G) {
+                                                       const Fields &f, int c0, int c1, int s0) {
   const int nel = sf.n_elements;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-  // the usual grid has omega = 0 for every channel: exp(-eta r^2 / rc^2), no square root; and with
-  // rcut == acut the staging phase has left fc(r) in Fields::G (uniform tests, scalar unit)
+  // the usual grid has omega = 0 for every channel: exp(-eta r^2 / rc^2), no square root (uniform test)
   bool no_shift = true;
   for (int c = 0; c < sf.n_rad; ++c) no_shift = no_shift && sf.omega[c] == 0.0;
-  const bool fc_staged = fc_in_G && sf.rcut == sf.acut && sf.angular;
   for (int64_t i = c0 + w; i < c1; i += nwaves) {
     const int sA = b.species[i];
     const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
@@ -361,7 +362,7 @@ __device__ __forceinline__ void reduce_radial_from_lds(const SFParams &sf, const
         for (int q = q0 + l; q < q1; q += 64) {
           const double r2 = f.zr[q].y;
           const double u = r2 * sf.inv_rc2;
-          const double fc = fc_staged ? f.gs[q].x : ((u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0);
+          const double fc = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
           if (no_shift) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(kBlock)
   if (b.n_blk_dev && (int)blockIdx.x >= *b.n_blk_dev) return;  // grid sized by an upper bound (MD loop)
   stagger(flags);
   extern __shared__ double lds[];
-  const Fields f = carve(lds, b.cap);
+  const Fields f = carve(lds, b.cap, true);
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
@@ -450,8 +451,8 @@ __global__ __launch_bounds__(kBlock)
   if (b.job_count) {  // job counters and partial sums: cleared before the staging barrier
     char *raw = reinterpret_cast<char *>(lds);
     int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
-    if (threadIdx.x < 160) cnt[threadIdx.x] = 0;
-    double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
+    if (threadIdx.x < kJobCtlBytes / 4) cnt[threadIdx.x] = 0;
+    double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * b.cap; k += blockDim.x) P0[k] = 0.0;
   }
   stage(sf, beta, b, f, s0, M, geom, true);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(kBlock)
         const double2 bih = f.ih[q];
         const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ra * bih.x;
         const double common = Ha * bih.y * hd_value<HD>(sf, ch, beta, u);
-        const int sb = NSPEC == 1 ? 0 : (int)f.gs[q].y;
+        const int sb = NSPEC == 1 ? 0 : (int)f.sp1[q];
         if constexpr (DEFZ) {
           const double c2 = cth * cth;
           const double t1 = common * cth, t2 = common * c2, t3 = t1 * c2, t4 = t2 * c2;
@@ -595,9 +596,8 @@ __global__ __launch_bounds__(kBlock)
       char *raw = reinterpret_cast<char *>(lds);
       JobLists jl = job_lists(f);
       jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
-      jl.start = jl.hist + 66;
-      jl.ctl = jl.start + 66;
-      double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + 640);
+      jl.start = jl.hist + 20;
+      double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
       const int n_jobs = make_jobs(jl, active, item, mask);
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
       if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kBlock)
         }
       __syncthreads();
       if (flags & 4) {
-        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0, true);
+        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
         reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
         return;
       }
@@ -628,12 +628,12 @@ __global__ __launch_bounds__(kBlock)
     } else {
     deal_by_popcount(f, b.cap, M, item, mask);
     // flags & 4: this launch holds every angular channel of the model: the descriptors are
-    // assembled from LDS, without a round trip through part4. The partial sums of up to 9 local
-    // channels at a time go behind r2: x .. G (6 cap doubles) and the rings behind them (3 cap
+    // assembled from LDS, without a round trip through part4. The partial sums of up to 8 local
+    // channels at a time go behind {z r2}: xy, ih, sp1 (5 cap doubles) and the rings behind them (3 cap
     // doubles) are dead by now; more partner species take more passes.
     constexpr int kLocal = NSPEC * NG * NZ;
     constexpr int kGZ = NG * NZ;
-    constexpr int kSpPerPass = 9 / kGZ;
+    constexpr int kSpPerPass = 8 / kGZ;
     if (flags & 4) {
       double mine[kLocal];
 #pragma unroll
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kBlock)
             if (sp_lo * kGZ + k < kLocal) red[(size_t)k * b.cap + item] = mine[sp_lo * kGZ + k];
         }
         __syncthreads();
-        if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0, false);
+        if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
         reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, red, b.cap, c0, c1, s0, sp_lo, sp_hi);
         __syncthreads();
       }
@@ -960,7 +960,7 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 
 // n_local > 0: forward launch in job mode (counters + per-pair partial sums behind the fields)
 size_t v2_lds_bytes(bool backward, int cap, int n_local) {
-  if (!backward && n_local > 0) return v2_counter_offset(cap) + 640 + (size_t)n_local * cap * sizeof(double);
+  if (!backward && n_local > 0) return v2_counter_offset(cap) + kJobCtlBytes + (size_t)n_local * cap * sizeof(double);
   return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
          (backward ? 3 * (size_t)cap * sizeof(double) : 0);
 }
