@@ -13,14 +13,15 @@
 // and the tf.gradients that give forces and virial (nn/basic.py:277-331).
 //
 // Two passes over the packed pair list:
-//   eam_atom_kernel  one wavefront per atom: pair geometry (written to the pair records),
+//   eam_atom_kernel  16 / 32 / 64 lanes per atom: pair geometry (written to the pair records),
 //                    rho_i, sum phi, and (ADP) the
 //                    dipole / quadrupole moments per neighbour species; lane 0
 //                    applies the embedding function and stores F'(rho_i).
-//   eam_pair_kernel  one lane per directed pair: dE/dD from the centre's F',
-//                    moments and the pair functions' derivatives.
-// Forces / virial / energy then use the same force_gather and frame_reduce
-// kernels as the symmetry-function path.
+//   eam_force_kernel (plain EAM) forces and per-atom virial of a centre in one pass.
+//   eam_pair_kernel  (ADP, nn pair functions) one lane per directed pair: dE/dD from the centre's F',
+//                    moments and the pair functions' derivatives; forces / virial then come from the
+//                    same force_gather kernel as the symmetry-function path.
+// frame_reduce sums the frames as for the symmetry-function path.
 //
 // "nn" functions (the reference's default potentials, alloy.py:110-112, adp.py:120-124): rho(r),
 // phi(r), u(r), w(r) and F(rho) given by `convolution1x1` on the scalar argument (eam.py:174-190,
@@ -131,15 +132,43 @@ __host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u
 // `el`: the per-element constants [nel][20], `phx`: the Zjw04xcp cross terms [pair types][7].
 
 // f(r) = a exp(-b (r/re - 1)) / (1 + (r/re - c)^20)   (generic.py:102-117)
+// 1 / re is loop-invariant in every caller (one division per wavefront, not two per pair)
 template <typename T>
 __device__ __forceinline__ void zhou_exp(double r, T a, T b, T c, T re, T &f, T &df) {
-  const T x = r / re;
+  const T inv_re = 1.0 / re;
+  const T x = r * inv_re;
   const T t = x - c;
   const T t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
   const T t20 = t16 * t4, t19 = t16 * t2 * t;
   const T den = 1.0 / (1.0 + t20);
   f = a * t_exp(-b * (x - 1.0)) * den;
-  df = f * (-b - 20.0 * t19 * den) / re;
+  df = f * (-b - 20.0 * t19 * den) * inv_re;
+}
+// Like pairs of a Zjw04 element: rho(r) and the second term of phi(r) are the SAME function up to the
+// prefactor (f_e against B; both use beta, lambda: zjw04.py:229-243, generic.py:102-117), so the pair
+// costs two exponentials and two quotients instead of three.
+template <typename T>
+__device__ __forceinline__ void zjw_rho_phi_aa(const T *p, double r, T &rho, T &drho, T &phi, T &dphi) {
+  const T inv_re = 1.0 / p[R_EQ];
+  const T x = r * inv_re;
+  T fa, dfa;
+  {
+    const T t = x - p[KAPPA];
+    const T t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+    const T den = 1.0 / (1.0 + t16 * t4);
+    fa = p[PA] * t_exp(-p[ALPHA] * (x - 1.0)) * den;
+    dfa = fa * (-p[ALPHA] - 20.0 * (t16 * t2 * t) * den) * inv_re;
+  }
+  const T t = x - p[LAMDA];
+  const T t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+  const T den = 1.0 / (1.0 + t16 * t4);
+  const T core = t_exp(-p[BETA] * (x - 1.0)) * den;
+  const T dlog = (-p[BETA] - 20.0 * (t16 * t2 * t) * den) * inv_re;
+  const T fb = p[PB] * core;
+  rho = p[F_EQ] * core;
+  drho = rho * dlog;
+  phi = fa - fb;
+  dphi = dfa - fb * dlog;
 }
 
 template <typename T>
@@ -350,14 +379,17 @@ __device__ __forceinline__ void mishin_polar(double r, T p1, T p2, T p3, T rc, T
 
 // moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
 // in the order xx yy zz yz xz xy
-template <bool OTHER>
+// W lanes per atom (16: one DPP row, four atoms per wavefront; 64: one wavefront per atom): an atom
+// with n neighbours occupies ceil(n / W) W lane slots, so narrow groups waste fewer lanes (n = 90: 96
+// slots against 128) while wide ones put more wavefronts in flight for a single small frame.
+template <bool OTHER, int W>
 __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBatch b, double *dF,
                                                           double *mom, double eps,
                                                           const double *__restrict__ pf, size_t ps,
                                                           double *rho_buf, int geom_done,
                                                           const TabDev *__restrict__ tabs) {
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / W;
+  const int lane = threadIdx.x & (W - 1);
   if (i >= b.n_atoms) return;
   const int nel = P.nel;
   const int sA = b.species[i];
@@ -371,7 +403,9 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     const bool u_nn = (P.nn_u >> pt) & 1u, w_nn = (P.nn_w >> pt) & 1u;
     const bool rho_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
     const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
-    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+    // like pairs of a Zjw04 element: rho and phi share an exponential and a quotient
+    const bool fused_aa = !OTHER && sb == sA && !rho_nn && !rho_tab && !phi_nn && !phi_tab;
+    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += W) {
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
       double rec[5];
@@ -406,16 +440,20 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       }
       if (P.list_rc2 > 0.0 && !(rec[3] < P.list_rc2)) continue;  // beyond rc: not a neighbour
       const double r = sqrt(rec[3]);
-      double f, df;
-      // density function of the NEIGHBOUR's element (alloy.py:176)
-      if (rho_nn) f = pf[PF_RHO * ps + q];
-      else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
-      else el_rho<OTHER, double>(P, P.el, sb, r, f, df);
+      double f, df = 0.0, fp, dfp = 0.0;
+      if (fused_aa) {
+        zjw_rho_phi_aa<double>(P.el[sb], r, f, df, fp, dfp);
+      } else {
+        // density function of the NEIGHBOUR's element (alloy.py:176)
+        if (rho_nn) f = pf[PF_RHO * ps + q];
+        else if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
+        else el_rho<OTHER, double>(P, P.el, sb, r, f, df);
+        if (phi_nn) fp = pf[PF_PHI * ps + q];
+        else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fp, dfp);
+        else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, fp, dfp);
+      }
       rho += f;
-      if (phi_nn) f = pf[PF_PHI * ps + q];
-      else if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, f, df);
-      else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, f, df);
-      phis += f;
+      phis += fp;
       if (P.adp) {
         const double dx = rec[0], dy = rec[1], dz = rec[2];
         double u, du, w, dw;
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     }
     if (P.adp) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) m[k] = wave_sum(m[k]);
+      for (int k = 0; k < 9; ++k) m[k] = group_sum<W>(m[k]);
       if (lane == 0) {
         const double nu = m[3] + m[4] + m[5];
         // 1/2 |mu|^2 + 1/2 sum_ab lambda_ab^2 - 1/6 (tr lambda)^2, per k-body term (adp.py:371-392, :458-492)
@@ -459,8 +497,8 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       }
     }
   }
-  rho = wave_sum(rho);
-  phis = wave_sum(phis);
+  rho = group_sum<W>(rho);
+  phis = group_sum<W>(phis);
   if (lane == 0) {
     if ((P.nn_embed >> sA) & 1u) {  // F(rho) is added by eam_nn_embed_kernel
       rho_buf[i] = rho;
@@ -816,11 +854,12 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
 // it is recomputed from an 8-byte gather of F'(rho_j) instead of a 32-byte random gather of a stored
 // g[rev p]; neither g nor the reverse-pair index is touched (eam.py:495-570 differentiated;
 // basic.py:277-331). One wavefront per atom, 16 atoms per workgroup (= one record of `bpart`).
-template <bool OTHER>
-__global__ __launch_bounds__(1024) void eam_force_kernel(EamParams P, DeviceBatch b, const double *dF,
-                                                         const TabDev *__restrict__ tabs) {
-  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+// W lanes per atom (see eam_atom_kernel), 16 atoms per workgroup (= one record of `bpart`).
+template <bool OTHER, int W>
+__global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBatch b, const double *dF,
+                                                           const TabDev *__restrict__ tabs) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x / W);
+  const int lane = threadIdx.x & (W - 1);
   const bool active = i < b.n_atoms;
   const int nel = P.nel;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -832,20 +871,25 @@ __global__ __launch_bounds__(1024) void eam_force_kernel(EamParams P, DeviceBatc
     for (int sb = 0; sb < nel; ++sb) {
       const int pt = pair_type(sA, sb, nel);
       const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
-      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += W) {
         const double2 *rec = pair_geom(b, (size_t)q);
         const double2 v0 = rec[0], v1 = rec[1];
         if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
         const double dFj = dF[b.pair_j[q]];
         const double r = sqrt(v1.y);
         double fn, drhoB, drhoA, dphi;
-        if (rhoB_tab) spline_eval(tabs[slot_rho(sb)], r, fn, drhoB);
-        else el_rho<OTHER, double>(P, P.el, sb, r, fn, drhoB);
-        if (sb == sA) drhoA = drhoB;
-        else if (rhoA_tab) spline_eval(tabs[slot_rho(sA)], r, fn, drhoA);
-        else el_rho<OTHER, double>(P, P.el, sA, r, fn, drhoA);
-        if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
-        else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, fn, dphi);
+        if (!OTHER && sb == sA && !rhoB_tab && !phi_tab) {
+          zjw_rho_phi_aa<double>(P.el[sb], r, fn, drhoB, fn, dphi);
+          drhoA = drhoB;
+        } else {
+          if (rhoB_tab) spline_eval(tabs[slot_rho(sb)], r, fn, drhoB);
+          else el_rho<OTHER, double>(P, P.el, sb, r, fn, drhoB);
+          if (sb == sA) drhoA = drhoB;
+          else if (rhoA_tab) spline_eval(tabs[slot_rho(sA)], r, fn, drhoA);
+          else el_rho<OTHER, double>(P, P.el, sA, r, fn, drhoA);
+          if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
+          else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, fn, dphi);
+        }
         const double inv_r = 1.0 / r;
         const double own = (dFi * drhoB + 0.5 * dphi) * inv_r;   // g[p] = own D
         const double both = own + (dFj * drhoA + 0.5 * dphi) * inv_r;  // g[p] - g[rev p] = both D
@@ -860,9 +904,9 @@ __global__ __launch_bounds__(1024) void eam_force_kernel(EamParams P, DeviceBatc
     }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) f[k] = wave_sum(f[k]);
+  for (int k = 0; k < 3; ++k) f[k] = group_sum<W>(f[k]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = wave_sum(w[k]);
+  for (int k = 0; k < 9; ++k) w[k] = group_sum<W>(w[k]);
   if (lane == 0 && active)
     for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
   block_partials(b, blockIdx.x, i, active, lane == 0, w);
@@ -1670,13 +1714,35 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   }
   bool other = false;
   for (int e = 0; e < m->p.nel; ++e) other = other || m->p.el_kind[e] != 0;
-  const dim3 agrid((unsigned)((b.n_atoms * 64 + kBlock - 1) / kBlock));
-  if (other)
-    hipLaunchKernelGGL(eam_atom_kernel<true>, agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf,
-                       ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev);
-  else
-    hipLaunchKernelGGL(eam_atom_kernel<false>, agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps, m->pf,
-                       ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev);
+  // plain EAM with analytic / tabulated pair functions: forces in one pass per centre (eam_force_kernel);
+  // ADP moments or nn pair functions: dE/dD per pair, then the shared force gather
+  static const bool no_fold = getenv("TA_EAM_NO_FOLD") != nullptr;    // A/B switches
+  static const int w_env = getenv("TA_EAM_W") ? atoi(getenv("TA_EAM_W")) : 0;
+  const bool want_f = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0;
+  const bool fold = want_f && !m->p.adp && !pair_nets && !no_fold;
+  // lanes per atom (measured, 4000-atom Ni frames, rc 6.5, us per frame for W = 16 / 32 / 64): EAM one
+  // frame 25.5 / 26.2 / 28.0, 64 frames 11.3 / 14.1 / 16.7; ADP one frame 48.4 / 47.1 / 47.3, 64 frames
+  // 24.4 / 24.8 / 27.3
+  const int W = w_env == 16 || w_env == 32 || w_env == 64 ? w_env
+                : (!m->p.adp || b.n_atoms >= 32768) ? 16 : 32;
+  const dim3 agrid((unsigned)((b.n_atoms * W + kBlock - 1) / kBlock));
+#define TA_EAM_ATOM(O, WW)                                                                                   \
+  hipLaunchKernelGGL((eam_atom_kernel<O, WW>), agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps,    \
+                     m->pf, ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev)
+#define TA_EAM_BY_W(MACRO)                            \
+  do {                                                \
+    if (other) {                                      \
+      if (W == 16) MACRO(true, 16);                   \
+      else if (W == 32) MACRO(true, 32);              \
+      else MACRO(true, 64);                           \
+    } else {                                          \
+      if (W == 16) MACRO(false, 16);                  \
+      else if (W == 32) MACRO(false, 32);             \
+      else MACRO(false, 64);                          \
+    }                                                 \
+  } while (0)
+  TA_EAM_BY_W(TA_EAM_ATOM);
+#undef TA_EAM_ATOM
   if (m->embed_nets) {
     EmbedTiles t;
     std::memset(&t, 0, sizeof(t));
@@ -1694,16 +1760,13 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
                          net_lds_bytes(m), s, m->nets_dev, t, m->activation, b, m->rho_buf, m->dF,
                          m->stride);
   }
-  if ((want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0) {
-    // plain EAM with analytic / tabulated pair functions: one pass per centre (eam_force_kernel);
-    // ADP moments or nn pair functions: dE/dD per pair, then the shared force gather
-    static const bool no_fold = getenv("TA_EAM_NO_FOLD") != nullptr;  // A/B switch
-    if (!m->p.adp && !pair_nets && !no_fold) {
+  if (want_f) {
+    if (fold) {
       const dim3 fgrid((unsigned)((b.n_atoms + 15) / 16));
-      if (other)
-        hipLaunchKernelGGL(eam_force_kernel<true>, fgrid, dim3(1024), 0, s, m->p, b, m->dF, m->tabs_dev);
-      else
-        hipLaunchKernelGGL(eam_force_kernel<false>, fgrid, dim3(1024), 0, s, m->p, b, m->dF, m->tabs_dev);
+#define TA_EAM_FORCE(O, WW) \
+  hipLaunchKernelGGL((eam_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->tabs_dev)
+      TA_EAM_BY_W(TA_EAM_FORCE);
+#undef TA_EAM_FORCE
     } else {
       const dim3 pgrid((unsigned)((b.n_pairs + kBlock - 1) / kBlock));
       if (other)
@@ -1717,6 +1780,7 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   } else if (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) {
     launch_force_gather(sf, b, s);
   }
+#undef TA_EAM_BY_W
 }
 
 }  // namespace ta

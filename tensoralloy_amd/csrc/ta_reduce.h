@@ -10,11 +10,15 @@ namespace ta {
 
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {
-  static_assert(W == 16 || W == 64, "groups are one DPP row or one wavefront");
-  if constexpr (W == 16)
+  static_assert(W == 16 || W == 32 || W == 64, "groups are one DPP row, half a wavefront or a wavefront");
+  if constexpr (W == 16) {
     return row16_sum(v);
-  else
+  } else if constexpr (W == 32) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+  } else {
     return wave_sum(v);
+  }
 }
 
 __device__ __forceinline__ int radial_term_of(int center, int other) {
@@ -103,8 +107,8 @@ __device__ __forceinline__ void atom_descriptors(const SFParams &sf, const Devic
 __device__ __forceinline__ void block_partials(const DeviceBatch &b, int group, int64_t i, bool active,
                                                bool row_leader, const double (&w)[9]) {
   __shared__ double part[16][10];
-  const int row = threadIdx.x >> 4;  // 16 lanes per atom in force_gather, one wavefront in the EAM kernel
-  const int slot = (blockDim.x == 256) ? row : (int)(threadIdx.x >> 6);
+  // 16 atoms per workgroup: 16 lanes per atom in force_gather, 16 / 32 / 64 in the EAM force kernel
+  const int slot = (int)(threadIdx.x / (blockDim.x >> 4));
   const int64_t first = (int64_t)group * 16, last = min(first + 16, b.n_atoms) - 1;
   const bool one_frame = b.frame_of_atom[first] == b.frame_of_atom[last];
   if (row_leader) {
