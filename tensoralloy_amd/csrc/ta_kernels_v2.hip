@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <type_traits>
 
 #include "ta_device.h"
 #include "ta_math.h"
@@ -280,9 +281,6 @@ __device__ __forceinline__ JobLists job_lists(const Fields &f) {
   return j;
 }
 __device__ __forceinline__ int job_item(uint32_t w) { return (int)(w & 255u); }
-__device__ __forceinline__ unsigned long long job_bits(uint32_t w) {
-  return (unsigned long long)(w >> 16) << (16 * ((w >> 8) & 3u));
-}
 
 // byte offset of the job counters (kJobCtlBytes) and, behind
 // them, of the forward kernel's per-pair partial sums P[n_local][cap]
@@ -460,7 +458,10 @@ __global__ __launch_bounds__(kBlock)
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
   // `pacc`: job mode, the sums of this (pair, partner subset) are ADDED to P[channel][item] in LDS
-  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out, double *pacc = nullptr) {
+  // `is_job` (std::true_type): `mask0` is a job word (see make_jobs): 16 candidate bits and their window,
+  // walked with 32-bit operations and without the loop over blocks of 64 candidate steps
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out, double *pacc, auto is_job) {
+    constexpr bool kJob = decltype(is_job)::value;
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -487,27 +488,15 @@ __global__ __launch_bounds__(kBlock)
 #pragma unroll
       for (int k = 0; k < 5; ++k) mom[sp][k] = 0.0;
 
-    const int smax = (Ha != 0.0) ? n / 2 : 0;
-    for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask;
-      if (have_mask) {
-        mask = (flags & (1 << 24)) ? 0ull : mask0;  // bit 24: measurement switch, triple bodies off
-      } else {
-        mask = partner_mask(sf, f, base, n, a, sc, smax);
-        // the candidate mask is geometry only: keep it for the backward kernel
-        if (b.masks) b.masks[(size_t)(sc >> 6) * b.n_pairs + p] = mask;
-      }
-      while (mask) {
-        const int k = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        int bl = a + sc + k;
+    // one candidate partner: position a + step of the centre's ring
+    auto triple = [&](int bl) {
         if (bl >= n) bl -= n;
         const int q = base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
         const double ex = bxy.x - ax, ey = bxy.y - ay, ez = bzr.x - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
-        if (!(u < 1.0)) continue;  // exact test (the mask is a superset); H_b = 0 adds nothing
+        if (!(u < 1.0)) return;  // exact test (the mask is a superset); H_b = 0 adds nothing
         const double2 bih = f.ih[q];
         const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ra * bih.x;
         const double common = Ha * bih.y * hd_value<HD>(sf, ch, beta, u);
@@ -542,7 +531,33 @@ __global__ __launch_bounds__(kBlock)
             }
           }
         }
+    };
+    if constexpr (kJob) {
+      const uint32_t jw = (uint32_t)mask0;
+      unsigned m = (flags & (1 << 24)) ? 0u : jw >> 16;  // bit 24: measurement switch, triple bodies off
+      const int k0 = a + 1 + 16 * (int)((jw >> 8) & 3u);
+      while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1;
+        triple(k0 + k);
       }
+    } else {
+    const int smax = (Ha != 0.0) ? n / 2 : 0;
+    for (int sc = 1; sc <= smax; sc += 64) {
+      unsigned long long mask;
+      if (have_mask) {
+        mask = (flags & (1 << 24)) ? 0ull : mask0;
+      } else {
+        mask = partner_mask(sf, f, base, n, a, sc, smax);
+        // the candidate mask is geometry only: keep it for the backward kernel
+        if (b.masks) b.masks[(size_t)(sc >> 6) * b.n_pairs + p] = mask;
+      }
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        triple(a + sc + k);
+      }
+    }
     }
     if constexpr (DEFZ) {
 #pragma unroll
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(kBlock)
           const int slot = job_slot(r, threadIdx.x, blockDim.x);
           if (slot < n_jobs) {
             const uint32_t jw = jl.word[slot];
-            run_item(job_item(jw), true, job_bits(jw), nullptr, P);
+            run_item(job_item(jw), true, jw, nullptr, P, std::true_type{});
           }
         }
       __syncthreads();
@@ -638,7 +653,7 @@ __global__ __launch_bounds__(kBlock)
       double mine[kLocal];
 #pragma unroll
       for (int k = 0; k < kLocal; ++k) mine[k] = 0.0;
-      if (active) run_item(item, true, mask, mine);
+      if (active) run_item(item, true, mask, mine, nullptr, std::false_type{});
       __syncthreads();  // nobody reads x .. G or the sort scratch any more
       double *red = reinterpret_cast<double *>(f.xy);
 #pragma unroll
@@ -656,11 +671,11 @@ __global__ __launch_bounds__(kBlock)
       }
       return;
     }
-    if (active) run_item(item, true, mask, nullptr);
+    if (active) run_item(item, true, mask, nullptr, nullptr, std::false_type{});
     }
   } else {
     if (b.job_count && threadIdx.x == 0) b.job_count[blockIdx.x] = -1;  // no list: the backward kernel scans itself
-    for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, nullptr);
+    for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, nullptr, nullptr, std::false_type{});
   }
 
   // Last forward launch of the evaluation (flags & 2): the workgroup owns whole centres, so it
@@ -711,7 +726,8 @@ __global__ __launch_bounds__(kBlock)
   stage(sf, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
-  auto run_item = [&](int item, bool have_mask, unsigned long long mask0) {
+  auto run_item = [&](int item, bool have_mask, unsigned long long mask0, auto is_job) {
+    constexpr bool kJob = decltype(is_job)::value;  // see the forward kernel
     const int64_t p = (int64_t)s0 + item;
     const int i = b.pair_i[p];
     const int base = b.pair_start[i] - s0;
@@ -761,16 +777,7 @@ __global__ __launch_bounds__(kBlock)
       }
     }
     double gx = 0.0, gy = 0.0, gz = 0.0;
-    const int smax = (Ha != 0.0) ? n / 2 : 0;
-    for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = have_mask ? mask0
-                                : (b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
-                                           : partner_mask(sf, f, base, n, a, sc, smax));
-      if (flags & (1 << 24)) mask = 0ull;  // measurement switch: triple bodies off
-      while (mask) {
-        const int k = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        int bl = a + sc + k;
+    auto triple = [&](int bl) {
         if (bl >= n) bl -= n;
         const int q = base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(kBlock)
         const double ex = bx - ax, ey = by - ay, ez = bz - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
         const double u = d2 * sf.inv_ac2;
-        if (!(u < 1.0)) continue;  // exact test (the mask is a superset)
+        if (!(u < 1.0)) return;  // exact test (the mask is a superset)
         const double2 bih = f.ih[q], bgs = f.gs[q];
         const double inv_rb = bih.x;
         const double inv_ab = inv_ra * inv_rb;
@@ -834,7 +841,29 @@ __global__ __launch_bounds__(kBlock)
         atomicAdd(&gacc[q], fma(cb, bx, -Q * ax));
         atomicAdd(&gacc[kCap + q], fma(cb, by, -Q * ay));
         atomicAdd(&gacc[2 * kCap + q], fma(cb, bz, -Q * az));
+    };
+    if constexpr (kJob) {
+      const uint32_t jw = (uint32_t)mask0;
+      unsigned m = (flags & (1 << 24)) ? 0u : jw >> 16;  // bit 24: measurement switch, triple bodies off
+      const int k0 = a + 1 + 16 * (int)((jw >> 8) & 3u);
+      while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1;
+        triple(k0 + k);
       }
+    } else {
+    const int smax = (Ha != 0.0) ? n / 2 : 0;
+    for (int sc = 1; sc <= smax; sc += 64) {
+      unsigned long long mask = have_mask ? mask0
+                                : (b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
+                                           : partner_mask(sf, f, base, n, a, sc, smax));
+      if (flags & (1 << 24)) mask = 0ull;
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        triple(a + sc + k);
+      }
+    }
     }
     atomicAdd(&gacc[item], gx);
     atomicAdd(&gacc[kCap + item], gy);
@@ -857,7 +886,7 @@ __global__ __launch_bounds__(kBlock)
         const int slot = job_slot(r, threadIdx.x, blockDim.x);
         if (slot < n_jobs) {
           const uint32_t jw = b.job_word[jbase + slot];
-          run_item(job_item(jw), true, job_bits(jw));
+          run_item(job_item(jw), true, jw, std::true_type{});
         }
       }
     } else if (one_pass) {  // see deal_by_popcount
@@ -871,9 +900,9 @@ __global__ __launch_bounds__(kBlock)
           mask = b.masks ? b.masks[p] : partner_mask(sf, f, base, n_own, item - base, 1, smax);
       }
       deal_by_popcount(f, kCap, M, item, mask);
-      if (active) run_item(item, true, mask);
+      if (active) run_item(item, true, mask, std::false_type{});
     } else {
-      for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull);
+      for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, std::false_type{});
     }
   }
   __syncthreads();
