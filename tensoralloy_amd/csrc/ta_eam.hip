@@ -405,7 +405,26 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
     // like pairs of a Zjw04 element: rho and phi share an exponential and a quotient
     const bool fused_aa = !OTHER && sb == sA && !rho_nn && !rho_tab && !phi_nn && !phi_tab;
-    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += W) {
+    // The pair loop is a chain of dependent loads (pair_j -> position of j) in front of ~300
+    // instructions, and a group makes several passes: the neighbour index and shift of the pass after
+    // next and the neighbour position of the next pass are fetched before this pass is evaluated.
+    const int q1 = seg[sb + 1];
+    int q = seg[sb] + lane;
+    int jn = 0, sn[3] = {0, 0, 0}, j2 = 0, s2[3] = {0, 0, 0};
+    double pn[3] = {0.0, 0.0, 0.0};
+    if (!geom_done) {
+      if (q < q1) {
+        jn = b.pair_j[q];
+        for (int c = 0; c < 3; ++c) sn[c] = b.pair_shift[3 * (size_t)q + c];
+      }
+      if (q + W < q1) {
+        j2 = b.pair_j[q + W];
+        for (int c = 0; c < 3; ++c) s2[c] = b.pair_shift[3 * (size_t)(q + W) + c];
+      }
+      if (q < q1)
+        for (int c = 0; c < 3; ++c) pn[c] = b.pos[3 * (size_t)jn + c];
+    }
+    for (; q < q1; q += W) {
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
       double rec[5];
@@ -417,11 +436,18 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
         rec[2] = c.x;
         rec[3] = c.y;
       } else {
-        const int j = b.pair_j[q];
+        const double rj[3] = {pn[0], pn[1], pn[2]};
+        const double sx = (double)sn[0], sy = (double)sn[1], sz = (double)sn[2];
+        if (q + W < q1) {
+          for (int c = 0; c < 3; ++c) pn[c] = b.pos[3 * (size_t)j2 + c];
+          for (int c = 0; c < 3; ++c) sn[c] = s2[c];
+        }
+        if (q + 2 * W < q1) {
+          j2 = b.pair_j[q + 2 * W];
+          for (int c = 0; c < 3; ++c) s2[c] = b.pair_shift[3 * (size_t)(q + 2 * W) + c];
+        }
         const double *h = b.cells + 9 * (size_t)b.frame_of_atom[i];
-        const double sx = (double)b.pair_shift[3 * (size_t)q], sy = (double)b.pair_shift[3 * (size_t)q + 1],
-                     sz = (double)b.pair_shift[3 * (size_t)q + 2];
-        const double *ri = b.pos + 3 * (size_t)i, *rj = b.pos + 3 * (size_t)j;
+        const double *ri = b.pos + 3 * (size_t)i;
         rec[0] = (rj[0] - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
         rec[1] = (rj[1] - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
         rec[2] = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
@@ -871,11 +897,31 @@ __global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBa
     for (int sb = 0; sb < nel; ++sb) {
       const int pt = pair_type(sA, sb, nel);
       const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
-      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += W) {
+      // as in eam_atom_kernel: the record and F'(rho_j) of the next pass and the neighbour index of the
+      // pass after next are fetched before this pass is evaluated
+      const int q1 = seg[sb + 1];
+      int q = seg[sb] + lane;
+      double2 n0 = make_double2(0.0, 0.0), n1 = n0;
+      double dFn = 0.0;
+      int j2 = 0;
+      if (q < q1) {
         const double2 *rec = pair_geom(b, (size_t)q);
-        const double2 v0 = rec[0], v1 = rec[1];
+        n0 = rec[0];
+        n1 = rec[1];
+        dFn = dF[b.pair_j[q]];
+      }
+      if (q + W < q1) j2 = b.pair_j[q + W];
+      for (; q < q1; q += W) {
+        const double2 v0 = n0, v1 = n1;
+        const double dFj = dFn;
+        if (q + W < q1) {
+          const double2 *rec = pair_geom(b, (size_t)(q + W));
+          n0 = rec[0];
+          n1 = rec[1];
+          dFn = dF[j2];
+        }
+        if (q + 2 * W < q1) j2 = b.pair_j[q + 2 * W];
         if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
-        const double dFj = dF[b.pair_j[q]];
         const double r = sqrt(v1.y);
         double fn, drhoB, drhoA, dphi;
         if (!OTHER && sb == sA && !rhoB_tab && !phi_tab) {
