@@ -77,6 +77,8 @@ def complete_cell(cell) -> np.ndarray:
     """`Atoms.get_cell(complete=True)`: fill zero lattice vectors with unit
     vectors orthogonal to the others."""
     cell = np.array(cell, dtype=np.float64).reshape(3, 3)
+    if cell.any(axis=1).all():  # three lattice vectors: nothing to fill in
+        return cell
     missing = [a for a in range(3) if not np.any(cell[a])]
     if len(missing) == 3:
         return np.eye(3)
@@ -202,7 +204,8 @@ class Atoms:
 
     def copy(self):
         a = Atoms(numbers=self.numbers.copy(), positions=self.positions.copy(),
-                  cell=self._cell.copy(), pbc=self.pbc.copy(), info=_copy.deepcopy(self.info))
+                  cell=self._cell.copy(), pbc=self.pbc.copy(),
+                  info=_copy.deepcopy(self.info) if self.info else {})
         return a
 
     def repeat(self, rep):

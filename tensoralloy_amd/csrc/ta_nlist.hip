@@ -97,6 +97,47 @@ __global__ __launch_bounds__(1024) void scan_kernel(int n, const int32_t *in, in
   }
 }
 
+// The MD step's variant: exclusive scan of the per-(atom, species) counts AND pair_start (every
+// (nel + 1)-th entry of the result) in one launch; the statistics finish_starts_kernel collects are
+// not read on that path.
+__global__ __launch_bounds__(1024) void scan_starts_kernel(int n_atoms, int nel, const int32_t *in,
+                                                           int32_t *out, int32_t *pair_start) {
+  __shared__ int wtot[16];
+  const int t = threadIdx.x;
+  const int n = n_atoms * (nel + 1);
+  // whole atoms per lane, so that a lane's first entry is an atom's first segment
+  const int apl = (n_atoms + 1023) / 1024;
+  const int a_lo = min(n_atoms, t * apl), a_hi = min(n_atoms, a_lo + apl);
+  const int lo = a_lo * (nel + 1), hi = a_hi * (nel + 1);
+  // eight loads in flight per lane: one workgroup does this, and it is latency all the way
+  int s = 0;
+  for (int k = lo; k < hi; k += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = in[min(k + u, hi - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (k + u < hi) ? v[u] : 0;
+  }
+  const int incl = block_scan_1024(s, wtot);
+  int run = incl - s;
+  for (int k = lo; k < hi; k += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = in[min(k + u, hi - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < hi) {
+        out[k + u] = run;
+        if ((k + u) % (nel + 1) == 0) pair_start[(k + u) / (nel + 1)] = run;
+        run += v[u];
+      }
+  }
+  if (t == 1023) {
+    out[n] = incl;
+    pair_start[n_atoms] = incl;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_bins_kernel(int n_atoms, const int32_t *binid,
                                                            const int32_t *bin_start,
                                                            int32_t *bin_cursor, int32_t *bin_atoms) {
@@ -336,7 +377,14 @@ __device__ __forceinline__ void pack_blocks_body(int n_atoms, const PackArgs &pk
   int base = 0;
   for (int r0 = 0; r0 < n_atoms; r0 += kPackRound) {
     const int nr = min(kPackRound, n_atoms - r0);
-    for (int idx = t; idx <= nr; idx += T) ps[idx] = pair_start[r0 + idx];
+    for (int idx = t; idx <= nr; idx += 8 * T) {  // eight loads in flight per lane
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pair_start[r0 + min(idx + u * T, nr)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (idx + u * T <= nr) ps[idx + u * T] = v[u];
+    }
     __syncthreads();
     const int lo = min(nr, t * kPackChunk), hi = min(nr, lo + kPackChunk);
     int nb = 0, load = 0, nc = 0;
@@ -572,10 +620,7 @@ void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double 
   hipLaunchKernelGGL(filter_kernel<0>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
                      seg_super, pj_super, ps_super, counts, (const int32_t *)nullptr, (int32_t *)nullptr,
                      (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, stats, none);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_atoms * (nel + 1), counts, seg_exact,
-                     reinterpret_cast<int32_t *>(stats) + 4);
-  hipLaunchKernelGGL(finish_starts_kernel, dim3(nblk(n_atoms + 1, kBlock)), dim3(kBlock), 0, s, n_atoms, nel,
-                     seg_exact, counts, pair_start, stats, reinterpret_cast<int32_t *>(stats) + 2, stats + 4);
+  hipLaunchKernelGGL(scan_starts_kernel, dim3(1), dim3(1024), 0, s, n_atoms, nel, counts, seg_exact, pair_start);
   const PackArgs pk{cap, pair_start, blk_center, n_blk_dev, max_blk};
   const dim3 fgrid(agrid.x + (blk_center ? 1u : 0u));
   hipLaunchKernelGGL(filter_kernel<1>, fgrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,

@@ -127,15 +127,16 @@ class Engine:
         """Copy back what `want` asked for; arrays cover the whole batch."""
         info = self.info
         N, F = int(info.n_atoms), int(info.n_frames)
-        out = {"energy": np.zeros(F)}
+        # (the library fills every array it is handed, or fails)
+        out = {"energy": np.empty(F)}
         forces = virial = atomic = desc = None
         if want & (_lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL):
-            forces = np.zeros((N, 3))
-            virial = np.zeros((F, 3, 3))
+            forces = np.empty((N, 3))
+            virial = np.empty((F, 3, 3))
         if want & _lib.TA_WANT_ATOMIC:
-            atomic = np.zeros(N)
+            atomic = np.empty(N)
         if descriptors:
-            desc = np.zeros((N, int(info.descriptor_dim)))
+            desc = np.empty((N, int(info.descriptor_dim)))
         null = C.POINTER(C.c_double)()
         self._check(self._lib.ta_get_results(
             self._handle, _lib.as_dp(out["energy"]),
