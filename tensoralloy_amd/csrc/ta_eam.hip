@@ -18,7 +18,8 @@
 //                    dipole / quadrupole moments per neighbour species; lane 0
 //                    applies the embedding function and stores F'(rho_i).
 //   eam_force_kernel (plain EAM) forces and per-atom virial of a centre in one pass.
-//   eam_pair_kernel  (ADP, nn pair functions) one lane per directed pair: dE/dD from the centre's F',
+//   adp_force_kernel (ADP) the same with the dipole / quadrupole terms (moments of j gathered).
+//   eam_pair_kernel  (nn pair functions) one lane per directed pair: dE/dD from the centre's F',
 //                    moments and the pair functions' derivatives; forces / virial then come from the
 //                    same force_gather kernel as the symmetry-function path.
 // frame_reduce sums the frames as for the symmetry-function path.
@@ -958,6 +959,131 @@ __global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBa
   block_partials(b, blockIdx.x, i, active, lane == 0, w);
 }
 
+// ADP with analytic / tabulated functions: the same one pass per centre. The reverse pair (centre j,
+// neighbour i, -D) has the same r and pair type, hence the same u, u', w, w', rho', phi'; what differs
+// are the centre's quantities, F'(rho_j) and the moments mu_j, Lambda_j of j for the neighbour species
+// of i, a 72-byte gather instead of the 32-byte store and the 64 bytes read back per pair by
+// eam_pair_kernel + force_gather (adp.py:315-498 differentiated; basic.py:277-331):
+//   g[p]     =  (c_i + k_i) D + u mu_i + 2 w Lambda_i D,   c = (F' rho' + phi' / 2) / r,
+//   g[rev p] = -(c_j + k_j) D + u mu_j - 2 w Lambda_j D,   k_i = ( mu_i.D u' + D.Lambda_i.D w') / r,
+//                                                          k_j = (-mu_j.D u' + D.Lambda_j.D w') / r.
+template <bool OTHER, int W>
+__global__ __launch_bounds__(16 * W) void adp_force_kernel(EamParams P, DeviceBatch b, const double *dF,
+                                                           const double *__restrict__ mom,
+                                                           const TabDev *__restrict__ tabs) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x / W);
+  const int lane = threadIdx.x & (W - 1);
+  const bool active = i < b.n_atoms;
+  const int nel = P.nel;
+  double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    const int sA = b.species[i];
+    const double dFi = dF[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    for (int sb = 0; sb < nel; ++sb) {
+      const int pt = pair_type(sA, sb, nel);
+      const double *pp = P.pair[pt];
+      const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
+      const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
+      double mi[9];
+      {
+        const double *src = mom + ((size_t)i * nel + sb) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mi[k] = src[k];
+      }
+      // pipelined as eam_force_kernel: record, F'(rho_j) and the moments of j for the next pass
+      const int q1 = seg[sb + 1];
+      int q = seg[sb] + lane;
+      double2 n0 = make_double2(0.0, 0.0), n1 = n0;
+      double dFn = 0.0, mn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      int j2 = 0;
+      if (q < q1) {
+        const double2 *rec = pair_geom(b, (size_t)q);
+        n0 = rec[0];
+        n1 = rec[1];
+        const int j = b.pair_j[q];
+        dFn = dF[j];
+        const double *src = mom + ((size_t)j * nel + sA) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mn[k] = src[k];
+      }
+      if (q + W < q1) j2 = b.pair_j[q + W];
+      for (; q < q1; q += W) {
+        const double2 v0 = n0, v1 = n1;
+        const double dFj = dFn;
+        double mj[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mj[k] = mn[k];
+        if (q + W < q1) {
+          const double2 *rec = pair_geom(b, (size_t)(q + W));
+          n0 = rec[0];
+          n1 = rec[1];
+          dFn = dF[j2];
+          const double *src = mom + ((size_t)j2 * nel + sA) * 9;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) mn[k] = src[k];
+        }
+        if (q + 2 * W < q1) j2 = b.pair_j[q + 2 * W];
+        if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
+        const double r = sqrt(v1.y);
+        double fn, drhoB, drhoA, dphi;
+        if (!OTHER && sb == sA && !rhoB_tab && !phi_tab) {
+          zjw_rho_phi_aa<double>(P.el[sb], r, fn, drhoB, fn, dphi);
+          drhoA = drhoB;
+        } else {
+          if (rhoB_tab) spline_eval(tabs[slot_rho(sb)], r, fn, drhoB);
+          else el_rho<OTHER, double>(P, P.el, sb, r, fn, drhoB);
+          if (sb == sA) drhoA = drhoB;
+          else if (rhoA_tab) spline_eval(tabs[slot_rho(sA)], r, fn, drhoA);
+          else el_rho<OTHER, double>(P, P.el, sA, r, fn, drhoA);
+          if (phi_tab) spline_eval(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
+          else pair_phi<OTHER, double>(P, P.el, P.phi, sA, sb, r, fn, dphi);
+        }
+        double u, du, wq, dw;
+        if (u_tab) spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
+        else mishin_polar<double>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        if (w_tab) spline_eval(tabs[slot_pair(nel, 3, pt)], r, wq, dw);
+        else mishin_polar<double>(r, pp[3], pp[4], pp[5], pp[7], pp[6], wq, dw);
+        const double inv_r = 1.0 / r;
+        const double dx = v0.x, dy = v0.y, dz = v1.x;
+        // own side
+        const double muD = mi[0] * dx + mi[1] * dy + mi[2] * dz;
+        const double lx = mi[3] * dx + mi[8] * dy + mi[7] * dz;
+        const double ly = mi[8] * dx + mi[4] * dy + mi[6] * dz;
+        const double lz = mi[7] * dx + mi[6] * dy + mi[5] * dz;
+        const double ci = (dFi * drhoB + 0.5 * dphi) * inv_r +
+                          (muD * du + (dx * lx + dy * ly + dz * lz) * dw) * inv_r;
+        const double g[3] = {ci * dx + u * mi[0] + 2.0 * wq * lx, ci * dy + u * mi[1] + 2.0 * wq * ly,
+                             ci * dz + u * mi[2] + 2.0 * wq * lz};
+        // reverse pair: centre j, -D
+        const double muDj = mj[0] * dx + mj[1] * dy + mj[2] * dz;
+        const double jx = mj[3] * dx + mj[8] * dy + mj[7] * dz;
+        const double jy = mj[8] * dx + mj[4] * dy + mj[6] * dz;
+        const double jz = mj[7] * dx + mj[6] * dy + mj[5] * dz;
+        const double cj = (dFj * drhoA + 0.5 * dphi) * inv_r +
+                          (-muDj * du + (dx * jx + dy * jy + dz * jz) * dw) * inv_r;
+        const double gr[3] = {-cj * dx + u * mj[0] - 2.0 * wq * jx, -cj * dy + u * mj[1] - 2.0 * wq * jy,
+                              -cj * dz + u * mj[2] - 2.0 * wq * jz};
+        const double d[3] = {dx, dy, dz};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          f[c] += g[c] - gr[c];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) w[3 * c + e] = fma(g[c], d[e], w[3 * c + e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = group_sum<W>(f[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = group_sum<W>(w[k]);
+  if (lane == 0 && active)
+    for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
+  block_partials(b, blockIdx.x, i, active, lane == 0, w);
+}
+
 // Tables of the analytic functions on caller-supplied abscissae (setfl / ADP export,
 // reference nn/eam/alloy.py:198-381): rows = elements (rho(r), F(rho)) or element pairs a <= b
 // (phi, u, w), evaluated by the same device functions the energy kernels use.
@@ -1760,15 +1886,16 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   }
   bool other = false;
   for (int e = 0; e < m->p.nel; ++e) other = other || m->p.el_kind[e] != 0;
-  // plain EAM with analytic / tabulated pair functions: forces in one pass per centre (eam_force_kernel);
-  // ADP moments or nn pair functions: dE/dD per pair, then the shared force gather
+  // analytic / tabulated pair functions: forces in one pass per centre (eam_force_kernel,
+  // adp_force_kernel); nn pair functions: dE/dD per pair, then the shared force gather
   static const bool no_fold = getenv("TA_EAM_NO_FOLD") != nullptr;    // A/B switches
   static const int w_env = getenv("TA_EAM_W") ? atoi(getenv("TA_EAM_W")) : 0;
   const bool want_f = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0;
-  const bool fold = want_f && !m->p.adp && !pair_nets && !no_fold;
+  static const bool no_fold_adp = getenv("TA_ADP_NO_FOLD") != nullptr;
+  const bool fold = want_f && !pair_nets && !no_fold && !(m->p.adp && no_fold_adp);
   // lanes per atom (measured, 4000-atom Ni frames, rc 6.5, us per frame for W = 16 / 32 / 64): EAM one
-  // frame 25.5 / 26.2 / 28.0, 64 frames 11.3 / 14.1 / 16.7; ADP one frame 48.4 / 47.1 / 47.3, 64 frames
-  // 24.4 / 24.8 / 27.3
+  // frame 25.5 / 26.2 / 28.0, 64 frames 11.3 / 14.1 / 16.7; ADP (one-pass force kernel, W = 16 / 32)
+  // one frame 36.6 / 36.0, 64 frames 18.0 / 21.0
   const int W = w_env == 16 || w_env == 32 || w_env == 64 ? w_env
                 : (!m->p.adp || b.n_atoms >= 32768) ? 16 : 32;
   const dim3 agrid((unsigned)((b.n_atoms * W + kBlock - 1) / kBlock));
@@ -1811,8 +1938,13 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
       const dim3 fgrid((unsigned)((b.n_atoms + 15) / 16));
 #define TA_EAM_FORCE(O, WW) \
   hipLaunchKernelGGL((eam_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->tabs_dev)
-      TA_EAM_BY_W(TA_EAM_FORCE);
+#define TA_ADP_FORCE(O, WW)                                                                              \
+  hipLaunchKernelGGL((adp_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->mom, \
+                     m->tabs_dev)
+      if (m->p.adp) TA_EAM_BY_W(TA_ADP_FORCE);
+      else TA_EAM_BY_W(TA_EAM_FORCE);
 #undef TA_EAM_FORCE
+#undef TA_ADP_FORCE
     } else {
       const dim3 pgrid((unsigned)((b.n_pairs + kBlock - 1) / kBlock));
       if (other)
