@@ -420,6 +420,62 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
   }
 }
 
+// One-element models, job mode: the same two assemblies with every lane busy. The G2 terms are
+// evaluated one PAIR per lane (a wavefront per centre walks ~90 pairs in two passes of 64, 70 % of
+// its lanes; the workgroup's ~180 pairs fill 94 % of three wavefronts) and left in LDS next to the
+// G4 partial sums; then every 16-lane row sums one (centre, channel) column (DPP row rotations
+// instead of cross-row shuffles): about 350 of the 950 wavefront instructions of the two assemblies.
+template <int NG, int NZ>
+__device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b,
+                                              const Fields &f, const double *P, int c0, int c1, int s0,
+                                              int item, bool active, bool skip_radial) {
+  constexpr int kGZ = NG * NZ;
+  const int cap = b.cap;
+  double *R = reinterpret_cast<double *>(f.xy);  // xy, ih, sp1 (5 cap doubles) are dead after the sweep
+  const int row = threadIdx.x >> 4, l = threadIdx.x & 15, nrows = blockDim.x >> 4;
+  const int ncent = c1 - c0;
+  bool no_shift = true;
+  for (int c = 0; c < sf.n_rad; ++c) no_shift = no_shift && sf.omega[c] == 0.0;
+  const double r2 = active ? f.zr[item].y : 0.0;
+  const int n_rad = skip_radial ? 0 : sf.n_rad;
+  for (int cc = 0; cc == 0 || cc < n_rad; cc += 4) {
+    if (cc) __syncthreads();  // the previous chunk's columns have been summed
+    if (active && cc < n_rad) {
+      const double u = r2 * sf.inv_rc2;
+      const double fc = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
+      const double r = no_shift ? 0.0 : sqrt(r2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = (cc + k < n_rad) ? cc + k : cc;
+        double arg = sf.eta[c] * u;
+        if (!no_shift) {
+          const double dr = r - sf.omega[c];
+          arg = sf.eta[c] * dr * dr * sf.inv_rc2;
+        }
+        R[k * cap + item] = ta_exp(-arg) * fc;  // sf.py:101-108
+      }
+    }
+    __syncthreads();
+    const int nrad_here = cc < n_rad ? (n_rad - cc < 4 ? n_rad - cc : 4) : 0;
+    const int per_centre = nrad_here + (cc == 0 ? kGZ : 0);
+    for (int t = row; t < ncent * per_centre; t += nrows) {
+      const int ci = t / per_centre, k = t - ci * per_centre;
+      const int64_t i = c0 + ci;
+      const int q0 = b.pair_start[i] - s0, q1 = b.pair_start[i + 1] - s0;
+      const bool radial = k < nrad_here;
+      const double *col = radial ? R + (size_t)k * cap : P + (size_t)(k - nrad_here) * cap;
+      double v = 0.0;
+      for (int q = q0 + l; q < q1; q += 16) v += col[q];
+      v = row16_sum(v);
+      if (l == 0) {
+        double *Gi = b.G + (size_t)i * sf.ndim;
+        if (radial) Gi[cc + k] = v;
+        else Gi[sf.n_radial_dim + ch.chan[k - nrad_here]] = v * sf.ang_scale;
+      }
+    }
+  }
+}
+
 // Phase stagger (flags bits 8..15 = sleep count, bits 16..20 = shift): a launch whose workgroups
 // are all resident at once runs its memory-bound staging and its VALU-bound triple loop in lock
 // step; holding back every other group of workgroups for a few microseconds lets the two phases of
@@ -627,8 +683,12 @@ __global__ __launch_bounds__(kBlock)
         }
       __syncthreads();
       if (flags & 4) {
-        if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
-        reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
+        if constexpr (NSPEC == 1) {
+          assemble_flat<NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0);
+        } else {
+          if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
+          reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
+        }
         return;
       }
       // several forward launches (one per beta): the sums travel through part4 as before
