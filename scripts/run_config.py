@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One BASELINE config on the resident batch, N evaluations (for rocprofv3: scripts/profile_configs.sh).
-  python scripts/run_config.py <sf|eam|adp|grap|nn_eam> [frames] [steps]"""
+  python scripts/run_config.py <sf|nimo|eam|adp|grap|nn_eam> [frames] [steps]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import ni_frame
@@ -14,6 +14,13 @@ want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA
 if kind == "sf":
     from bench import ni_model
     nn = ni_model()
+elif kind == "nimo":  # BASELINE config 3: Ni4Mo cell, 3920 atoms, G2 + G4, 2 x 128 MLP
+    from tensoralloy_amd import AtomicNN, SymmetryFunction, UniversalTransformer
+    from tests.helpers import nimo_supercell
+    nn = AtomicNN(["Ni", "Mo"], SymmetryFunction(["Ni", "Mo"]), hidden_sizes=[128, 128], activation="softplus",
+                  minmax_scale=False, export_properties=("energy", "forces", "stress"))
+    nn.attach_transformer(UniversalTransformer(["Ni", "Mo"], rcut=6.5, angular=True))
+    nn.initialize(seed=611)
 elif kind == "eam":
     nn = make_eam(["Ni"], 6.5)
 elif kind == "adp":
@@ -25,7 +32,11 @@ else:
     pl = [5.0 - 0.25 * k for k in range(16)]
     nn = make_grap_nn(["Ni"], 6.0, [64, 64], "pexp", {"rl": rl, "pl": pl}, moment_tensors=[0, 1, 2, 3])
 with Engine(nn) as eng:
-    info = eng.set_frames([ni_frame(611 + k) for k in range(frames)])
+    if kind == "nimo":
+        frame_list = [nimo_supercell("Ni4Mo_mp-11507", rep=(7, 7, 8), jitter=0.05, seed=611 + k) for k in range(frames)]
+    else:
+        frame_list = [ni_frame(611 + k) for k in range(frames)]
+    info = eng.set_frames(frame_list)
     total_ms, slots = eng.time_compute(want, 3, steps)
     P, N = int(info.n_pairs), int(info.n_atoms)
     out = {"config": kind, "frames": frames, "atoms": N, "pairs": P, "ms_per_eval": total_ms / steps,

@@ -420,16 +420,19 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
   }
 }
 
-// One-element models, job mode: the same two assemblies with every lane busy. The G2 terms are
-// evaluated one PAIR per lane (a wavefront per centre walks ~90 pairs in two passes of 64, 70 % of
-// its lanes; the workgroup's ~180 pairs fill 94 % of three wavefronts) and left in LDS next to the
-// G4 partial sums; then every 16-lane row sums one (centre, channel) column (DPP row rotations
-// instead of cross-row shuffles): about 350 of the 950 wavefront instructions of the two assemblies.
-template <int NG, int NZ>
+// Job mode: the same two assemblies with every lane busy. The G2 terms are evaluated one PAIR per
+// lane (a wavefront per centre walks ~90 pairs in two passes of 64, 70 % of its lanes; the
+// workgroup's ~180 pairs fill 94 % of three wavefronts) and left in LDS next to the G4 partial sums;
+// then every 16-lane row sums one (centre, channel) column (DPP row rotations instead of cross-row
+// shuffles): about 350 of the 950 wavefront instructions of the two assemblies for one element. The
+// angular term {A, B}, A < B, is the column of partner species A over the pairs of species B plus the
+// column of partner species B over the pairs of species A, summed by the same row (one store).
+template <int NSPEC, int NG, int NZ>
 __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b,
                                               const Fields &f, const double *P, int c0, int c1, int s0,
                                               int item, bool active, bool skip_radial) {
   constexpr int kGZ = NG * NZ;
+  constexpr int kTerms = NSPEC * (NSPEC + 1) / 2;
   const int cap = b.cap;
   double *R = reinterpret_cast<double *>(f.xy);  // xy, ih, sp1 (5 cap doubles) are dead after the sweep
   const int row = threadIdx.x >> 4, l = threadIdx.x & 15, nrows = blockDim.x >> 4;
@@ -457,20 +460,34 @@ __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk
     }
     __syncthreads();
     const int nrad_here = cc < n_rad ? (n_rad - cc < 4 ? n_rad - cc : 4) : 0;
-    const int per_centre = nrad_here + (cc == 0 ? kGZ : 0);
+    const int n_radial_tasks = NSPEC * nrad_here;
+    const int per_centre = n_radial_tasks + (cc == 0 ? kTerms * kGZ : 0);
     for (int t = row; t < ncent * per_centre; t += nrows) {
       const int ci = t / per_centre, k = t - ci * per_centre;
       const int64_t i = c0 + ci;
-      const int q0 = b.pair_start[i] - s0, q1 = b.pair_start[i + 1] - s0;
-      const bool radial = k < nrad_here;
-      const double *col = radial ? R + (size_t)k * cap : P + (size_t)(k - nrad_here) * cap;
+      const int32_t *seg = b.seg_start + (size_t)i * (NSPEC + 1);
+      double *Gi = b.G + (size_t)i * sf.ndim;
       double v = 0.0;
-      for (int q = q0 + l; q < q1; q += 16) v += col[q];
-      v = row16_sum(v);
-      if (l == 0) {
-        double *Gi = b.G + (size_t)i * sf.ndim;
-        if (radial) Gi[cc + k] = v;
-        else Gi[sf.n_radial_dim + ch.chan[k - nrad_here]] = v * sf.ang_scale;
+      if (k < n_radial_tasks) {
+        const int sb = NSPEC == 1 ? 0 : k / nrad_here, kk = k - sb * nrad_here;
+        const double *col = R + (size_t)kk * cap;
+        for (int q = seg[sb] - s0 + l; q < seg[sb + 1] - s0; q += 16) v += col[q];
+        v = row16_sum(v);
+        if (l == 0) Gi[radial_term2(b.species[i], sb) * sf.n_rad + cc + kk] = v;
+      } else {
+        const int k2 = k - n_radial_tasks;
+        const int term = k2 / kGZ, gz = k2 - term * kGZ;
+        int sa = 0, sb = 0;  // term index -> (sa <= sb), row-major upper triangle
+        for (int rem = term, len = NSPEC; rem >= len; rem -= len, --len) ++sa;
+        sb = term - (sa * NSPEC - (sa * (sa - 1)) / 2) + sa;
+        const double *colA = P + (size_t)(sa * kGZ + gz) * cap;  // partner species sa, pairs of species sb
+        for (int q = seg[sb] - s0 + l; q < seg[sb + 1] - s0; q += 16) v += colA[q];
+        if (sa != sb) {
+          const double *colB = P + (size_t)(sb * kGZ + gz) * cap;
+          for (int q = seg[sa] - s0 + l; q < seg[sa + 1] - s0; q += 16) v += colB[q];
+        }
+        v = row16_sum(v);
+        if (l == 0) Gi[sf.n_radial_dim + term * sf.n_ang + ch.chan[gz]] = v * sf.ang_scale;
       }
     }
   }
@@ -683,12 +700,7 @@ __global__ __launch_bounds__(kBlock)
         }
       __syncthreads();
       if (flags & 4) {
-        if constexpr (NSPEC == 1) {
-          assemble_flat<NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0);
-        } else {
-          if (!(flags & (1 << 26))) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
-          reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, P, b.cap, c0, c1, s0, 0, NSPEC);
-        }
+        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0);
         return;
       }
       // several forward launches (one per beta): the sums travel through part4 as before
