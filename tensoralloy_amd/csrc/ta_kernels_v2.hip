@@ -46,7 +46,7 @@ constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
 constexpr int kNF = 8;   // backward: {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
 constexpr int kNFf = 7;  // forward: the last record is the species alone (8 bytes): 1.5 KB of LDS less,
                          // which with the trimmed job counters lets 7 workgroups share a CU instead of 6
-constexpr int kJobCtlBytes = 160;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs
+constexpr int kJobCtlBytes = 240;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs, cstart[17 (+3)]
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void deal_by_popcount(const Fields &f, int cap, int M
 // (dead once the masks exist), is written to HBM by the forward kernel and read back by the backward
 // kernel: one construction serves both sweeps.
 struct JobLists {
-  uint32_t *word;            // [4 * lanes]: pair | window << 8 | bits << 16
+  uint32_t *word;            // [4 * lanes]: pair | window << 8 | centre of the pair in the workgroup << 10 | bits << 16
   int *hist, *start;         // [20], [20] (17 used: job sizes 16 .. 1, total)
 };
 
@@ -281,6 +281,11 @@ __device__ __forceinline__ JobLists job_lists(const Fields &f) {
   return j;
 }
 __device__ __forceinline__ int job_item(uint32_t w) { return (int)(w & 255u); }
+// a job names its centre (index in the workgroup's run, < kMaxCentersPerBlock = 16), so that the sweeps
+// take the centre's first pair and neighbour count from a table in LDS (`cstart`) instead of the chain
+// of dependent global loads pair_i[p] -> pair_start[i], pair_start[i + 1]
+__device__ __forceinline__ int job_centre(uint32_t w) { return (int)((w >> 10) & 15u); }
+static_assert(kMaxCentersPerBlock <= 16, "four bits of a job word name the centre");
 
 // byte offset of the job counters (kJobCtlBytes) and, behind
 // them, of the forward kernel's per-pair partial sums P[n_local][cap]
@@ -299,7 +304,7 @@ __host__ __device__ inline int v2_max_jobs(int cap) { return 4 * cap; }
 // every round and the wavefronts of a workgroup get large and small rounds alike. Replaces the cut
 // into jobs of exactly K = 8 set bits, whose bit-peeling loops and prefix sums were 2.5 M of the
 // forward kernel's 17.4 M VALU instructions, and its 10-byte (mask, code) records.
-__device__ __forceinline__ int make_jobs(JobLists &j, bool active, int item, unsigned long long m0) {
+__device__ __forceinline__ int make_jobs(JobLists &j, bool active, int item, int centre, unsigned long long m0) {
   const int tid = threadIdx.x;
   int cnt[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
   if (active) {
@@ -328,7 +333,8 @@ __device__ __forceinline__ int make_jobs(JobLists &j, bool active, int item, uns
     for (int w = 0; w < 4; ++w)
       if (cnt[w]) {
         const int slot = j.start[16 - cnt[w]] + rank[w];
-        j.word[slot] = (uint32_t)item | ((uint32_t)w << 8) | ((uint32_t)((m0 >> (16 * w)) & 0xffffull) << 16);
+        j.word[slot] = (uint32_t)item | ((uint32_t)w << 8) | ((uint32_t)centre << 10) |
+                       ((uint32_t)((m0 >> (16 * w)) & 0xffffull) << 16);
       }
   }
   const int n = j.start[16];
@@ -522,7 +528,9 @@ __global__ __launch_bounds__(kBlock)
   if (b.job_count) {  // job counters and partial sums: cleared before the staging barrier
     char *raw = reinterpret_cast<char *>(lds);
     int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
-    if (threadIdx.x < kJobCtlBytes / 4) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 40) cnt[threadIdx.x] = 0;
+    else if (threadIdx.x < 40 + 17 && (int)threadIdx.x - 40 <= c1 - c0)  // cstart[k]: first pair of centre c0 + k
+      cnt[threadIdx.x] = b.pair_start[c0 + threadIdx.x - 40] - b.pair_start[c0];
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * b.cap; k += blockDim.x) P0[k] = 0.0;
   }
@@ -536,9 +544,17 @@ __global__ __launch_bounds__(kBlock)
   auto run_item = [&](int item, bool have_mask, unsigned long long mask0, double *out, double *pacc, auto is_job) {
     constexpr bool kJob = decltype(is_job)::value;
     const int64_t p = (int64_t)s0 + item;
-    const int i = b.pair_i[p];
-    const int base = b.pair_start[i] - s0;
-    const int n = b.pair_start[i + 1] - b.pair_start[i];
+    int base, n;
+    if constexpr (kJob) {
+      const int *cstart = reinterpret_cast<const int *>(reinterpret_cast<const char *>(lds) + v2_counter_offset(b.cap)) + 40;
+      const int ci = job_centre((uint32_t)mask0);
+      base = cstart[ci];
+      n = cstart[ci + 1] - base;
+    } else {
+      const int i = b.pair_i[p];
+      base = b.pair_start[i] - s0;
+      n = b.pair_start[i + 1] - b.pair_start[i];
+    }
     const int a = item - base;
     const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item];
     const double ax = axy.x, ay = axy.y, az = azr.x;
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(kBlock)
       jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
       jl.start = jl.hist + 20;
       double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
-      const int n_jobs = make_jobs(jl, active, item, mask);
+      const int n_jobs = make_jobs(jl, active, item, active ? b.pair_i[s0 + item] - c0 : 0, mask);
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
       if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
       for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x) b.job_word[jbase + slot] = jl.word[slot];
@@ -795,15 +811,26 @@ __global__ __launch_bounds__(kBlock)
   const int M = b.pair_start[c1] - s0;
   const double beta = ch.beta[0];
   for (int k = threadIdx.x; k < 3 * kCap; k += blockDim.x) gacc[k] = 0.0;
+  // cstart[k]: first pair of centre c0 + k (see job_centre), in the kCap bytes in front of gacc
+  int *cstart = reinterpret_cast<int *>(gacc) - 20;
+  if ((int)threadIdx.x <= c1 - c0 && threadIdx.x < 17) cstart[threadIdx.x] = b.pair_start[c0 + threadIdx.x] - s0;
   stage(sf, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
   auto run_item = [&](int item, bool have_mask, unsigned long long mask0, auto is_job) {
     constexpr bool kJob = decltype(is_job)::value;  // see the forward kernel
     const int64_t p = (int64_t)s0 + item;
-    const int i = b.pair_i[p];
-    const int base = b.pair_start[i] - s0;
-    const int n = b.pair_start[i + 1] - b.pair_start[i];
+    int i, base, n;
+    if constexpr (kJob) {
+      const int ci = job_centre((uint32_t)mask0);
+      i = c0 + ci;
+      base = cstart[ci];
+      n = cstart[ci + 1] - base;
+    } else {
+      i = b.pair_i[p];
+      base = b.pair_start[i] - s0;
+      n = b.pair_start[i + 1] - b.pair_start[i];
+    }
     const int a = item - base;
     const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item], ags = f.gs[item];
     const double ax = axy.x, ay = axy.y, az = azr.x;
