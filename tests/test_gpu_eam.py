@@ -45,6 +45,25 @@ def test_adp_binary(lib):
     _compare(make_eam(["Mo", "Ni"], 6.0, adp=True), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
 
 
+def test_adp_large_batch_uses_the_narrow_groups(lib):
+    """Batches of 32768 atoms or more run the ADP kernels with 16 lanes per atom, smaller ones with
+    32 (ta_eam.hip: eam_compute): the same binary frame, 160 copies in one batch (34560 atoms) against
+    the one-frame evaluation that `_compare` pins to the oracle."""
+    from tensoralloy_amd import Engine
+    nn = make_eam(["Mo", "Ni"], 6.0, adp=True)
+    atoms = _alloy(["Ni", "Ni", "Mo"], rep=(3, 3, 3), a=3.6)
+    n_copies = 32768 // len(atoms) + 1
+    with Engine(nn) as eng:
+        one = eng.evaluate([atoms])[0]
+        many = eng.evaluate([atoms] * n_copies)
+    o = oracle_eam_eval(nn, atoms)
+    assert abs(one["energy"] - o["energy"]) < E_TOL
+    for r in (many[0], many[n_copies // 2], many[-1]):
+        assert abs(r["energy"] - one["energy"]) < 1e-9
+        assert np.abs(r["forces"] - one["forces"]).max() < 1e-10
+        assert np.abs(r["virial"] - one["virial"]).max() < 1e-8
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_nn_eam_default_potentials(lib, monkeypatch, generic):
     """The reference's default `EamAlloyNN(elements)`: rho, phi and embed are all "nn" functions
