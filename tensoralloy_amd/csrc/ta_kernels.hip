@@ -24,6 +24,7 @@
 // (no atomics, no cross-lane traffic); the descriptor sum takes half of it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <stdexcept>
 
 #include "ta_device.h"
@@ -341,22 +342,25 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(SFParams sf, AngChunk 
 //   F_i = sum_{p in N(i)} (g[p] - g[rev p])        (F = -dE/dR, basic.py:281-287)
 //   W_i = sum_{p in N(i)} g[p] (x) D[p]            (== -F^T R + (dE/dh)^T h, basic.py:306-316)
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
-  // 16 lanes (one DPP row) per atom: the 12 sums are VALU row rotations, no LDS shuffles
-  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
-  const int lane = threadIdx.x & 15;
+// W lanes per atom, 16 atoms per workgroup (one `bpart` record): 16 (one DPP row: the 12 sums are VALU row
+// rotations, no LDS shuffles) for batches; 32 for a single small frame, whose ~1000 wavefronts would
+// otherwise walk 90 pairs in two dependent batches of 4 x 16 (one batch of 4 x 32 instead).
+template <int W>
+__global__ __launch_bounds__(16 * W) void force_gather_kernel(DeviceBatch b) {
+  const int64_t i = ((int64_t)blockIdx.x * (16 * W) + threadIdx.x) / W;
+  const int lane = threadIdx.x & (W - 1);
   const bool active = i < b.n_atoms;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int q0 = active ? b.pair_start[i] : 0, q1 = active ? b.pair_start[i + 1] : 0;
   if (b.own_sums) {
     // the backward kernel left sum_p g[p] and the virial rows per atom: only g[rev p] is gathered
     // (36 bytes per pair instead of 100)
-    for (int qb = q0 + lane; qb < q1; qb += 64) {
+    for (int qb = q0 + lane; qb < q1; qb += 4 * W) {
       int r[4];
       bool ok[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int q = qb + 16 * k;
+        const int q = qb + W * k;
         ok[k] = q < q1;
         r[k] = ok[k] ? b.pair_rev[q] : 0;
       }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) f[k] = row16_sum(f[k]);
+    for (int k = 0; k < 3; ++k) f[k] = group_sum<W>(f[k]);
     if (lane == 0 && active) {
       const double *own = b.fown + 12 * (size_t)i;
       for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k] + own[k];
@@ -389,19 +393,19 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
   }
   // batches of 4 strided pairs: the 4 reverse indices, then all 4 x 9 operands, are in flight
   // together, so a batch costs two memory latencies instead of eight
-  for (int qb = q0 + lane; qb < q1; qb += 64) {
+  for (int qb = q0 + lane; qb < q1; qb += 4 * W) {
     int r[4];
     bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int q = qb + 16 * k;
+      const int q = qb + W * k;
       ok[k] = q < q1;
       r[k] = ok[k] ? b.pair_rev[q] : 0;
     }
     double gq[4][3], gr[4][3], d[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int q = ok[k] ? qb + 16 * k : q0;
+      const int q = ok[k] ? qb + W * k : q0;
       const double2 *rec = pair_geom(b, (size_t)q);
       const double2 v0 = rec[0], v1 = rec[1];
       d[k][0] = v0.x;
@@ -430,9 +434,9 @@ __global__ __launch_bounds__(kBlock) void force_gather_kernel(DeviceBatch b) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) f[k] = row16_sum(f[k]);
+  for (int k = 0; k < 3; ++k) f[k] = group_sum<W>(f[k]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = row16_sum(w[k]);
+  for (int k = 0; k < 9; ++k) w[k] = group_sum<W>(w[k]);
   if (lane == 0 && active) {
     for (int k = 0; k < 3; ++k) b.forces[3 * (size_t)i + k] = f[k];
   }
@@ -582,8 +586,11 @@ void launch_backward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int
 
 void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  hipLaunchKernelGGL(force_gather_kernel, dim3(blocks_for(b.n_atoms * 16, kBlock)), dim3(kBlock), 0,
-                     s, b);
+  static const int w_env = getenv("TA_GATHER_W") ? atoi(getenv("TA_GATHER_W")) : 0;  // A/B switch
+  const int W = (w_env == 16 || w_env == 32) ? w_env : (b.n_atoms < 16384 ? 32 : 16);
+  const dim3 grid((unsigned)((b.n_atoms + 15) / 16));
+  if (W == 32) hipLaunchKernelGGL(force_gather_kernel<32>, grid, dim3(512), 0, s, b);
+  else hipLaunchKernelGGL(force_gather_kernel<16>, grid, dim3(256), 0, s, b);
 }
 
 void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s) {
