@@ -436,10 +436,9 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
 template <int NSPEC, int NG, int NZ>
 __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b,
                                               const Fields &f, const double *P, int c0, int c1, int s0,
-                                              int item, bool active, bool skip_radial) {
+                                              int item, bool active, bool skip_radial, int cap) {
   constexpr int kGZ = NG * NZ;
   constexpr int kTerms = NSPEC * (NSPEC + 1) / 2;
-  const int cap = b.cap;
   double *R = reinterpret_cast<double *>(f.xy);  // xy, ih, sp1 (5 cap doubles) are dead after the sweep
   const int row = threadIdx.x >> 4, l = threadIdx.x & 15, nrows = blockDim.x >> 4;
   const int ncent = c1 - c0;
@@ -511,28 +510,33 @@ __device__ __forceinline__ void stagger(int flags) {
 
 // DEFZ: zeta = {1, 4} known at compile time (the reference's default grid,
 // nn/atomic/sf.py:37), so the powers are two multiplications, no scalar loops.
-template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
+// CAP: the records a workgroup stages (b.cap) as a compile-time constant, 0 = take it from the batch.
+// With CAP known the LDS arrays sit at constant offsets from each other, so the random partner reads
+// and the accumulator updates of the triple bodies address them as one shifted index + immediate
+// offsets instead of one address computation each (six VALU instructions per backward triple).
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP>
 __global__ __launch_bounds__(kBlock)
     __attribute__((amdgpu_waves_per_eu(DEFZ && NSPEC == 1 ? 5 : 1, 8))) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
                                                                DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
+  const int kCap = CAP > 0 ? CAP : b.cap;
   const int geom = flags & 1;
   if (b.n_blk_dev && (int)blockIdx.x >= *b.n_blk_dev) return;  // grid sized by an upper bound (MD loop)
   stagger(flags);
   extern __shared__ double lds[];
-  const Fields f = carve(lds, b.cap, true);
+  const Fields f = carve(lds, kCap, true);
   const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
   const int s0 = b.pair_start[c0];
   const int M = b.pair_start[c1] - s0;
   const double beta = ch.beta[0];
   if (b.job_count) {  // job counters and partial sums: cleared before the staging barrier
     char *raw = reinterpret_cast<char *>(lds);
-    int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
+    int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(kCap));
     if (threadIdx.x < 40) cnt[threadIdx.x] = 0;
     else if (threadIdx.x < 40 + 17 && (int)threadIdx.x - 40 <= c1 - c0)  // cstart[k]: first pair of centre c0 + k
       cnt[threadIdx.x] = b.pair_start[c0 + threadIdx.x - 40] - b.pair_start[c0];
-    double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
-    for (int k = threadIdx.x; k < NSPEC * NG * NZ * b.cap; k += blockDim.x) P0[k] = 0.0;
+    double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
+    for (int k = threadIdx.x; k < NSPEC * NG * NZ * kCap; k += blockDim.x) P0[k] = 0.0;
   }
   stage(sf, beta, b, f, s0, M, geom, true);
 
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(kBlock)
     const int64_t p = (int64_t)s0 + item;
     int base, n;
     if constexpr (kJob) {
-      const int *cstart = reinterpret_cast<const int *>(reinterpret_cast<const char *>(lds) + v2_counter_offset(b.cap)) + 40;
+      const int *cstart = reinterpret_cast<const int *>(reinterpret_cast<const char *>(lds) + v2_counter_offset(kCap)) + 40;
       const int ci = job_centre((uint32_t)mask0);
       base = cstart[ci];
       n = cstart[ci + 1] - base;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(kBlock)
           const int c = ch.chan[ig * NZ + iz];
           const double v = acc[sp][ig][iz] * ch.kz[iz];
           if (pacc) {
-            if (v != 0.0) atomicAdd(&pacc[(size_t)((sp * NG + ig) * NZ + iz) * b.cap + item], v);
+            if (v != 0.0) atomicAdd(&pacc[(size_t)((sp * NG + ig) * NZ + iz) * kCap + item], v);
           } else if (out)
             out[(sp * NG + ig) * NZ + iz] = v;
           else
@@ -699,9 +703,9 @@ __global__ __launch_bounds__(kBlock)
       // job mode (see make_jobs): build the list once, leave it for the backward kernel, sweep it
       char *raw = reinterpret_cast<char *>(lds);
       JobLists jl = job_lists(f);
-      jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(b.cap));
+      jl.hist = reinterpret_cast<int *>(raw + v2_counter_offset(kCap));
       jl.start = jl.hist + 20;
-      double *P = reinterpret_cast<double *>(raw + v2_counter_offset(b.cap) + kJobCtlBytes);
+      double *P = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
       const int n_jobs = make_jobs(jl, active, item, active ? b.pair_i[s0 + item] - c0 : 0, mask);
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
       if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(kBlock)
         }
       __syncthreads();
       if (flags & 4) {
-        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0);
+        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0, kCap);
         return;
       }
       // several forward launches (one per beta): the sums travel through part4 as before
@@ -726,10 +730,10 @@ __global__ __launch_bounds__(kBlock)
         for (int sp = 0; sp < NSPEC; ++sp)
 #pragma unroll
           for (int gz = 0; gz < NG * NZ; ++gz)
-            b.part4[(size_t)(sp * sf.n_ang + ch.chan[gz]) * b.n_pairs + p] = P[(size_t)(sp * NG * NZ + gz) * b.cap + threadIdx.x];
+            b.part4[(size_t)(sp * sf.n_ang + ch.chan[gz]) * b.n_pairs + p] = P[(size_t)(sp * NG * NZ + gz) * kCap + threadIdx.x];
       }
     } else {
-    deal_by_popcount(f, b.cap, M, item, mask);
+    deal_by_popcount(f, kCap, M, item, mask);
     // flags & 4: this launch holds every angular channel of the model: the descriptors are
     // assembled from LDS, without a round trip through part4. The partial sums of up to 8 local
     // channels at a time go behind {z r2}: xy, ih, sp1 (5 cap doubles) and the rings behind them (3 cap
@@ -750,11 +754,11 @@ __global__ __launch_bounds__(kBlock)
         if (active) {
 #pragma unroll
           for (int k = 0; k < kSpPerPass * kGZ; ++k)
-            if (sp_lo * kGZ + k < kLocal) red[(size_t)k * b.cap + item] = mine[sp_lo * kGZ + k];
+            if (sp_lo * kGZ + k < kLocal) red[(size_t)k * kCap + item] = mine[sp_lo * kGZ + k];
         }
         __syncthreads();
         if (sp_lo == 0) reduce_radial_from_lds(sf, b, f, c0, c1, s0);
-        reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, red, b.cap, c0, c1, s0, sp_lo, sp_hi);
+        reduce_angular_from_lds<NSPEC, NG, NZ>(sf, ch, b, red, kCap, c0, c1, s0, sp_lo, sp_hi);
         __syncthreads();
       }
       return;
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(kBlock)
   }
 }
 
-template <int NSPEC, int NG, int NZ, int HD, bool DEFZ>
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP>
 // Occupancy: the backward body is latency-bound at the 3 wavefronts per SIMD the compiler settles for
 // (133 VGPRs); asking for 5 (96 VGPRs, 10 spilled) measured 72 -> 66 us on the benchmark frame and
 // 51 -> 45 us per frame in batches (4: 69 / 47, 6: 68 / 45). Only the default-grid instantiations
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(kBlock)
   if (b.n_blk_dev && (int)blockIdx.x >= *b.n_blk_dev) return;  // grid sized by an upper bound (MD loop)
   stagger(flags);
   extern __shared__ double lds[];
-  const int kCap = b.cap;  // multiple of 64
+  const int kCap = CAP > 0 ? CAP : b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
   // partner accumulators sit behind the float copies and species bytes, 8-byte aligned
   double *gacc = lds + kNF * kCap + (3 * (2 * kCap + kRingPad)) / 2 + kCap / 8;
@@ -1047,20 +1051,23 @@ void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geo
   const size_t lds = v2_lds_bytes(false, b.cap, b.job_count ? NSPEC * NG * NZ : 0);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true>), grid, block, lds, s, sf, ch, b, geom);
+      if (b.cap == kCapMin)
+        hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin>), grid, block, lds, s, sf, ch, b, geom);
+      else
+        hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, 0>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
     if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, geom);
+      hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, true, 0>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
   }
   if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, geom);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 16, false, 0>), grid, block, lds, s, sf, ch, b, geom);
   else if (ch.n_hd == 24)
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, geom);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 24, false, 0>), grid, block, lds, s, sf, ch, b, geom);
   else
-    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b, geom);
+    hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 0, false, 0>), grid, block, lds, s, sf, ch, b, geom);
 }
 template <int NSPEC, int NG, int NZ>
 void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int first, hipStream_t s) {
@@ -1068,20 +1075,23 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
   const size_t lds = v2_lds_bytes(true, b.cap);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true>), grid, block, lds, s, sf, ch, b, first);
+      if (b.cap == kCapMin)
+        hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin>), grid, block, lds, s, sf, ch, b, first);
+      else
+        hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true, 0>), grid, block, lds, s, sf, ch, b, first);
       return;
     }
     if (ch.n_hd == 16 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, true>), grid, block, lds, s, sf, ch, b, first);
+      hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, true, 0>), grid, block, lds, s, sf, ch, b, first);
       return;
     }
   }
   if (ch.n_hd > 0 && ch.n_hd <= 16)  // coefficients beyond n_hd are zero
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, false>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 16, false, 0>), grid, block, lds, s, sf, ch, b, first);
   else if (ch.n_hd == 24)
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24, false>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 24, false, 0>), grid, block, lds, s, sf, ch, b, first);
   else
-    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 0, false>), grid, block, lds, s, sf, ch, b, first);
+    hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 0, false, 0>), grid, block, lds, s, sf, ch, b, first);
 }
 
 }  // namespace
