@@ -346,6 +346,7 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
   if (m->angular && !(m->acut > 0.0)) throw std::invalid_argument("acut must be positive");
   sf.inv_rc2 = 1.0 / (sf.rcut * sf.rcut);
   sf.inv_ac2 = 1.0 / (sf.acut * sf.acut);
+  sf.two_inv_ac2 = 2.0 * sf.inv_ac2;
   sf.eps = m->eps > 0.0 ? m->eps : 1e-14;  // Precision.high / medium eps, precision.py:113-114
   sf.n_elements = nel;
   sf.n_rad = m->n_eta * m->n_omega;

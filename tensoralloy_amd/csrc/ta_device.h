@@ -22,6 +22,7 @@ constexpr int kMaxHd = 24;        // coefficients of the Hd(u) expansion
 struct SFParams {
   double rcut, acut;
   double inv_rc2, inv_ac2;  // 1 / rcut^2, 1 / acut^2
+  double two_inv_ac2;       // 2 / acut^2 (du/dr = 2 r / acut^2: one scalar operand in the triple bodies)
   double eps;               // added under the square root (universal.py:470-472)
   double ang_scale;         // 0.5 when every {j,k} is visited twice (v1 kernels), else 1
   int n_elements;

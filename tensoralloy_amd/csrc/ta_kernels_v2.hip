@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kBlock)
 
     // one candidate partner: position a + step of the centre's ring
     auto triple = [&](int bl) {
-        if (bl >= n) bl -= n;
+        bl = (int)min((unsigned)bl, (unsigned)bl - (unsigned)n);  // bl < 2 n: bl mod n without a compare / select
         const int q = base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
         const double ex = bxy.x - ax, ey = bxy.y - ay, ez = bzr.x - az;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(kBlock)
     }
     double gx = 0.0, gy = 0.0, gz = 0.0;
     auto triple = [&](int bl) {
-        if (bl >= n) bl -= n;
+        bl = (int)min((unsigned)bl, (unsigned)bl - (unsigned)n);  // bl < 2 n: bl mod n without a compare / select
         const int q = base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
         const double bx = bxy.x, by = bxy.y, bz = bzr.x;
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(kBlock)
         const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ab;
         double Hd, dHd;
         hd_eval<HD>(sf, ch, beta, u, Hd, dHd);
-        const double Hd2 = 2.0 * sf.inv_ac2 * dHd;
+        const double Hd2 = sf.two_inv_ac2 * dHd;
         const double Hb = bih.y, Gb = bgs.x;
         const int sb = NSPEC == 1 ? 0 : (int)bgs.y;
         double S0 = 0.0, S1 = 0.0;
