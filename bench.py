@@ -291,7 +291,9 @@ def main():
         f5 = CONFIG5_FRAMES_PER_GPU
         frames5 = [ni_frame(611 + rank * f5 + k, rep=args.rep) for k in range(f5)]
         info5 = eng.set_frames(frames5)
-        k5, w5 = max(5, min(args.steps, 20)), 2
+        # six warm-up steps (29 ms): this block is the first sustained work of the process, and two were
+        # not enough for the GPU to reach its working clocks (54.7 against 55.3 M, same session)
+        k5, w5 = max(5, min(args.steps, 20)), 6
         el5, esum = coll.run(k5, w5, want)
         atoms5 = coll.total(int(info5.n_atoms))
         local_sum = float(eng.fetch(_lib.TA_WANT_ENERGY)["energy"].sum())
