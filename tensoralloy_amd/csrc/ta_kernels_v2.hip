@@ -818,6 +818,32 @@ __global__ __launch_bounds__(kBlock)
   // cstart[k]: first pair of centre c0 + k (see job_centre), in the kCap bytes in front of gacc
   int *cstart = reinterpret_cast<int *>(gacc) - 20;
   if ((int)threadIdx.x <= c1 - c0 && threadIdx.x < 17) cstart[threadIdx.x] = b.pair_start[c0 + threadIdx.x] - s0;
+  // One-element default grid: the polynomial coefficients of dE/dG (see `pc` below) once per CENTRE,
+  // by the last lanes of the workgroup while the others stage, instead of four dependent global loads
+  // and twenty operations in the prologue of every job
+  double *pctab = gacc + 3 * kCap;  // [kMaxCentersPerBlock][5]
+  if constexpr (DEFZ && NSPEC == 1) {
+    const int k = (int)blockDim.x - 1 - (int)threadIdx.x;
+    if (k < c1 - c0) {
+      const double *wsrc = b.dEdG + (size_t)(c0 + k) * sf.ndim + sf.n_radial_dim;
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig) {
+        const double g1 = ch.gamma[ig], g2 = g1 * g1;
+        const double w1 = wsrc[ch.chan[ig * NZ]] * ch.kz[0], w4 = wsrc[ch.chan[ig * NZ + 1]] * ch.kz[1];
+        p0 += w1 + w4;
+        p1 += g1 * (w1 + 4.0 * w4);
+        p2 += 6.0 * g2 * w4;
+        p3 += 4.0 * g2 * g1 * w4;
+        p4 += g2 * g2 * w4;
+      }
+      pctab[5 * k] = p0;
+      pctab[5 * k + 1] = p1;
+      pctab[5 * k + 2] = p2;
+      pctab[5 * k + 3] = p3;
+      pctab[5 * k + 4] = p4;
+    }
+  }
   stage(sf, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
@@ -844,9 +870,10 @@ __global__ __launch_bounds__(kBlock)
 
     // dE/dG of the channels of term (sa, sp) for every partner species sp
     // w = dE/dG 2^(1-zeta); wd = w zeta gamma (factor of the derivative of (1 + gamma c)^zeta)
+    constexpr bool kTable = kJob && DEFZ && NSPEC == 1;  // coefficients from `pctab`
     double w[NSPEC][NG][NZ], wd[NSPEC][NG][NZ];
 #pragma unroll
-    for (int sp = 0; sp < NSPEC; ++sp) {
+    for (int sp = 0; sp < (kTable ? 0 : NSPEC); ++sp) {
       const double *wsrc = b.dEdG + (size_t)i * sf.ndim + sf.n_radial_dim +
                            angular_term2(sa, sp, nel) * sf.n_ang;
 #pragma unroll
@@ -862,7 +889,11 @@ __global__ __launch_bounds__(kBlock)
     // S1 = sum_c w_c kz zeta g (1 + g c)^(zeta - 1) its derivative: coefficients once per job, then
     // 4 + 3 fused multiply-adds per triple instead of 16 operations
     double pc[NSPEC][5];
-    if constexpr (DEFZ) {
+    if constexpr (kTable) {
+      const double *src = pctab + 5 * (i - c0);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pc[0][k] = src[k];
+    } else if constexpr (DEFZ) {
 #pragma unroll
       for (int sp = 0; sp < NSPEC; ++sp) {
 #pragma unroll
@@ -985,12 +1016,19 @@ __global__ __launch_bounds__(kBlock)
     const int n_jobs = (one_pass && b.job_count) ? b.job_count[blockIdx.x] : -1;
     if (n_jobs >= 0) {  // the forward kernel's job list (see make_jobs): no scan, no sort here
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
-      for (int r = 0; r * (int)blockDim.x < n_jobs; ++r) {
+      // at most four rounds (four jobs per pair, one pair per lane): the words of all of them are
+      // fetched before the first job runs, not one dependent global load per round
+      uint32_t jws[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
         const int slot = job_slot(r, threadIdx.x, blockDim.x);
-        if (slot < n_jobs) {
-          const uint32_t jw = b.job_word[jbase + slot];
-          run_item(job_item(jw), true, jw, std::true_type{});
-        }
+        jws[r] = slot < n_jobs ? b.job_word[jbase + slot] : 0u;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r * (int)blockDim.x >= n_jobs) break;
+        const int slot = job_slot(r, threadIdx.x, blockDim.x);
+        if (slot < n_jobs) run_item(job_item(jws[r]), true, jws[r], std::true_type{});
       }
     } else if (one_pass) {  // see deal_by_popcount
       unsigned long long mask = 0ull;
@@ -1100,7 +1138,7 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 size_t v2_lds_bytes(bool backward, int cap, int n_local) {
   if (!backward && n_local > 0) return v2_counter_offset(cap) + kJobCtlBytes + (size_t)n_local * cap * sizeof(double);
   return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
-         (backward ? 3 * (size_t)cap * sizeof(double) : 0);
+         (backward ? 3 * (size_t)cap * sizeof(double) + kMaxCentersPerBlock * 5 * sizeof(double) : 0);
 }
 int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 
