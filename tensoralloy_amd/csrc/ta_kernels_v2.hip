@@ -799,7 +799,7 @@ template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP>
 // 51 -> 45 us per frame in batches (4: 69 / 47, 6: 68 / 45). Only the default-grid instantiations
 // are constrained; the generic ones keep the compiler's choice.
 __global__ __launch_bounds__(kBlock)
-    __attribute__((amdgpu_waves_per_eu(DEFZ ? (NSPEC == 1 ? 5 : 4) : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
+    __attribute__((amdgpu_waves_per_eu(DEFZ ? (NSPEC <= 2 ? 5 : 4) : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
                                                              DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int first = flags & 1;
