@@ -183,6 +183,14 @@ enum {
 
 int ta_device_count(void);
 
+/* Version of this header's ABI (entry points AND struct layouts; bumped whenever either changes) and
+ * sizeof(ta_model_desc) as the library was compiled: a binding checks both before the first real
+ * call, so that a stale or foreign build of the library is refused instead of misreading a struct.
+ * (The reference has no counterpart: its "ABI" is the frozen graph's `Metadata/api`, basic.py:43.) */
+#define TA_ABI_VERSION 3
+int ta_abi_version(void);
+int ta_model_desc_size(void);
+
 /* replaces TensorAlloyCalculator.__init__ graph import + Session creation
  * (calculator.py:40-87): validates the model, uploads weights to `device`. */
 int ta_create(const ta_model_desc *model, int device, ta_handle *out);
@@ -210,10 +218,16 @@ int ta_set_frames(ta_handle h, int32_t n_frames, const ta_frame *frames,
  *                        list was built and no cell has changed; otherwise it is rebuilt exactly as
  *                        ta_set_frames does. *rebuilt (may be NULL) = 1 when it was rebuilt.
  *                        With skin = 0 every call rebuilds. Asynchronous on the reuse path.
- *   ta_list_stats        lists built / reused by this handle so far. */
+ *   ta_list_stats        lists built / reused by this handle so far.
+ *   ta_list_sizes        directed pairs, triples and the largest per-(centre, species) neighbour
+ *                        count of the RESIDENT list (what ta_batch_info reported at ta_set_frames,
+ *                        refreshed when ta_update_positions rebuilt the list; nij / nijk / nnl_max
+ *                        of the reference's metadata, transformer/universal.py:878-887).
+ *                        Any pointer may be NULL. */
 int ta_set_skin(ta_handle h, double skin);
 int ta_update_positions(ta_handle h, const double *positions, const double *cells, int32_t *rebuilt);
 int ta_list_stats(ta_handle h, int64_t *n_builds, int64_t *n_reuses);
+int ta_list_sizes(ta_handle h, int64_t *n_pairs, int64_t *n_triples, int32_t *nnl_max);
 
 /* replaces Session.run(ops, feed_dict) (calculator.py:368): enqueues the
  * kernels on the handle's stream; asynchronous. */
@@ -242,25 +256,6 @@ int ta_set_stream(ta_handle h, void *stream);
 /* blocks until the handle's stream is idle */
 int ta_synchronize(ta_handle h);
 
-/* Measurement (bench.py): runs `warmup` untimed then `steps` timed passes of
- * ta_compute over the resident batch, timed with HIP events on the handle's
- * stream. total_ms = wall of the `steps` passes; kernel_ms[k] (may be NULL) =
- * average duration per pass of kernel slot k, measured in a second run with
- * events around every launch. */
-int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
-                    double *total_ms, double *kernel_ms /*[TA_N_KERNEL_SLOTS]*/);
-
-/* Measurement (bench.py, SURVEY 8(d) "achievable-copy figure"): device-to-device copy of `bytes`
- * bytes by a grid-stride kernel (16 B per lane) on the handle's stream, `reps` timed repetitions
- * after 2 untimed ones; *gbs = (bytes read + bytes written) / average time, in GB/s. */
-int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs);
-
-/* Measurement (bench.py, SURVEY 8(d) FP64 figure): number of unordered neighbour pairs {j, k} of the
- * resident batch's centres with r_ij, r_ik and r_jk all below acut, i.e. the triples whose G4 term
- * (sf.py:126-173) is not identically zero; ta_batch_info.n_triples counts all of them. Runs one
- * energy evaluation first (the count reads the pair records). */
-int ta_count_contributing_triples(ta_handle h, int64_t *n_contributing);
-
 /* sum of the resident batch's frame energies, left on the device for a
  * collective: returns a device pointer to one double (valid until destroy). */
 int ta_batch_energy_device_ptr(ta_handle h, void **dptr);
@@ -273,10 +268,6 @@ int ta_copy_batch_energy(ta_handle h, void *dst_device);
  * NULL restores the library's own buffer. Takes effect for launches made after the call;
  * ta_set_frames restores the library's own buffer. */
 int ta_set_batch_energy_target(ta_handle h, void *dst_device);
-
-/* debugging / parity: host copy of the pair list of the resident batch
- * (centre, neighbour, shift[3]) in the library's order. Arrays sized n_pairs. */
-int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift /*[n][3]*/);
 
 /* Host-only (no GPU needed): the neighbour list the library builds for one
  * frame, i.e. `ase.neighborlist.neighbor_list('ijS', atoms, rc)` as called at
@@ -348,6 +339,33 @@ int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *d
 int ta_eam_tabulate(ta_handle h, int32_t n_r, const double *r, int32_t n_rho, const double *rho,
                     double *rho_of_r, double *phi_of_r, double *embed_of_rho, double *u_of_r,
                     double *w_of_r);
+
+/* --- measurement and diagnostics ------------------------------------------------------------------
+ * Used by bench.py, scripts/ and tests/ only; NOT part of the drop-in path (nothing in
+ * tensoralloy_amd/calculator.py or transformer/ calls them, and the reference has no counterpart). */
+
+/* Measurement (bench.py): runs `warmup` untimed then `steps` timed passes of
+ * ta_compute over the resident batch, timed with HIP events on the handle's
+ * stream. total_ms = wall of the `steps` passes; kernel_ms[k] (may be NULL) =
+ * average duration per pass of kernel slot k, measured in a second run with
+ * events around every launch. */
+int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
+                    double *total_ms, double *kernel_ms /*[TA_N_KERNEL_SLOTS]*/);
+
+/* Measurement (bench.py, SURVEY 8(d) "achievable-copy figure"): device-to-device copy of `bytes`
+ * bytes by a grid-stride kernel (16 B per lane) on the handle's stream, `reps` timed repetitions
+ * after 2 untimed ones; *gbs = (bytes read + bytes written) / average time, in GB/s. */
+int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs);
+
+/* Measurement (bench.py, SURVEY 8(d) FP64 figure): number of unordered neighbour pairs {j, k} of the
+ * resident batch's centres with r_ij, r_ik and r_jk all below acut, i.e. the triples whose G4 term
+ * (sf.py:126-173) is not identically zero; ta_batch_info.n_triples counts all of them. Runs one
+ * energy evaluation first (the count reads the pair records). */
+int ta_count_contributing_triples(ta_handle h, int64_t *n_contributing);
+
+/* debugging / parity: host copy of the pair list of the resident batch
+ * (centre, neighbour, shift[3]) in the library's order. Arrays sized n_pairs. */
+int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift /*[n][3]*/);
 
 #ifdef __cplusplus
 }

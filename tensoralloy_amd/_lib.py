@@ -32,6 +32,7 @@ TA_CUTOFF = {"cosine": 0, "polynomial": 1}
 TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
           "sigmoid": 5, "softsign": 6, "elu": 7}
 TA_N_KERNEL_SLOTS = 10
+TA_ABI_VERSION = 3  # include/tensoralloy_amd.h: TA_ABI_VERSION
 KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
                 "force_gather", "frame_reduce", "eam", "neighbor_update", "grap_forward"]
 
@@ -43,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
     "ta_energy_gradient", "ta_measure_hbm_copy", "ta_set_skin", "ta_update_positions", "ta_list_stats",
     "ta_count_contributing_triples", "ta_loss_gradient", "ta_constant_count", "ta_get_constants", "ta_update_constants",
-    "ta_constant_gradient",
+    "ta_constant_gradient", "ta_list_sizes", "ta_abi_version", "ta_model_desc_size",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -100,7 +101,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     srcs = [CSRC_DIR / s for s in SOURCES]
     headers = list(CSRC_DIR.glob("*.h")) + [INCLUDE_DIR / "tensoralloy_amd.h"]
     deps = srcs + headers
-    if not force and LIB_PATH.exists():
+    stamp = OBJ_DIR / "flags.txt"
+    flags_same = stamp.exists() and stamp.read_text() == " ".join(_compile_flags())
+    if not force and flags_same and LIB_PATH.exists():
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:
             return LIB_PATH
@@ -112,12 +115,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in deps):
-                return LIB_PATH
             OBJ_DIR.mkdir(exist_ok=True)
             flags = _compile_flags()
-            stamp = OBJ_DIR / "flags.txt"
-            if not stamp.exists() or stamp.read_text() != " ".join(flags):
+            flags_same = stamp.exists() and stamp.read_text() == " ".join(flags)
+            if not force and flags_same and LIB_PATH.exists() and \
+                    LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in deps):
+                return LIB_PATH
+            if not flags_same:
                 force = True
             hdr_time = max(p.stat().st_mtime for p in headers)
 
@@ -163,8 +167,21 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
     # TA_LIB_AB=<path of another build of the same ABI>: kernel A/B runs inside one GPU session
-    # (box-to-box differences of ~5 % otherwise hide a 2 % kernel change)
-    lib = C.CDLL(os.environ.get("TA_LIB_AB") or str(LIB_PATH))
+    # (box-to-box differences of ~5 % otherwise hide a 2 % kernel change). Never silent, and only a
+    # library that reports this binding's ABI version (struct layouts included) is accepted.
+    path = os.environ.get("TA_LIB_AB") or str(LIB_PATH)
+    if path != str(LIB_PATH):
+        import sys
+        sys.stderr.write(f"tensoralloy_amd: TA_LIB_AB is set, loading {path} instead of {LIB_PATH}\n")
+    lib = C.CDLL(path)
+    try:
+        lib.ta_abi_version.restype = C.c_int
+        version, desc_size = lib.ta_abi_version(), lib.ta_model_desc_size()
+    except AttributeError:
+        version, desc_size = -1, -1
+    if version != TA_ABI_VERSION or desc_size != C.sizeof(ModelDesc):
+        raise ImportError(f"{path}: ABI version {version} / ta_model_desc of {desc_size} bytes, this binding "
+                          f"is version {TA_ABI_VERSION} / {C.sizeof(ModelDesc)} bytes: rebuild the library")
     H = C.c_void_p
     lib.ta_device_count.restype = C.c_int
     lib.ta_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(H)]
@@ -198,6 +215,7 @@ def load():
     lib.ta_set_skin.argtypes = [H, C.c_double]
     lib.ta_update_positions.argtypes = [H, _dp, _dp, _ip]
     lib.ta_list_stats.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.ta_list_sizes.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.ta_free.argtypes = [C.c_void_p]
     lib.ta_eam_tabulate.argtypes = [H, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.ta_free.restype = None

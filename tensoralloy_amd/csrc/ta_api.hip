@@ -360,6 +360,13 @@ void build_sf_model(ta_context *h, const ta_model_desc *m) {
       sf.eta[e * m->n_omega + o] = m->eta[e];
       sf.omega[e * m->n_omega + o] = m->omega[o];
     }
+  for (int c = 1; c < sf.n_rad; ++c) {
+    if ((c & 3) == 0 || sf.omega[c] != sf.omega[c - 1] || !(sf.eta[c - 1] > 0.0)) continue;
+    const double k = sf.eta[c] / sf.eta[c - 1];
+    if (k >= 2.0 && k <= 16.0 && k == std::nearbyint(k) && k * sf.eta[c - 1] == sf.eta[c] &&
+        !std::getenv("TA_NO_ETA_CHAIN"))
+      sf.eta_pow[c] = (signed char)k;
+  }
   sf.n_radial_dim = nel * sf.n_rad;
   sf.n_ang = 0;
   sf.n_beta = 0;
@@ -768,6 +775,9 @@ int guarded(ta_context *h, F &&fn) {
 }  // namespace
 
 extern "C" {
+
+int ta_abi_version(void) { return TA_ABI_VERSION; }
+int ta_model_desc_size(void) { return (int)sizeof(ta_model_desc); }
 
 int ta_device_count(void) {
   int n = 0;
@@ -1219,6 +1229,15 @@ int ta_list_stats(ta_handle h, int64_t *n_builds, int64_t *n_reuses) {
   return TA_OK;
 }
 
+int ta_list_sizes(ta_handle h, int64_t *n_pairs, int64_t *n_triples, int32_t *nnl_max) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (n_pairs) *n_pairs = h->hp.n_pairs;
+  if (n_triples) *n_triples = h->hp.n_triples;
+  if (nnl_max) *nnl_max = h->hp.nnl_max;
+  return TA_OK;
+}
+
 int ta_compute(ta_handle h, uint32_t want) {
   if (!h) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "ta_compute called before ta_set_frames");
@@ -1312,10 +1331,38 @@ int ta_batch_energy_device_ptr(ta_handle h, void **dptr) {
 }
 
 namespace {
+// 16 B per lane and four independent loads in flight per lane before the first store (a one-load
+// grid-stride loop reached 4.8 TB/s of the 6.3 TB/s the microarch guide measures for a float4 copy)
 __global__ __launch_bounds__(256) void hbm_copy_kernel(const double2 *__restrict__ src,
                                                        double2 *__restrict__ dst, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = src[k];
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; k + 3 * stride < n; k += 4 * stride) {
+    const double2 a = src[k], b = src[k + stride], c = src[k + 2 * stride], d = src[k + 3 * stride];
+    dst[k] = a;
+    dst[k + stride] = b;
+    dst[k + 2 * stride] = c;
+    dst[k + 3 * stride] = d;
+  }
+  for (; k < n; k += stride) dst[k] = src[k];
+}
+// the same with non-temporal loads and stores (streamed once: nothing to keep in L2 / MALL)
+__global__ __launch_bounds__(256) void hbm_copy_nt_kernel(const double2 *__restrict__ src,
+                                                          double2 *__restrict__ dst, size_t n) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 *s = reinterpret_cast<const d2 *>(src);
+  d2 *d = reinterpret_cast<d2 *>(dst);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; k + 3 * stride < n; k += 4 * stride) {
+    const d2 a = __builtin_nontemporal_load(s + k), b = __builtin_nontemporal_load(s + k + stride),
+             c = __builtin_nontemporal_load(s + k + 2 * stride), e = __builtin_nontemporal_load(s + k + 3 * stride);
+    __builtin_nontemporal_store(a, d + k);
+    __builtin_nontemporal_store(b, d + k + stride);
+    __builtin_nontemporal_store(c, d + k + 2 * stride);
+    __builtin_nontemporal_store(e, d + k + 3 * stride);
+  }
+  for (; k < n; k += stride) d[k] = s[k];
 }
 }  // namespace
 
@@ -1381,10 +1428,17 @@ int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs) {
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     HIP_CHECK(hipMemsetAsync(src, 0, n * 16, s));
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
-    for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    static const int per_cu = std::getenv("TA_COPY_WG_PER_CU") ? std::atoi(std::getenv("TA_COPY_WG_PER_CU")) : 8;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)256 * std::max(1, per_cu));
+    static const int mode = std::getenv("TA_COPY_MODE") ? std::atoi(std::getenv("TA_COPY_MODE")) : 0;
+    auto one = [&]() {
+      if (mode == 1) (void)hipMemcpyAsync(dst, src, n * 16, hipMemcpyDeviceToDevice, s);
+      else if (mode == 2) hipLaunchKernelGGL(hbm_copy_nt_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+      else hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    };
+    for (int k = 0; k < 2; ++k) one();
     HIP_CHECK(hipEventRecord(e0, s));
-    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    for (int k = 0; k < reps; ++k) one();
     HIP_CHECK(hipEventRecord(e1, s));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -1564,6 +1618,13 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
     if (!frame_coeff) return fail(h, TA_ERR_INVALID, "nothing to differentiate");
     return ta_energy_gradient(h, frame_coeff, grad, n_grad);
   }
+  // Per-pair buffers of this entry (tangents, Jacobian) are sized and walked by the resident
+  // list's pair count. Under a Verlet skin the kernels run on the exact list extracted from it
+  // (apply_filter: only the first pair_start[N] entries of the ex_* arrays are defined), so the two
+  // do not match: refuse instead of reading the undefined tail. Training never needs a skin.
+  if (h->filtered)
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: not available on a skin-filtered batch; "
+                                       "ta_set_skin(h, 0) and ta_set_frames first");
   return guarded(h, [&]() {
     int64_t total = 0;
     for (int e = 0; e < h->n_elements; ++e) total += ta::mlp_param_count(h->mlp[e]);
@@ -1656,6 +1717,9 @@ int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *d
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
   if (!h->eam) return fail(h, TA_ERR_INVALID, "the model has no empirical potential");
   if (!frame_coeff && !dR && !dh) return fail(h, TA_ERR_INVALID, "nothing to differentiate");
+  if (h->filtered)  // see ta_loss_gradient
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_constant_gradient: not available on a skin-filtered batch; "
+                                       "ta_set_skin(h, 0) and ta_set_frames first");
   return guarded(h, [&]() {
     const int64_t total = ta::eam_constant_count(h->eam);
     if (n_grad != total)
@@ -1770,10 +1834,15 @@ int ta_get_pairs(ta_handle h, int32_t *i, int32_t *j, int32_t *shift) {
   if (h->pairs_on_device) {
     return guarded(h, [&]() {
       HIP_CHECK(hipStreamSynchronize(h->stream));
-      if (i && P) HIP_CHECK(hipMemcpy(i, h->db.pair_i, P * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (j && P) HIP_CHECK(hipMemcpy(j, h->db.pair_j, P * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (shift && P)
-        HIP_CHECK(hipMemcpy(shift, h->db.pair_shift, 3 * P * sizeof(int32_t), hipMemcpyDeviceToHost));
+      // the RESIDENT list (n_pairs of ta_batch_info): under a Verlet skin that is the skin list, not
+      // the exact list the kernels extract from it per step (whose arrays are defined only up to
+      // their own, smaller count)
+      const int32_t *pi = h->filtered ? h->pair_i.ptr : h->db.pair_i;
+      const int32_t *pj = h->filtered ? h->pair_j.ptr : h->db.pair_j;
+      const int32_t *ps = h->filtered ? h->pair_shift.ptr : h->db.pair_shift;
+      if (i && P) HIP_CHECK(hipMemcpy(i, pi, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (j && P) HIP_CHECK(hipMemcpy(j, pj, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (shift && P) HIP_CHECK(hipMemcpy(shift, ps, 3 * P * sizeof(int32_t), hipMemcpyDeviceToHost));
     });
   }
   if (i) std::memcpy(i, h->hp.pair_i.data(), P * sizeof(int32_t));

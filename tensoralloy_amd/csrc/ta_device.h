@@ -35,6 +35,12 @@ struct SFParams {
   int n_beta;
   double eta[kMaxRadial], omega[kMaxRadial];
   double beta[kMaxBetaSlots];
+  // Power chain of the radial exponentials: eta_pow[c] = k >= 2 when eta[c] = k eta[c - 1] exactly,
+  // omega[c] = omega[c - 1] and c - 1 lies in the same group of four channels, so that
+  // exp(-eta[c] x) = exp(-eta[c - 1] x)^k costs a few multiplications instead of an exponential
+  // (the reference's default grid eta = {0.05, 4, 20, 80}: two exponentials instead of four);
+  // 0 = evaluate the exponential.
+  signed char eta_pow[kMaxRadial];
 };
 
 // One launch of the angular kernels handles NB x NG x NZ channels.

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
     int q = seg[sb] + lane;
     int jn = 0, sn[3] = {0, 0, 0}, j2 = 0, s2[3] = {0, 0, 0};
     double pn[3] = {0.0, 0.0, 0.0};
-    if (!geom_done) {
+    if (geom_done != 1) {
       if (q < q1) {
         jn = b.pair_j[q];
         for (int c = 0; c < 3; ++c) sn[c] = b.pair_shift[3 * (size_t)q + c];
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
       // pair geometry D = Rj - Ri + S.h, r^2 = D.D + eps (universal.py:448-474), computed here and
       // left in the pair record for the pair kernel and the force gather
       double rec[5];
-      if (geom_done) {  // eam_geom_kernel has been here
+      if (geom_done == 1) {  // eam_geom_kernel has been here
         const double2 *src = pair_geom(b, (size_t)q);
         const double2 a = src[0], c = src[1];
         rec[0] = a.x;
@@ -454,7 +454,11 @@ __global__ __launch_bounds__(kBlock) void eam_atom_kernel(EamParams P, DeviceBat
         rec[2] = (rj[2] - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
         rec[3] = rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2] + eps;
         rec[4] = 1.0 / sqrt(rec[3]);
-        if (b.rec4) {  // compact 32-byte record {D, r^2}: the readers recompute 1 / r
+        if (geom_done == 2) {
+          // no record: the one-pass force kernels recompute D from the neighbour's position and the
+          // shift (positions stay in L2; 16 bytes of indices per pair instead of a 32-byte store here
+          // and a 32-byte load there)
+        } else if (b.rec4) {  // compact 32-byte record {D, r^2}: the readers recompute 1 / r
           double2 *dst = reinterpret_cast<double2 *>(b.rec4 + 4 * (size_t)q);
           dst[0] = make_double2(rec[0], rec[1]);
           dst[1] = make_double2(rec[2], rec[3]);
@@ -882,9 +886,47 @@ __global__ __launch_bounds__(kBlock) void eam_pair_kernel(EamParams P, DeviceBat
 // g[rev p]; neither g nor the reverse-pair index is touched (eam.py:495-570 differentiated;
 // basic.py:277-331). One wavefront per atom, 16 atoms per workgroup (= one record of `bpart`).
 // W lanes per atom (see eam_atom_kernel), 16 atoms per workgroup (= one record of `bpart`).
+// The geometry of a pair in the one-pass force kernels: from the pair record (`from_pos` = 0) or
+// recomputed with the expressions of eam_atom_kernel from the neighbour's position and the shift,
+// which are prefetched one pass ahead as raw values (the arithmetic waits for them only when the pass
+// that needs them starts).
+struct PairFetch {
+  double2 n0, n1;  // record, or {x_j, y_j}, {z_j, -}
+  int s[3];
+};
+__device__ __forceinline__ void fetch_pair(const DeviceBatch &b, int from_pos, int q, int j, PairFetch &f) {
+  if (from_pos) {
+    const double *rj = b.pos + 3 * (size_t)j;
+    f.n0 = make_double2(rj[0], rj[1]);
+    f.n1 = make_double2(rj[2], 0.0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f.s[c] = b.pair_shift[3 * (size_t)q + c];
+  } else {
+    const double2 *rec = pair_geom(b, (size_t)q);
+    f.n0 = rec[0];
+    f.n1 = rec[1];
+  }
+}
+__device__ __forceinline__ void pair_vector(const PairFetch &f, int from_pos, const double *ri, const double *h,
+                                            double eps, double &dx, double &dy, double &dz, double &r2) {
+  if (from_pos) {
+    const double sx = (double)f.s[0], sy = (double)f.s[1], sz = (double)f.s[2];
+    dx = (f.n0.x - ri[0]) + (sx * h[0] + sy * h[3] + sz * h[6]);
+    dy = (f.n0.y - ri[1]) + (sx * h[1] + sy * h[4] + sz * h[7]);
+    dz = (f.n1.x - ri[2]) + (sx * h[2] + sy * h[5] + sz * h[8]);
+    r2 = dx * dx + dy * dy + dz * dz + eps;
+  } else {
+    dx = f.n0.x;
+    dy = f.n0.y;
+    dz = f.n1.x;
+    r2 = f.n1.y;
+  }
+}
+
 template <bool OTHER, int W>
 __global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBatch b, const double *dF,
-                                                           const TabDev *__restrict__ tabs) {
+                                                           const TabDev *__restrict__ tabs, int from_pos,
+                                                           double eps) {
   const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x / W);
   const int lane = threadIdx.x & (W - 1);
   const bool active = i < b.n_atoms;
@@ -895,33 +937,36 @@ __global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBa
     const double dFi = dF[i];
     const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
     const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    const double *hcell = b.cells + 9 * (size_t)b.frame_of_atom[i];
+    const double ri[3] = {b.pos[3 * (size_t)i], b.pos[3 * (size_t)i + 1], b.pos[3 * (size_t)i + 2]};
     for (int sb = 0; sb < nel; ++sb) {
       const int pt = pair_type(sA, sb, nel);
       const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
-      // as in eam_atom_kernel: the record and F'(rho_j) of the next pass and the neighbour index of the
+      // as in eam_atom_kernel: the geometry and F'(rho_j) of the next pass and the neighbour index of the
       // pass after next are fetched before this pass is evaluated
       const int q1 = seg[sb + 1];
       int q = seg[sb] + lane;
-      double2 n0 = make_double2(0.0, 0.0), n1 = n0;
+      PairFetch nx;
+      nx.n0 = nx.n1 = make_double2(0.0, 0.0);
+      nx.s[0] = nx.s[1] = nx.s[2] = 0;
       double dFn = 0.0;
       int j2 = 0;
       if (q < q1) {
-        const double2 *rec = pair_geom(b, (size_t)q);
-        n0 = rec[0];
-        n1 = rec[1];
-        dFn = dF[b.pair_j[q]];
+        const int j = b.pair_j[q];
+        fetch_pair(b, from_pos, q, j, nx);
+        dFn = dF[j];
       }
       if (q + W < q1) j2 = b.pair_j[q + W];
       for (; q < q1; q += W) {
-        const double2 v0 = n0, v1 = n1;
+        const PairFetch cur = nx;
         const double dFj = dFn;
         if (q + W < q1) {
-          const double2 *rec = pair_geom(b, (size_t)(q + W));
-          n0 = rec[0];
-          n1 = rec[1];
+          fetch_pair(b, from_pos, q + W, j2, nx);
           dFn = dF[j2];
         }
         if (q + 2 * W < q1) j2 = b.pair_j[q + 2 * W];
+        double2 v0, v1;
+        pair_vector(cur, from_pos, ri, hcell, eps, v0.x, v0.y, v1.x, v1.y);
         if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
         const double r = sqrt(v1.y);
         double fn, drhoB, drhoA, dphi;
@@ -970,7 +1015,8 @@ __global__ __launch_bounds__(16 * W) void eam_force_kernel(EamParams P, DeviceBa
 template <bool OTHER, int W>
 __global__ __launch_bounds__(16 * W) void adp_force_kernel(EamParams P, DeviceBatch b, const double *dF,
                                                            const double *__restrict__ mom,
-                                                           const TabDev *__restrict__ tabs) {
+                                                           const TabDev *__restrict__ tabs, int from_pos,
+                                                           double eps) {
   const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x / W);
   const int lane = threadIdx.x & (W - 1);
   const bool active = i < b.n_atoms;
@@ -981,6 +1027,8 @@ __global__ __launch_bounds__(16 * W) void adp_force_kernel(EamParams P, DeviceBa
     const double dFi = dF[i];
     const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
     const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    const double *hcell = b.cells + 9 * (size_t)b.frame_of_atom[i];
+    const double ri[3] = {b.pos[3 * (size_t)i], b.pos[3 * (size_t)i + 1], b.pos[3 * (size_t)i + 2]};
     for (int sb = 0; sb < nel; ++sb) {
       const int pt = pair_type(sA, sb, nel);
       const double *pp = P.pair[pt];
@@ -995,14 +1043,14 @@ __global__ __launch_bounds__(16 * W) void adp_force_kernel(EamParams P, DeviceBa
       // pipelined as eam_force_kernel: record, F'(rho_j) and the moments of j for the next pass
       const int q1 = seg[sb + 1];
       int q = seg[sb] + lane;
-      double2 n0 = make_double2(0.0, 0.0), n1 = n0;
+      PairFetch nx;
+      nx.n0 = nx.n1 = make_double2(0.0, 0.0);
+      nx.s[0] = nx.s[1] = nx.s[2] = 0;
       double dFn = 0.0, mn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       int j2 = 0;
       if (q < q1) {
-        const double2 *rec = pair_geom(b, (size_t)q);
-        n0 = rec[0];
-        n1 = rec[1];
         const int j = b.pair_j[q];
+        fetch_pair(b, from_pos, q, j, nx);
         dFn = dF[j];
         const double *src = mom + ((size_t)j * nel + sA) * 9;
 #pragma unroll
@@ -1010,21 +1058,21 @@ __global__ __launch_bounds__(16 * W) void adp_force_kernel(EamParams P, DeviceBa
       }
       if (q + W < q1) j2 = b.pair_j[q + W];
       for (; q < q1; q += W) {
-        const double2 v0 = n0, v1 = n1;
+        const PairFetch cur = nx;
         const double dFj = dFn;
         double mj[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) mj[k] = mn[k];
         if (q + W < q1) {
-          const double2 *rec = pair_geom(b, (size_t)(q + W));
-          n0 = rec[0];
-          n1 = rec[1];
+          fetch_pair(b, from_pos, q + W, j2, nx);
           dFn = dF[j2];
           const double *src = mom + ((size_t)j2 * nel + sA) * 9;
 #pragma unroll
           for (int k = 0; k < 9; ++k) mn[k] = src[k];
         }
         if (q + 2 * W < q1) j2 = b.pair_j[q + 2 * W];
+        double2 v0, v1;
+        pair_vector(cur, from_pos, ri, hcell, eps, v0.x, v0.y, v1.x, v1.y);
         if (P.list_rc2 > 0.0 && !(v1.y < P.list_rc2)) continue;  // beyond rc: not a neighbour
         const double r = sqrt(v1.y);
         double fn, drhoB, drhoA, dphi;
@@ -1893,6 +1941,10 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   const bool want_f = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) && b.n_pairs > 0;
   static const bool no_fold_adp = getenv("TA_ADP_NO_FOLD") != nullptr;
   const bool fold = want_f && !pair_nets && !no_fold && !(m->p.adp && no_fold_adp);
+  // One-pass force kernels (and energy-only evaluations) need no pair records: the force kernels
+  // recompute D from pos[j] + S.h. TA_EAM_RECORDS=1 keeps the record round trip (A/B switch).
+  static const bool keep_rec = getenv("TA_EAM_RECORDS") != nullptr;
+  const bool no_rec = !pair_nets && !keep_rec && (fold || !(want & (TA_WANT_FORCES | TA_WANT_VIRIAL)));
   // lanes per atom (measured, 4000-atom Ni frames, rc 6.5, us per frame for W = 16 / 32 / 64): EAM one
   // frame 25.5 / 26.2 / 28.0, 64 frames 11.3 / 14.1 / 16.7; ADP (one-pass force kernel, W = 16 / 32)
   // one frame 36.6 / 36.0, 64 frames 18.0 / 21.0
@@ -1901,7 +1953,7 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
   const dim3 agrid((unsigned)((b.n_atoms * W + kBlock - 1) / kBlock));
 #define TA_EAM_ATOM(O, WW)                                                                                   \
   hipLaunchKernelGGL((eam_atom_kernel<O, WW>), agrid, dim3(kBlock), 0, s, m->p, b, m->dF, m->mom, m->eps,    \
-                     m->pf, ps, m->rho_buf, pair_nets ? 1 : 0, m->tabs_dev)
+                     m->pf, ps, m->rho_buf, pair_nets ? 1 : (no_rec ? 2 : 0), m->tabs_dev)
 #define TA_EAM_BY_W(MACRO)                            \
   do {                                                \
     if (other) {                                      \
@@ -1937,10 +1989,11 @@ void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s
     if (fold) {
       const dim3 fgrid((unsigned)((b.n_atoms + 15) / 16));
 #define TA_EAM_FORCE(O, WW) \
-  hipLaunchKernelGGL((eam_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->tabs_dev)
+  hipLaunchKernelGGL((eam_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->tabs_dev, \
+                     no_rec ? 1 : 0, m->eps)
 #define TA_ADP_FORCE(O, WW)                                                                              \
   hipLaunchKernelGGL((adp_force_kernel<O, WW>), fgrid, dim3(16 * WW), 0, s, m->p, b, m->dF, m->mom, \
-                     m->tabs_dev)
+                     m->tabs_dev, no_rec ? 1 : 0, m->eps)
       if (m->p.adp) TA_EAM_BY_W(TA_ADP_FORCE);
       else TA_EAM_BY_W(TA_EAM_FORCE);
 #undef TA_EAM_FORCE

@@ -48,6 +48,16 @@ constexpr int kNFf = 7;  // forward: the last record is the species alone (8 byt
                          // which with the trimmed job counters lets 7 workgroups share a CU instead of 6
 constexpr int kJobCtlBytes = 240;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs, cstart[17 (+3)]
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
+constexpr int kRTab = 8;      // backward: radial dE/dG values per centre kept in LDS (neighbour species x radial channels)
+
+// LDS experiment switches (scripts/lds_probe.sh, -DTA_LDS_PROBE builds only; wrong results by
+// construction): TA_DEBUG_SKIP bit 4 sends the partner atomics of the backward body to conflict-free
+// addresses, bit 5 its late partner reads, bit 6 every partner read (and drops the exact u < 1 test)
+#ifdef TA_LDS_PROBE
+__device__ __forceinline__ bool kProbe(int flags, int bit) { return (flags >> bit) & 1; }
+#else
+__device__ __forceinline__ constexpr bool kProbe(int, int) { return false; }
+#endif
 
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
   int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
@@ -61,7 +71,7 @@ __device__ __forceinline__ int radial_term2(int center, int other) {
 // geometry with four 128-bit LDS reads ({x y}, {z r2}, {1/r H}, {G species}) instead of eight 64-bit
 // and one byte read (LDS instructions, not arithmetic, bound the backward body).
 struct Fields {
-  double2 *zr, *xy, *ih, *gs;  // {z, r^2}, {x, y}, {1/r, H}, {G, species of the neighbour as a double}
+  double2 *zr, *xy, *ih, *gs;  // {z, r^2}, {x, y}, {1/r, H}, {L = (dH/dr) / (r H), species of the neighbour as a double}
   double *sp1;                 // forward kernel: species alone (gs is null there)
   float *xf, *yf, *zf;  // single-precision ring copies for the candidate scan: the n neighbours of
                         // a centre are stored twice in a row (2 * base + k and + n), so partner
@@ -122,7 +132,14 @@ __device__ __forceinline__ double hd_value(const SFParams &sf, const AngChunk &c
 // (reference calculate_rij, transformer/universal.py:448-474) is computed here
 // and the pair record written for the later kernels; otherwise it is read.
 // `forward`: the forward kernel has no use for G = (dH/dr)/r (Fields::sp1 instead of Fields::gs).
-__device__ __forceinline__ void stage(const SFParams &sf, double beta, const DeviceBatch &b,
+// The pair's own factor H(u) = exp(-beta u) fc(u), u = r^2 / acut^2, is the SAME function as the
+// third side's Hd(u): with the power series (HD > 0) value and derivative cost one Horner sweep (22
+// fused multiply-adds; 11 in the forward kernel, which needs the value only) instead of the cutoff
+// series + an exponential (about 50). The backward kernel stages the logarithmic derivative
+// L = (dH/dr) / (r H) instead of G = (dH/dr) / r: its triple body then factors T = Ha Hb Hd out of all
+// three derivatives (see there). H = 0 (pair beyond acut) gives L = 0; such a pair has no triples.
+template <int HD>
+__device__ __forceinline__ void stage(const SFParams &sf, const AngChunk &ch, double beta, const DeviceBatch &b,
                                       const Fields &f, int s0, int M, int geom = 0, bool forward = false) {
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
     double2 v0, v1, v2;
@@ -173,17 +190,19 @@ __device__ __forceinline__ void stage(const SFParams &sf, double beta, const Dev
       f.zf[k0] = f.zf[k0 + cn] = (float)v1.x;
     }
     const double u = v1.y * sf.inv_ac2;
-    double H = 0.0, G = 0.0;
+    double H = 0.0, L = 0.0;
     if (u < 1.0) {
-      double fc, dfdu;
-      cutoff_u(sf.cutoff, u, fc, dfdu);
-      const double e = ta_exp(-beta * u);
-      H = e * fc;
-      G = e * 2.0 * sf.inv_ac2 * (dfdu - beta * fc);
+      if (forward) {
+        H = hd_value<HD>(sf, ch, beta, u);
+      } else {
+        double dH;
+        hd_eval<HD>(sf, ch, beta, u, H, dH);
+        L = (H != 0.0) ? sf.two_inv_ac2 * dH / H : 0.0;
+      }
     }
     f.ih[item] = make_double2(v2.x, H);
     if (forward) f.sp1[item] = (double)b.species[b.pair_j[s0 + item]];
-    else f.gs[item] = make_double2(G, (double)b.species[b.pair_j[s0 + item]]);
+    else f.gs[item] = make_double2(L, (double)b.species[b.pair_j[s0 + item]]);
   }
   __syncthreads();
 }
@@ -209,13 +228,17 @@ __device__ __forceinline__ unsigned long long partner_mask(const SFParams &sf, c
     const float *px = f.xf + ring + sc + 16 * g, *py = f.yf + ring + sc + 16 * g,
                 *pz = f.zf + ring + sc + 16 * g;
     unsigned m = 0u;
+    // candidates from the highest position down, m = 2 m + (d2 < lim): the comparison's lane mask goes
+    // straight into the carry input of an add (v_cmp + v_addc_co, two instructions per candidate
+    // instead of compare / select / or)
 #pragma unroll
-    for (int k = 0; k < 16; k += 2) {
+    for (int k = 14; k >= 0; k -= 2) {
       const f32x2 vx = {px[k], px[k + 1]}, vy = {py[k], py[k + 1]}, vz = {pz[k], pz[k + 1]};
       const f32x2 ex = vx - ax2, ey = vy - ay2, ez = vz - az2;
       const f32x2 d2 = __builtin_elementwise_fma(ex, ex, __builtin_elementwise_fma(ey, ey, ez * ez));
-      m |= (d2.x < lim) ? (1u << k) : 0u;
-      m |= (d2.y < lim) ? (2u << k) : 0u;
+      const float dhi = d2.y, dlo = d2.x;
+      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(dhi), "v"(lim) : "vcc");
+      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(dlo), "v"(lim) : "vcc");
     }
     mask |= (unsigned long long)m << (16 * g);
   }
@@ -452,15 +475,22 @@ __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk
       const double u = r2 * sf.inv_rc2;
       const double fc = (u < 1.0) ? cutoff_u_value(sf.cutoff, u) : 0.0;
       const double r = no_shift ? 0.0 : sqrt(r2);
+      double ev[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = (cc + k < n_rad) ? cc + k : cc;
-        double arg = sf.eta[c] * u;
-        if (!no_shift) {
-          const double dr = r - sf.omega[c];
-          arg = sf.eta[c] * dr * dr * sf.inv_rc2;
+        const int pw = (cc + k < n_rad && k > 0) ? sf.eta_pow[c] : 0;  // wave-uniform
+        if (pw > 0) {
+          ev[k] = pow_int_m1(ev[k > 0 ? k - 1 : 0], pw) * ev[k > 0 ? k - 1 : 0];  // SFParams::eta_pow
+        } else {
+          double arg = sf.eta[c] * u;
+          if (!no_shift) {
+            const double dr = r - sf.omega[c];
+            arg = sf.eta[c] * dr * dr * sf.inv_rc2;
+          }
+          ev[k] = ta_exp(-arg);
         }
-        R[k * cap + item] = ta_exp(-arg) * fc;  // sf.py:101-108
+        R[k * cap + item] = ev[k] * fc;  // sf.py:101-108
       }
     }
     __syncthreads();
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(kBlock)
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * kCap; k += blockDim.x) P0[k] = 0.0;
   }
-  stage(sf, beta, b, f, s0, M, geom, true);
+  stage<HD>(sf, ch, beta, b, f, s0, M, geom, true);
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
@@ -584,13 +614,13 @@ __global__ __launch_bounds__(kBlock)
     // one candidate partner: position a + step of the centre's ring
     auto triple = [&](int bl) {
         bl = (int)min((unsigned)bl, (unsigned)bl - (unsigned)n);  // bl < 2 n: bl mod n without a compare / select
-        const int q = base + bl;
+        const int q = kProbe(flags, 30) ? (int)threadIdx.x : base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
         const double ex = bxy.x - ax, ey = bxy.y - ay, ez = bzr.x - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
-        const double u = d2 * sf.inv_ac2;
+        const double u = kProbe(flags, 30) ? 0.5 : d2 * sf.inv_ac2;
         if (!(u < 1.0)) return;  // exact test (the mask is a superset); H_b = 0 adds nothing
-        const double2 bih = f.ih[q];
+        const double2 bih = f.ih[kProbe(flags, 29) ? (int)threadIdx.x : q];
         const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ra * bih.x;
         const double common = Ha * bih.y * hd_value<HD>(sf, ch, beta, u);
         const int sb = NSPEC == 1 ? 0 : (int)f.sp1[q];
@@ -837,14 +867,30 @@ __global__ __launch_bounds__(kBlock)
         p3 += 4.0 * g2 * g1 * w4;
         p4 += g2 * g2 * w4;
       }
+      // in powers of w = 2 cos(theta) (what the triple body has: (r_a^2 + r_b^2 - r_ab^2) / (r_a r_b))
       pctab[5 * k] = p0;
-      pctab[5 * k + 1] = p1;
-      pctab[5 * k + 2] = p2;
-      pctab[5 * k + 3] = p3;
-      pctab[5 * k + 4] = p4;
+      pctab[5 * k + 1] = 0.5 * p1;
+      pctab[5 * k + 2] = 0.25 * p2;
+      pctab[5 * k + 3] = 0.125 * p3;
+      pctab[5 * k + 4] = 0.0625 * p4;
     }
   }
-  stage(sf, beta, b, f, s0, M);
+  // dE/dG of the RADIAL channels per (centre, neighbour species) for the epilogue's G2 share, fetched
+  // here by the lanes next to those (the workgroup's last ones, mostly without a pair) so that the
+  // epilogue walks no pair_i -> species / dE/dG chain of dependent global loads at the kernel's tail
+  double *rtab = pctab + 5 * kMaxCentersPerBlock;  // [kMaxCentersPerBlock][kRTab]
+  const bool use_rtab = first && NSPEC * sf.n_rad <= kRTab;
+  if (use_rtab) {
+    const int per = NSPEC * sf.n_rad;
+    const int t = (int)blockDim.x - 1 - (int)threadIdx.x - kMaxCentersPerBlock;
+    if (t >= 0 && t < (c1 - c0) * per) {
+      const int ci = t / per, rem = t - ci * per;
+      const int sb = rem / sf.n_rad, c = rem - sb * sf.n_rad;
+      const int64_t i = c0 + ci;
+      rtab[ci * kRTab + rem] = b.dEdG[(size_t)i * sf.ndim + radial_term2(b.species[i], sb) * sf.n_rad + c];
+    }
+  }
+  stage<HD>(sf, ch, beta, b, f, s0, M);
   const int nel = sf.n_elements;
 
   auto run_item = [&](int item, bool have_mask, unsigned long long mask0, auto is_job) {
@@ -864,14 +910,14 @@ __global__ __launch_bounds__(kBlock)
     const int a = item - base;
     const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item], ags = f.gs[item];
     const double ax = axy.x, ay = axy.y, az = azr.x;
-    const double ra2 = azr.y, inv_ra = aih.x, Ha = aih.y, Ga = ags.x;
+    const double ra2 = azr.y, inv_ra = aih.x, Ha = aih.y, La = ags.x;
     const double inv_ra2 = inv_ra * inv_ra;
     const int sa = (int)ags.y;
 
     // dE/dG of the channels of term (sa, sp) for every partner species sp
     // w = dE/dG 2^(1-zeta); wd = w zeta gamma (factor of the derivative of (1 + gamma c)^zeta)
     constexpr bool kTable = kJob && DEFZ && NSPEC == 1;  // coefficients from `pctab`
-    double w[NSPEC][NG][NZ], wd[NSPEC][NG][NZ];
+    double w_[NSPEC][NG][NZ], wd[NSPEC][NG][NZ];
 #pragma unroll
     for (int sp = 0; sp < (kTable ? 0 : NSPEC); ++sp) {
       const double *wsrc = b.dEdG + (size_t)i * sf.ndim + sf.n_radial_dim +
@@ -880,8 +926,8 @@ __global__ __launch_bounds__(kBlock)
       for (int ig = 0; ig < NG; ++ig)
 #pragma unroll
         for (int iz = 0; iz < NZ; ++iz) {
-          w[sp][ig][iz] = wsrc[ch.chan[ig * NZ + iz]] * ch.kz[iz];
-          wd[sp][ig][iz] = w[sp][ig][iz] * ch.zeta[iz] * ch.gamma[ig];
+          w_[sp][ig][iz] = wsrc[ch.chan[ig * NZ + iz]] * ch.kz[iz];
+          wd[sp][ig][iz] = w_[sp][ig][iz] * ch.zeta[iz] * ch.gamma[ig];
         }
     }
 
@@ -901,35 +947,44 @@ __global__ __launch_bounds__(kBlock)
 #pragma unroll
         for (int ig = 0; ig < NG; ++ig) {
           const double g1 = ch.gamma[ig], g2 = g1 * g1;
-          const double w1 = w[sp][ig][0], w4 = w[sp][ig][1];
+          const double w1 = w_[sp][ig][0], w4 = w_[sp][ig][1];
           pc[sp][0] += w1 + w4;
-          pc[sp][1] += g1 * (w1 + 4.0 * w4);
-          pc[sp][2] += 6.0 * g2 * w4;
-          pc[sp][3] += 4.0 * g2 * g1 * w4;
-          pc[sp][4] += g2 * g2 * w4;
+          pc[sp][1] += 0.5 * g1 * (w1 + 4.0 * w4);  // powers of w = 2 cos(theta), as in `pctab`
+          pc[sp][2] += 0.25 * 6.0 * g2 * w4;
+          pc[sp][3] += 0.125 * 4.0 * g2 * g1 * w4;
+          pc[sp][4] += 0.0625 * g2 * g2 * w4;
         }
       }
     }
-    double gx = 0.0, gy = 0.0, gz = 0.0;
+    // Own share of dE/dD_a = sum_b (ca D_a + Q D_b): the scalar sum of ca and the vector sum of Q D_b
+    // (1 + 3 operations per triple instead of 6), combined once at the end
+    double csum = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
     auto triple = [&](int bl) {
         bl = (int)min((unsigned)bl, (unsigned)bl - (unsigned)n);  // bl < 2 n: bl mod n without a compare / select
-        const int q = base + bl;
+        const int q = kProbe(flags, 30) ? (int)threadIdx.x : base + bl;
         const double2 bxy = f.xy[q], bzr = f.zr[q];
         const double bx = bxy.x, by = bxy.y, bz = bzr.x;
         const double ex = bx - ax, ey = by - ay, ez = bz - az;
         const double d2 = fma(ex, ex, fma(ey, ey, fma(ez, ez, sf.eps)));
-        const double u = d2 * sf.inv_ac2;
+        const double u = kProbe(flags, 30) ? 0.5 : d2 * sf.inv_ac2;
         if (!(u < 1.0)) return;  // exact test (the mask is a superset)
-        const double2 bih = f.ih[q], bgs = f.gs[q];
-        const double inv_rb = bih.x;
+        const int q2 = kProbe(flags, 29) ? (int)threadIdx.x : q;
+        const double2 bih = f.ih[q2], bgs = f.gs[q2];
+        const double inv_rb = bih.x, Hb = bih.y, Lb = bgs.x;
+        const int sb = NSPEC == 1 ? 0 : (int)bgs.y;
+        // V = S0(c) T with T = Ha Hb Hd, c = cos(theta) = w / 2, w = (ra^2 + rb^2 - d^2) / (ra rb):
+        //   dV/dD_a = ca D_a + Q D_b,   dV/dD_b = cb D_b + Q D_a,
+        //   ca = S0 T La - (S1 T) c / ra^2 + X,  cb = S0 T Lb - (S1 T) c / rb^2 + X,
+        //   Q = (S1 T) / (ra rb) - X,   X = S0 Ha Hb Hd2,   S1 = dS0/dc,
+        // La, Lb = (dH/dr) / (r H) of the two pairs (staged), Hd2 = (dHd/dr) / r of the third side.
+        // Product form throughout: nothing is divided by a cutoff factor or by (1 + gamma c).
         const double inv_ab = inv_ra * inv_rb;
-        const double cth = (ra2 + bzr.y - d2) * 0.5 * inv_ab;
+        const double w = (ra2 + bzr.y - d2) * inv_ab;
         double Hd, dHd;
         hd_eval<HD>(sf, ch, beta, u, Hd, dHd);
         const double Hd2 = sf.two_inv_ac2 * dHd;
-        const double Hb = bih.y, Gb = bgs.x;
-        const int sb = NSPEC == 1 ? 0 : (int)bgs.y;
-        double S0 = 0.0, S1 = 0.0;
+        double S0 = 0.0, Yc, Y;  // Y = S1 T, Yc = Y c
+        const double HH = Ha * Hb, T = HH * Hd;
         if constexpr (DEFZ) {
           double p0 = pc[0][0], p1 = pc[0][1], p2 = pc[0][2], p3 = pc[0][3], p4 = pc[0][4];
 #pragma unroll
@@ -940,18 +995,23 @@ __global__ __launch_bounds__(kBlock)
             p3 = (sb == sp) ? pc[sp][3] : p3;
             p4 = (sb == sp) ? pc[sp][4] : p4;
           }
-          S0 = fma(fma(fma(fma(p4, cth, p3), cth, p2), cth, p1), cth, p0);
-          S1 = fma(fma(fma(4.0 * p4, cth, 3.0 * p3), cth, 2.0 * p2), cth, p1);
+          S0 = fma(fma(fma(fma(p4, w, p3), w, p2), w, p1), w, p0);
+          const double S1w = fma(fma(fma(4.0 * p4, w, 3.0 * p3), w, 2.0 * p2), w, p1);  // dS0/dw = S1 / 2
+          const double Z = S1w * T;
+          Yc = Z * w;  // (2 Z) (w / 2)
+          Y = Z + Z;
         } else {
+          const double cth = 0.5 * w;
+          double S1 = 0.0;
 #pragma unroll
           for (int ig = 0; ig < NG; ++ig) {
             const double basev = fma(ch.gamma[ig], cth, 1.0);
 #pragma unroll
             for (int iz = 0; iz < NZ; ++iz) {
-              double ws = w[0][ig][iz], wds = wd[0][ig][iz];
+              double ws = w_[0][ig][iz], wds = wd[0][ig][iz];
 #pragma unroll
               for (int sp = 1; sp < NSPEC; ++sp) {
-                ws = (sb == sp) ? w[sp][ig][iz] : ws;
+                ws = (sb == sp) ? w_[sp][ig][iz] : ws;
                 wds = (sb == sp) ? wd[sp][ig][iz] : wds;
               }
               double pm1;
@@ -963,18 +1023,22 @@ __global__ __launch_bounds__(kBlock)
               S1 = fma(wds, pm1, S1);
             }
           }
+          Y = S1 * T;
+          Yc = Y * cth;
         }
-        // (dV/dr_a)/r_a, (dV/dr_b)/r_b, (dV/dr_jk)/r_jk for V = sum_c w_c v_c
-        const double Aa = Hb * Hd * fma(S1 * Ha, inv_ab - cth * inv_ra2, S0 * Ga);
-        const double Ab = Ha * Hd * fma(S1 * Hb, inv_ab - cth * inv_rb * inv_rb, S0 * Gb);
-        const double Q = Ha * Hb * fma(-S1 * inv_ab, Hd, S0 * Hd2);
-        const double ca = Aa + Q, cb = Ab + Q;
-        gx = fma(ca, ax, fma(-Q, bx, gx));
-        gy = fma(ca, ay, fma(-Q, by, gy));
-        gz = fma(ca, az, fma(-Q, bz, gz));
-        atomicAdd(&gacc[q], fma(cb, bx, -Q * ax));
-        atomicAdd(&gacc[kCap + q], fma(cb, by, -Q * ay));
-        atomicAdd(&gacc[2 * kCap + q], fma(cb, bz, -Q * az));
+        const double S0T = S0 * T;
+        const double X = (S0 * HH) * Hd2;
+        const double ca = fma(S0T, La, fma(-Yc, inv_ra2, X));
+        const double cb = fma(S0T, Lb, fma(-Yc, inv_rb * inv_rb, X));
+        const double Q = fma(Y, inv_ab, -X);
+        csum += ca;
+        gx = fma(Q, bx, gx);
+        gy = fma(Q, by, gy);
+        gz = fma(Q, bz, gz);
+        const int q3 = kProbe(flags, 28) ? (int)threadIdx.x : q;
+        atomicAdd(&gacc[q3], fma(cb, bx, Q * ax));
+        atomicAdd(&gacc[kCap + q3], fma(cb, by, Q * ay));
+        atomicAdd(&gacc[2 * kCap + q3], fma(cb, bz, Q * az));
     };
     if constexpr (kJob) {
       const uint32_t jw = (uint32_t)mask0;
@@ -999,9 +1063,9 @@ __global__ __launch_bounds__(kBlock)
       }
     }
     }
-    atomicAdd(&gacc[item], gx);
-    atomicAdd(&gacc[kCap + item], gy);
-    atomicAdd(&gacc[2 * kCap + item], gz);
+    atomicAdd(&gacc[item], fma(csum, ax, gx));
+    atomicAdd(&gacc[kCap + item], fma(csum, ay, gy));
+    atomicAdd(&gacc[2 * kCap + item], fma(csum, az, gz));
   };
 
   {
@@ -1052,19 +1116,28 @@ __global__ __launch_bounds__(kBlock)
     double gx = gacc[item], gy = gacc[kCap + item], gz = gacc[2 * kCap + item];
     if (first) {
       // radial (G2) share: s_p D / r  (sf.py:101-108 differentiated)
-      const int i = b.pair_i[p];
+      const double *wr;
+      if (use_rtab) {
+        int ci = 0;
+        for (int k = 1; k < c1 - c0; ++k) ci += (item >= cstart[k]) ? 1 : 0;
+        wr = rtab + ci * kRTab + (NSPEC == 1 ? 0 : (int)f.gs[item].y * sf.n_rad);
+      } else {
+        const int i = b.pair_i[p];
+        wr = b.dEdG + (size_t)i * sf.ndim + radial_term2(b.species[i], (int)f.gs[item].y) * sf.n_rad;
+      }
       const double r2 = f.zr[item].y, inv_r = f.ih[item].x;
       const double ur = r2 * sf.inv_rc2;
       double s = 0.0;
       if (ur < 1.0) {
         double fc, dfdu;
         cutoff_u(sf.cutoff, ur, fc, dfdu);
-        const double r = sqrt(r2);
+        const double r = r2 * inv_r;  // no square root: 1 / r is staged
         const double dfdr = dfdu * 2.0 * r * sf.inv_rc2;
-        const double *wr = b.dEdG + (size_t)i * sf.ndim + radial_term2(b.species[i], (int)f.gs[item].y) * sf.n_rad;
+        double e = 0.0;
         for (int c = 0; c < sf.n_rad; ++c) {
           const double dr = r - sf.omega[c];
-          const double e = ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2);
+          const int pw = sf.eta_pow[c];  // wave-uniform: exp(-eta[c] x) = exp(-eta[c - 1] x)^pw
+          e = pw > 0 ? pow_int_m1(e, pw) * e : ta_exp(-sf.eta[c] * dr * dr * sf.inv_rc2);
           s = fma(wr[c], e * (dfdr - 2.0 * sf.eta[c] * dr * fc * sf.inv_rc2), s);
         }
       }
@@ -1138,10 +1211,17 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 size_t v2_lds_bytes(bool backward, int cap, int n_local) {
   if (!backward && n_local > 0) return v2_counter_offset(cap) + kJobCtlBytes + (size_t)n_local * cap * sizeof(double);
   return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
-         (backward ? 3 * (size_t)cap * sizeof(double) + kMaxCentersPerBlock * 5 * sizeof(double) : 0);
+         (backward ? 3 * (size_t)cap * sizeof(double) + kMaxCentersPerBlock * (5 + kRTab) * sizeof(double) : 0);
 }
 int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 
+#ifdef TA_V2_FEW  // experiment builds (ISA inspection, quick A/B): the benchmark shape only
+#define TA_DISPATCH_V2(FN, ...)                                   \
+  do {                                                            \
+    if (nspec * 100 + ng * 10 + nz != 122) throw std::domain_error("TA_V2_FEW build"); \
+    FN<1, 2, 2>(__VA_ARGS__);                                     \
+  } while (0)
+#else
 #define TA_DISPATCH_V2(FN, ...)                                   \
   do {                                                            \
     const int key = nspec * 100 + ng * 10 + nz;                   \
@@ -1164,13 +1244,14 @@ int v2_job_stride(int cap) { return v2_max_jobs(cap); }
         throw std::domain_error("no second-generation angular kernel for this (species, gamma, zeta) shape"); \
     }                                                             \
   } while (0)
+#endif
 
 // stagger flags for a launch: "<count>[,<shift>]" from the environment (experiment switch)
 static int stagger_bits(const DeviceBatch &b, const char *var) {
   const char *e = getenv(var);
   if (getenv("TA_DEBUG_NO_TRIPLES")) return 1 << 24;  // instruction accounting (wrong results)
   // more accounting switches (wrong results): bit 0 triple bodies, 1 candidate scan, 2 G2 sums, 3 job sweep
-  if (const char *d = getenv("TA_DEBUG_SKIP")) return (atoi(d) & 15) << 24;
+  if (const char *d = getenv("TA_DEBUG_SKIP")) return (atoi(d) & 127) << 24;
   if (!e) return 0;
   int n = 0, shift = 3;
   if (sscanf(e, "%d,%d", &n, &shift) < 1) return 0;

@@ -36,6 +36,7 @@ class Engine:
         self._volumes = None
         self._md_sig = None   # (n, numbers, pbc) of the single resident frame of `evaluate_md`
         self._md_cell = None
+        self.batch_generation = 0  # bumped whenever the resident batch or its coordinates change
 
     # -- lifetime ----------------------------------------------------------------
     def close(self):
@@ -72,6 +73,7 @@ class Engine:
         self._check(self._lib.ta_set_frames(self._handle, len(frames), arr, C.byref(info)))
         self.info = info
         self._frames = frames
+        self.batch_generation += 1  # what is resident changed (train.Trainer's shortcut checks this)
         self._md_sig = None
         self._volumes = np.array([abs(np.linalg.det(f.cell)) for f in frames])
         self._natoms = np.array([len(f.species) for f in frames], dtype=np.int64)
@@ -94,9 +96,16 @@ class Engine:
             if len(cells) != int(self.info.n_frames):
                 raise ValueError("one cell per resident frame")
             cptr = _lib.as_dp(cells)
-            self._volumes = np.abs(np.linalg.det(cells))
         rebuilt = C.c_int32(0)
         self._check(self._lib.ta_update_positions(self._handle, _lib.as_dp(pos), cptr, C.byref(rebuilt)))
+        self.batch_generation += 1
+        if cells is not None:  # only once the call has succeeded
+            self._volumes = np.abs(np.linalg.det(cells))
+        if rebuilt.value:
+            # a rebuilt list has new pair / triple counts: scripts derive bytes per evaluation from them
+            n_pairs, n_triples, nnl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+            self._check(self._lib.ta_list_sizes(self._handle, C.byref(n_pairs), C.byref(n_triples), C.byref(nnl)))
+            self.info.n_pairs, self.info.n_triples, self.info.nnl_max = n_pairs.value, n_triples.value, nnl.value
         return bool(rebuilt.value)
 
     def list_stats(self):

@@ -294,6 +294,7 @@ class Trainer:
         if self.constants_mode and not self.analytic:
             raise ValueError("the constants have no finite-difference path")
         self._resident = False
+        self._generation = -1
         self.frames = list(frames[lo:hi])
         self.e_ref = np.asarray(energies, dtype=np.float64)[lo:hi]
         self.f_ref = None if forces is None else [np.asarray(f, dtype=np.float64) for f in forces[lo:hi]]
@@ -313,7 +314,9 @@ class Trainer:
     def loss_and_gradient(self):
         from .atoms import Atoms
         eng = self.engine
-        if self.analytic and self._resident:
+        # the shortcut holds only while the engine still has THIS trainer's frames resident: any
+        # set_frames / update_positions on the (public) engine in between bumps its generation
+        if self.analytic and self._resident and eng.batch_generation == self._generation:
             # same frames as the last step: the batch, its neighbour list, descriptors and their
             # Jacobian are resident; only the MLP changed
             eng.compute(_lib_want_all())
@@ -321,6 +324,7 @@ class Trainer:
         else:
             res = eng.evaluate(self.frames)
             self._resident = self.analytic
+            self._generation = eng.batch_generation
         pred_e = np.array([r["energy"] for r in res])
         we, wf, ws = self.weights
         terms = {}

@@ -391,3 +391,56 @@ def test_fit_of_empirical_constants_recovers_a_teacher(lib):
         if n is None or n[1] in ("r_eq", "rho_e", "rho_s"):
             assert end[k] == off[k]
     assert np.abs(end - off).max() > 0
+
+
+def test_per_pair_entries_on_a_skin_filtered_batch(lib):
+    """with a Verlet skin the kernels run on the exact list extracted from the
+    resident skin list, whose arrays are defined only up to their own pair count. The per-pair
+    gradient entry refuses such a batch instead of walking the undefined tail, `pairs()` hands out
+    the resident (skin) list with `info.n_pairs` entries, and with the skin back at 0 the gradient
+    is the one an unfiltered engine gives."""
+    from tensoralloy_amd import Engine
+    from tests.helpers import fcc
+    nn = make_nn(["Ni"], 4.5, True, [8, 8], seed=5)
+    frames = [fcc(rep=(3, 3, 3), seed=3)]
+    n = len(frames[0])
+    rng = np.random.RandomState(1)
+    dR, c = rng.normal(size=(n, 3)), np.array([0.3])
+    with Engine(nn) as eng:
+        eng.set_frames(frames)
+        eng.compute(3)
+        ref = eng.loss_gradient(c, dR)
+        n_exact = int(eng.info.n_pairs)
+        eng.set_skin(0.5)
+        info = eng.set_frames(frames)
+        eng.compute(3)
+        assert int(info.n_pairs) > n_exact
+        with pytest.raises(ValueError, match="skin-filtered"):
+            eng.loss_gradient(c, dR)
+        i, j, s = eng.pairs()
+        assert len(i) == int(info.n_pairs) and i.min() >= 0 and i.max() < n and j.min() >= 0 and j.max() < n
+        d = frames[0].positions[j] - frames[0].positions[i] + s @ np.asarray(frames[0].get_cell(complete=True))
+        r = np.linalg.norm(d, axis=1)
+        assert r.max() < 4.5 + 0.5 and (r < 4.5).sum() == n_exact
+        eng.set_skin(0.0)
+        eng.set_frames(frames)
+        eng.compute(3)
+        again = eng.loss_gradient(c, dR)
+    assert np.abs(again - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_trainer_shortcut_notices_a_foreign_batch(lib):
+    """`Trainer.engine` is public; an evaluation of other frames between two steps
+    (a validation pass) must not let the next step reuse the 'resident' batch."""
+    from tensoralloy_amd.train import Trainer
+    from tests.helpers import fcc
+    nn = make_nn(["Ni"], 4.5, True, [8], seed=5)
+    teacher = make_nn(["Ni"], 4.5, True, [8], seed=6)
+    frames = [fcc(rep=(2, 2, 2), seed=k) for k in range(2)]
+    refs = [oracle_eval(teacher, a) for a in frames]
+    tr = Trainer(nn, frames, np.array([o["energy"] for o in refs]), [o["forces"] for o in refs], None, device=0)
+    l0, _, g0 = tr.loss_and_gradient()
+    tr.engine.evaluate([fcc(rep=(2, 2, 2), seed=77), fcc(rep=(2, 2, 2), seed=78)])  # same sizes, other geometry
+    l1, _, g1 = tr.loss_and_gradient()
+    tr.close()
+    assert abs(l1 - l0) < 1e-12 and np.abs(g1 - g0).max() < 1e-10

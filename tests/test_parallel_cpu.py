@@ -65,3 +65,25 @@ def test_two_rank_energy_allreduce():
     assert spans == [(0, 3), (3, 5)]
     for _, _, _, e in out:
         assert abs(e - total) < 1e-9
+
+
+def test_bench_with_more_ranks_than_gpus_fails_fast():
+    """`python bench.py --gpus 2` (nccl) where fewer than two GPUs are visible — none here — must
+    exit non-zero within seconds and say why, not sit in the rendezvous (VERDICT r2, weak #10)."""
+    import subprocess
+    import sys
+    import time
+    from tensoralloy_amd import _lib
+    _lib.build()  # the spawning process would build a stale library first: not what is timed here
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TA_BENCH_BACKEND"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--rep", "4", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0
+    assert time.time() - t0 < 60
+    assert "GPU(s) visible" in p.stderr and "rank exit codes" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
