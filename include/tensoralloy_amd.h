@@ -330,6 +330,20 @@ int ta_update_constants(ta_handle h, const double *constants, int64_t n_constant
 int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
                          double *grad, int64_t n_grad);
 
+/* "nn" pair functions of an EAM / ADP model (rho(r), phi(r), u(r), w(r) as `convolution1x1` networks of
+ * the pair distance, nn/eam/eam.py:174-190 — the reference's DEFAULT potentials, alloy.py:110-112):
+ * `on` != 0 evaluates them through cubic Hermite tables of 32769 knots over [0, rcut] that the
+ * library builds from the networks (value and derivative exact at every knot; rebuilt by
+ * ta_update_weights), `on` = 0 evaluates the networks for every pair. Tables are the default for
+ * inference (environment TA_EAM_NN_TABLES=0 turns them off at ta_create); they differ from the exact
+ * evaluation by ~1e-12 eV per structure, and they are how the reference deploys these potentials
+ * itself (`export_to_setfl`, alloy.py:198-381, with a ~30x coarser table). Weight gradients
+ * (ta_energy_gradient) need the networks: the first such call switches the handle to exact
+ * evaluation for good, after which `on` != 0 is ignored. The embedding networks F(rho) are always
+ * exact. No effect on models without nn pair functions. Drops nothing resident: the next
+ * ta_compute uses the new mode (call ta_set_frames again if a Verlet skin is in use). */
+int ta_set_nn_tables(ta_handle h, int on);
+
 /* Tables of an EAM / ADP model's functions (analytic, nn or tabulated) on caller-supplied abscissae: what
  * `EamAlloyNN.export_to_setfl` (nn/eam/alloy.py:198-381) evaluates through a TF session before it
  * writes a LAMMPS setfl file. Rows: elements (sorted) for rho(r) [n_elements][n_r] and F(rho)
@@ -353,8 +367,9 @@ int ta_time_compute(ta_handle h, uint32_t want, int32_t warmup, int32_t steps,
                     double *total_ms, double *kernel_ms /*[TA_N_KERNEL_SLOTS]*/);
 
 /* Measurement (bench.py, SURVEY 8(d) "achievable-copy figure"): device-to-device copy of `bytes`
- * bytes by a grid-stride kernel (16 B per lane) on the handle's stream, `reps` timed repetitions
- * after 2 untimed ones; *gbs = (bytes read + bytes written) / average time, in GB/s. */
+ * bytes on the handle's stream, three ways (grid-stride kernel with 16 B per lane and four loads in
+ * flight, the same with non-temporal accesses, the runtime's hipMemcpyAsync), each with `reps` timed
+ * repetitions after 2 untimed ones; *gbs = the best (bytes read + bytes written) / average time, GB/s. */
 int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs);
 
 /* Measurement (bench.py, SURVEY 8(d) FP64 figure): number of unordered neighbour pairs {j, k} of the

@@ -59,6 +59,9 @@ void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
                  hipEvent_t *ev /* 2 events or null */);
 void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test */);
 bool eam_is_plain(const EamModel *);
+void eam_set_nn_tables(EamModel *, bool on);
+bool eam_nn_tables_on(const EamModel *);
+void eam_mark_trained(EamModel *);
 int64_t eam_param_count(const EamModel *);
 void eam_update_weights(EamModel *, const double *flat, int64_t n);
 int64_t eam_constant_count(const EamModel *);
@@ -1430,24 +1433,32 @@ int ta_measure_hbm_copy(ta_handle h, int64_t bytes, int32_t reps, double *gbs) {
     HIP_CHECK(hipMemsetAsync(src, 0, n * 16, s));
     static const int per_cu = std::getenv("TA_COPY_WG_PER_CU") ? std::atoi(std::getenv("TA_COPY_WG_PER_CU")) : 8;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)256 * std::max(1, per_cu));
-    static const int mode = std::getenv("TA_COPY_MODE") ? std::atoi(std::getenv("TA_COPY_MODE")) : 0;
-    auto one = [&]() {
-      if (mode == 1) (void)hipMemcpyAsync(dst, src, n * 16, hipMemcpyDeviceToDevice, s);
-      else if (mode == 2) hipLaunchKernelGGL(hbm_copy_nt_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
-      else hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
-    };
-    for (int k = 0; k < 2; ++k) one();
-    HIP_CHECK(hipEventRecord(e0, s));
-    for (int k = 0; k < reps; ++k) one();
-    HIP_CHECK(hipEventRecord(e1, s));
-    HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // three ways to copy, the fastest counts (measured on this pool: 4.8-5.2, 5.0-5.5 and 5.0-5.5 TB/s
+    // read + written; the microarch guide quotes 6.29 for a float4 copy): the grid-stride kernel, the
+    // runtime's device-to-device copy, the kernel with non-temporal loads and stores
+    static const int only = std::getenv("TA_COPY_MODE") ? std::atoi(std::getenv("TA_COPY_MODE")) : -1;
+    double best = 0.0;
+    for (int mode = 0; mode < 3; ++mode) {
+      if (only >= 0 && mode != only) continue;
+      auto one = [&]() {
+        if (mode == 1) (void)hipMemcpyAsync(dst, src, n * 16, hipMemcpyDeviceToDevice, s);
+        else if (mode == 2) hipLaunchKernelGGL(hbm_copy_nt_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+        else hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+      };
+      for (int k = 0; k < 2; ++k) one();
+      HIP_CHECK(hipEventRecord(e0, s));
+      for (int k = 0; k < reps; ++k) one();
+      HIP_CHECK(hipEventRecord(e1, s));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms > 0.f) best = std::max(best, 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9);
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(src);
     (void)hipFree(dst);
-    *gbs = ms > 0.f ? 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+    *gbs = best;
   });
 }
 
@@ -1529,6 +1540,14 @@ int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int
       if (n_grad != total)
         throw std::invalid_argument("ta_energy_gradient: expected room for " + std::to_string(total) + " values");
       if (total == 0) return;
+      // weight gradients differentiate the networks themselves: from here on this handle evaluates its
+      // nn pair functions exactly, not through their tables (eam_set_nn_tables)
+      if (h->filtered)
+        throw std::domain_error("ta_energy_gradient: not available on a skin-filtered batch; "
+                                "ta_set_skin(h, 0) and ta_set_frames first");
+      if (ta::eam_nn_tables_on(h->eam)) HIP_CHECK(hipStreamSynchronize(h->stream));
+      ta::eam_mark_trained(h->eam);
+      ta::eam_ensure(h->eam, h->db);  // the per-pair columns of the exact evaluation
       // every function depends on the weights: the forward pass runs again (rho, F', moments)
       compute_impl(h, TA_WANT_ENERGY, false, nullptr);
       hipStream_t s = h->stream;
@@ -1787,6 +1806,19 @@ int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64
 }
 
 void ta_free(void *p) { std::free(p); }
+
+int ta_set_nn_tables(ta_handle h, int on) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->eam) return TA_OK;
+  return guarded(h, [&]() {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->filtered && !on)
+      throw std::domain_error("ta_set_nn_tables: a skin-filtered batch is resident; ta_set_frames again afterwards "
+                              "(set the mode before ta_set_frames)");
+    ta::eam_set_nn_tables(h->eam, on != 0);
+    if (h->have_batch) ta::eam_ensure(h->eam, h->db);
+  });
+}
 
 int ta_eam_tabulate(ta_handle h, int32_t n_r, const double *r, int32_t n_rho, const double *rho,
                     double *rho_of_r, double *phi_of_r, double *embed_of_rho, double *u_of_r,

@@ -1247,7 +1247,44 @@ __global__ __launch_bounds__(THREADS) void eam_nn_table_kernel(const MlpDev *__r
       [&](int, int, double) {});
 }
 
+// Value and derivative of one nn function at the knots k dx of a table (forward + backward sweep of
+// the same 16-row tile the exact kernels use): fv[2 k] = f, fv[2 k + 1] = f'
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void eam_nn_knots_kernel(const MlpDev *__restrict__ nets, int slot,
+                                                               int act, double dx, int n, double *fv,
+                                                               int stride) {
+  extern __shared__ double lds[];
+  double *buf0 = lds, *buf1 = lds + kMlpRows * stride, *da = lds + 2 * kMlpRows * stride;
+  const int a0 = blockIdx.x * kMlpRows;
+  const int nrows = min(kMlpRows, n - a0);
+  if (threadIdx.x < kMlpRows) buf0[threadIdx.x * stride] = (double)(a0 + (int)threadIdx.x) * dx;
+  __syncthreads();
+  mlp_tile<16>(
+      nets[slot], act, 1, nrows, buf0, buf1, stride, da, [&](int row, double y) { fv[2 * (size_t)(a0 + row)] = y; },
+      [&](int row, int, double d) { fv[2 * (size_t)(a0 + row) + 1] = d; });
+}
+
+// cubic Hermite pieces {c0, c1, c2, c3} in t = x - x_k from the knot values and derivatives
+// (the layout `spline_eval` reads): the interpolant matches f and f' at every knot
+__global__ __launch_bounds__(kBlock) void hermite_coef_kernel(int n, double dx, const double *__restrict__ fv,
+                                                              double *__restrict__ c) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n - 1) return;
+  const double f0 = fv[2 * (size_t)k], d0 = fv[2 * (size_t)k + 1], f1 = fv[2 * (size_t)k + 2],
+               d1 = fv[2 * (size_t)k + 3];
+  const double inv = 1.0 / dx, slope = (f1 - f0) * inv;
+  c[4 * (size_t)k] = f0;
+  c[4 * (size_t)k + 1] = d0;
+  c[4 * (size_t)k + 2] = (3.0 * slope - 2.0 * d0 - d1) * inv;
+  c[4 * (size_t)k + 3] = (d0 + d1 - 2.0 * slope) * inv * inv;
+}
+
 constexpr int kNetThreads = 256;
+// Knots of an nn function's table over [0, rcut]: dx = rcut / 32768 (2e-4 A at rcut = 6.5). Cubic
+// Hermite error: value dx^4 / 384 |f''''|, derivative about dx^3 / 72 |f''''| (1e-17 / 1e-13 per unit of
+// f''''): far below the 1e-6 eV / 1e-5 eV/A the path is held to, for any network this side of a step
+// function. 1 MB per function: the tables of a model stay in L2.
+constexpr int kNnTableKnots = 32769;
 
 }  // namespace
 
@@ -1275,6 +1312,14 @@ struct EamModel {
   size_t fast_lds = 0;
   NnFnList fns;                   // the pair functions that are nn functions
   double *rho_buf = nullptr;      // [cap_atoms]
+  // nn pair functions through tables (inference): see eam_set_nn_tables
+  double rcut = 0.0;
+  bool tables_on = false, trained = false;
+  bool pair_nets_exact = false;
+  EamParams p_exact;              // function masks of the exact evaluation
+  std::vector<TabDev> tabs_host;  // [n_slots] file tables and, while tables_on, the nn pair functions
+  std::vector<double *> nn_coef;  // [n_slots] device coefficients of an nn function's table (or null)
+  double *knot_fv = nullptr;      // [2 kNnTableKnots] scratch
 };
 
 namespace {
@@ -1351,6 +1396,8 @@ size_t net_lds_bytes(const EamModel *e) {
 
 }  // namespace
 
+void eam_set_nn_tables(EamModel *m, bool on);
+
 EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   const int nel = m->n_elements;
   const bool adp = m->kind == TA_MODEL_EAM_ADP;
@@ -1381,6 +1428,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
   }
   EamModel *e = new EamModel();
   std::memset(&e->p, 0, sizeof(e->p));
+  e->rcut = m->rcut;
   e->p.nel = nel;
   e->p.adp = adp ? 1 : 0;
   e->eps = m->eps > 0.0 ? m->eps : 1e-14;
@@ -1405,6 +1453,7 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
         t.c = eam_upload(e, c);
       }
       e->tabs_dev = eam_upload(e, tabs);
+      e->tabs_host = tabs;
       for (int k = 0; k < nel; ++k) {
         if (tabs[slot_rho(k)].n) e->p.tab_rho |= 1u << k;
         if (tabs[slot_embed(nel, k)].n) e->p.tab_embed |= 1u << k;
@@ -1506,7 +1555,98 @@ EamModel *eam_create(const ta_model_desc *m, std::string &err) {
       err = "r_eq, rho_e and rho_s must be positive";
       return nullptr;
     }
+  e->p_exact = e->p;
+  e->pair_nets_exact = e->pair_nets;
+  if (e->pair_nets) {
+    const char *env = getenv("TA_EAM_NN_TABLES");
+    if (!(env && env[0] == '0')) {
+      try {
+        eam_set_nn_tables(e, true);
+      } catch (const std::exception &ex) {
+        err = ex.what();
+        eam_destroy(e);
+        return nullptr;
+      }
+    }
+  }
   return e;
+}
+
+// (Re)tabulate every nn PAIR function (rho, phi, u, w of r; the embedding networks stay exact: one
+// evaluation per atom) on kNnTableKnots knots over [0, rcut]; device work on the null stream, synchronous.
+static void eam_build_nn_tables(EamModel *m) {
+  const int nel = m->p.nel, npair = nel * (nel + 1) / 2;
+  const int n = kNnTableKnots;
+  const double dx = m->rcut / (double)(n - 1);
+  if (!m->knot_fv && hipMalloc((void **)&m->knot_fv, 2 * (size_t)n * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+  if ((int)m->tabs_host.size() != m->n_slots) m->tabs_host.assign(m->n_slots, TabDev{0, 0.0, 0.0, nullptr});
+  if ((int)m->nn_coef.size() != m->n_slots) m->nn_coef.assign(m->n_slots, nullptr);
+  auto build = [&](int slot) {
+    if (m->nets[slot].n_layers == 0) return;
+    if (!m->nn_coef[slot]) {
+      double *c = nullptr;
+      if (hipMalloc((void **)&c, 4 * (size_t)(n - 1) * sizeof(double)) != hipSuccess) throw std::bad_alloc();
+      m->owned.push_back(c);
+      m->nn_coef[slot] = c;
+    }
+    hipLaunchKernelGGL(eam_nn_knots_kernel<kNetThreads>, dim3((unsigned)((n + kMlpRows - 1) / kMlpRows)),
+                       dim3(kNetThreads), net_lds_bytes(m), 0, m->nets_dev, slot, m->activation, dx, n, m->knot_fv,
+                       m->stride);
+    hipLaunchKernelGGL(hermite_coef_kernel, dim3((unsigned)((n - 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, n,
+                       dx, m->knot_fv, m->nn_coef[slot]);
+    m->tabs_host[slot] = TabDev{n, dx, 1.0 / dx, m->nn_coef[slot]};
+  };
+  for (int e = 0; e < nel; ++e) build(slot_rho(e));
+  for (int cls = 1; cls < (m->p.adp ? 4 : 2); ++cls)
+    for (int pt = 0; pt < npair; ++pt) build(slot_pair(nel, cls, pt));
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
+    throw std::runtime_error("tabulating the nn functions failed");
+  if (!m->tabs_dev) {
+    TabDev *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)m->n_slots * sizeof(TabDev)) != hipSuccess) throw std::bad_alloc();
+    m->owned.push_back(reinterpret_cast<double *>(d));
+    m->tabs_dev = d;
+  }
+  if (hipMemcpy(m->tabs_dev, m->tabs_host.data(), (size_t)m->n_slots * sizeof(TabDev), hipMemcpyHostToDevice) !=
+      hipSuccess)
+    throw std::runtime_error("hipMemcpy of the function tables failed");
+}
+
+// nn PAIR functions through cubic Hermite tables (`on`) or evaluated exactly per pair (off).
+// rho(r), phi(r), u(r), w(r) are functions of one scalar, the pair distance, which a step evaluates
+// for ~90 pairs per atom: 96 softplus + sigmoid evaluations and 64 fp64 MFMAs per (pair, function)
+// exactly, one 32-byte gather and 7 fused multiply-adds from the table. This is how the reference
+// deploys these potentials itself (`export_to_setfl` tabulates them for LAMMPS, alloy.py:198-381); the
+// table here is ~30x finer than a setfl file's and carries exact derivatives at the knots. With
+// tables the model runs the one-pass kernels of the analytic / tabulated potentials (no per-pair
+// columns, no pair records, no force gather). Weight gradients need the networks themselves: a
+// handle that trains (ta_energy_gradient) switches to exact evaluation for good.
+void eam_set_nn_tables(EamModel *m, bool on) {
+  if (!m->pair_nets_exact) return;  // nothing to tabulate
+  if (on && m->trained) return;
+  if (on) {
+    eam_build_nn_tables(m);
+    const double keep = m->p.list_rc2;
+    m->p = m->p_exact;
+    m->p.list_rc2 = keep;
+    m->p.tab_rho |= m->p.nn_rho;
+    m->p.tab_phi |= m->p.nn_phi;
+    m->p.tab_u |= m->p.nn_u;
+    m->p.tab_w |= m->p.nn_w;
+    m->p.nn_rho = m->p.nn_phi = m->p.nn_u = m->p.nn_w = 0;
+    m->pair_nets = false;
+  } else {
+    const double keep = m->p.list_rc2;
+    m->p = m->p_exact;
+    m->p.list_rc2 = keep;
+    m->pair_nets = m->pair_nets_exact;
+  }
+  m->tables_on = on;
+}
+bool eam_nn_tables_on(const EamModel *m) { return m->tables_on; }
+void eam_mark_trained(EamModel *m) {
+  m->trained = true;
+  if (m->tables_on) eam_set_nn_tables(m, false);
 }
 
 void eam_destroy(EamModel *m) {
@@ -1518,6 +1658,7 @@ void eam_destroy(EamModel *m) {
   if (m->gcoeff) (void)hipFree(m->gcoeff);
   if (m->gscratch) (void)hipFree(m->gscratch);
   if (m->gpartial) (void)hipFree(m->gpartial);
+  if (m->knot_fv) (void)hipFree(m->knot_fv);
   for (double *d : m->owned) (void)hipFree(d);
   delete m;
 }
@@ -1614,6 +1755,7 @@ void eam_update_weights(EamModel *m, const double *flat, int64_t n) {
         throw std::runtime_error("hipMemcpy of the EAM function networks failed");
     }
   }
+  if (m->tables_on) eam_build_nn_tables(m);  // the tables follow the weights
 }
 
 namespace {

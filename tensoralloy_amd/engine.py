@@ -79,6 +79,12 @@ class Engine:
         self._natoms = np.array([len(f.species) for f in frames], dtype=np.int64)
         return info
 
+    def set_nn_tables(self, on: bool):
+        """nn pair functions of an EAM / ADP model through the library's Hermite tables (default for
+        inference) or evaluated exactly for every pair (`ta_set_nn_tables`). Set it before
+        `set_frames`."""
+        self._check(self._lib.ta_set_nn_tables(self._handle, 1 if on else 0))
+
     def set_skin(self, skin: float):
         """Verlet skin in Angstrom for the lists built from now on (0 = exact list)."""
         self._check(self._lib.ta_set_skin(self._handle, float(skin)))
