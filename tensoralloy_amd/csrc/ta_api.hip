@@ -231,7 +231,7 @@ struct ta_context {
   std::vector<double> ref_pos, ref_cells;      // positions / cells the resident list was built for
   size_t o_pos = 0, o_cells = 0, o_species = 0;  // byte offsets in the packed input
   // exact list of the current step, extracted on the device from the resident skin list (nl_filter)
-  DevBuf<int32_t> ex_pair_i, ex_pair_j, ex_pair_shift, ex_pair_rev, ex_pair_start, ex_seg_start, ex_counts,
+  DevBuf<int32_t> ex_pair_i, ex_pair_j, ex_pair_shift, ex_pair_rev, ex_pair_start, ex_pair_stop, ex_seg_start, ex_counts,
       ex_map, ex_blk;
   bool filtered = false;                       // db points at the ex_* arrays
   hipEvent_t ev_upload = nullptr;              // last H2D copy out of stage_in
@@ -863,7 +863,7 @@ int ta_destroy(ta_handle h) {
   h->jvp_J.release(); h->tan_dD.release(); h->tan_dG.release(); h->tan_dir.release();
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release();
-  for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start,
+  for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start, &h->ex_pair_stop,
                   &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk})
     b->release();
   h->masks.release(); h->job_word.release(); h->job_count.release();
@@ -919,20 +919,19 @@ void apply_filter(ta_context *h) {
   h->ex_pair_shift.ensure(3 * P + 3);
   h->ex_pair_rev.ensure(P + 1);
   h->ex_pair_start.ensure(N + 1);
+  h->ex_pair_stop.ensure(N + 1);
   h->ex_seg_start.ensure(N * (nel + 1) + 1);
-  h->ex_counts.ensure(N * (nel + 1) + 1);
   h->ex_map.ensure(P + 1);
-  h->ex_blk.ensure(N + 4);
-  h->nl_stats.ensure(8);
+  const int n_run_slots = nl_filter_blocks((int)N);
+  h->ex_blk.ensure((size_t)n_run_slots + 4);
   const bool blocks = h->kind == TA_MODEL_SF_MLP;
-  int32_t *n_blk_dev = h->ex_blk.ptr + N + 2;
-  nl_filter((int)N, (int64_t)P, nel, h->rmax, h->db.pos, h->db.cells, h->db.frame_of_atom, h->seg_start.ptr,
-            h->pair_j.ptr, h->pair_shift.ptr, h->pair_rev.ptr, h->ex_counts.ptr, h->ex_map.ptr,
-            h->ex_seg_start.ptr, h->ex_pair_start.ptr, h->ex_pair_i.ptr, h->ex_pair_j.ptr,
-            h->ex_pair_shift.ptr, h->ex_pair_rev.ptr, h->nl_stats.ptr, h->db.cap,
-            blocks ? h->ex_blk.ptr : nullptr, n_blk_dev, (int)N, h->stream);
+  nl_filter((int)N, (int64_t)P, nel, h->rmax, h->db.pos, h->db.cells, h->db.frame_of_atom,
+            h->pair_start.ptr, h->seg_start.ptr, h->pair_j.ptr, h->pair_shift.ptr, h->pair_rev.ptr, h->ex_map.ptr,
+            h->ex_seg_start.ptr, h->ex_pair_start.ptr, h->ex_pair_stop.ptr, h->ex_pair_i.ptr, h->ex_pair_j.ptr,
+            h->ex_pair_shift.ptr, h->ex_pair_rev.ptr, h->db.cap, blocks ? h->ex_blk.ptr : nullptr, h->stream);
   HIP_CHECK(hipGetLastError());
   h->db.pair_start = h->ex_pair_start.ptr;
+  h->db.pair_stop = h->ex_pair_stop.ptr;
   h->db.seg_start = h->ex_seg_start.ptr;
   h->db.pair_i = h->ex_pair_i.ptr;
   h->db.pair_j = h->ex_pair_j.ptr;
@@ -940,9 +939,10 @@ void apply_filter(ta_context *h) {
   h->db.pair_rev = h->ex_pair_rev.ptr;
   if (blocks) {
     h->db.blk_center = h->ex_blk.ptr;
-    h->db.n_blk = (int)N;  // upper bound of the grid: every run holds at least one centre
-    h->db.n_blk_dev = n_blk_dev;
-    ensure_job_lists(h, N);
+    h->db.n_blk = n_run_slots;  // 16 run slots per group of 16 centres; unused ones are empty runs
+    h->db.blk_groups = n_run_slots / 16;
+    h->db.n_blk_dev = nullptr;
+    ensure_job_lists(h, (size_t)n_run_slots);
   }
   h->filtered = true;
 }
@@ -963,6 +963,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   h->descriptors_valid = false;
   h->jvp_valid = false;
   h->filtered = false;
+  h->db.pair_stop = nullptr;
+  h->db.blk_groups = 0;
   h->db.n_blk_dev = nullptr;
   h->r_list = h->rmax + h->skin;
   size_t N = 0;
@@ -1377,7 +1379,7 @@ __global__ __launch_bounds__(256) void count_triples_kernel(ta::DeviceBatch b, d
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= b.n_atoms) return;
-  const int p0 = b.pair_start[i], p1 = b.pair_start[i + 1];
+  const int p0 = b.pair_start[i], p1 = ta::pair_stop_of(b, i);
   unsigned long long n = 0;
   for (int pa = p0 + lane; pa < p1; pa += 64) {
     const double2 *ra = ta::pair_geom(b, (size_t)pa);

@@ -67,10 +67,19 @@ struct DeviceBatch {
   int32_t *frame_of_atom = nullptr;
   int32_t *atom_start = nullptr; // [F+1]
   int32_t *pair_start = nullptr; // [N+1]
+  // [N] or null. Null: the pairs of centre i end where those of i + 1 begin. Set on the MD path
+  // (ta_nlist.hip::nl_filter), whose exact list keeps every group of 16 centres at the group's offset
+  // in the skin list (no prefix sum over the whole batch), so groups are separated by unused slots.
+  int32_t *pair_stop = nullptr;
   int32_t *seg_start = nullptr;  // [N][nel+1]
   int32_t *pair_i = nullptr, *pair_j = nullptr, *pair_shift = nullptr, *pair_rev = nullptr;
   int32_t *blk_center = nullptr; // [n_blk+1] first centre of every v2 workgroup
   int n_blk = 0;
+  // MD step (ta_nlist.hip::filter_group_kernel): > 0 = number of groups of 16 centres, each owning 16
+  // run slots of which the later ones are usually empty. Workgroup b then takes slot
+  // 16 (b mod groups) + b / groups, so that the slots in use come first in launch order (interleaved
+  // with the empty ones they ran on half of the shader engines: 48 -> 77 us for the forward kernel)
+  int blk_groups = 0;
   const int32_t *n_blk_dev = nullptr;  // MD loop: the packing was made on the device, `n_blk` is only an upper
                                        // bound of the grid; workgroups beyond *n_blk_dev leave at once
   int cap = kCapMin;             // records per v2 workgroup (multiple of 64)
@@ -109,6 +118,13 @@ struct DeviceBatch {
   double *virial = nullptr; // [F][9]
   double *batch_energy = nullptr;  // [1]
 };
+
+// end of centre i's pairs (see DeviceBatch::pair_stop)
+#ifdef __HIPCC__
+__device__ __forceinline__ int pair_stop_of(const DeviceBatch &b, int64_t i) {
+  return b.pair_stop ? b.pair_stop[i] : b.pair_start[i + 1];
+}
+#endif
 
 // {Dx, Dy}, {Dz, r^2} of pair q, from the compact or the full record
 #ifdef __HIPCC__
@@ -193,12 +209,12 @@ int nl_bins(const NlGrid &g);
 void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, int32_t *pair_start,
               hipStream_t s);
+int nl_filter_blocks(int n_atoms);
 void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double *pos, const double *cells,
-               const int32_t *frame_of_atom, const int32_t *seg_super, const int32_t *pj_super,
-               const int32_t *ps_super, const int32_t *rev_super, int32_t *counts, int32_t *map,
-               int32_t *seg_exact, int32_t *pair_start, int32_t *pi_out, int32_t *pj_out, int32_t *ps_out,
-               int32_t *rev_out, unsigned long long *stats, int cap, int32_t *blk_center, int32_t *n_blk_dev,
-               int max_blk, hipStream_t s);
+               const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super,
+               const int32_t *pj_super, const int32_t *ps_super, const int32_t *rev_super, int32_t *map,
+               int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out, int32_t *pj_out,
+               int32_t *ps_out, int32_t *rev_out, int cap, int32_t *blk_center, hipStream_t s);
 void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,
              const int32_t *species, const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w,
              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, hipStream_t s);

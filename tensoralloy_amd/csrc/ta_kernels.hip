@@ -351,7 +351,7 @@ __global__ __launch_bounds__(16 * W) void force_gather_kernel(DeviceBatch b) {
   const int lane = threadIdx.x & (W - 1);
   const bool active = i < b.n_atoms;
   double f[3] = {0, 0, 0}, w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int q0 = active ? b.pair_start[i] : 0, q1 = active ? b.pair_start[i + 1] : 0;
+  const int q0 = active ? b.pair_start[i] : 0, q1 = active ? pair_stop_of(b, i) : 0;
   if (b.own_sums) {
     // the backward kernel left sum_p g[p] and the virial rows per atom: only g[rev p] is gathered
     // (36 bytes per pair instead of 100)

@@ -183,7 +183,7 @@ __device__ __forceinline__ void stage(const SFParams &sf, const AngChunk &ch, do
     f.zr[item] = v1;
     {
       const int ci = b.pair_i[s0 + item];
-      const int cbase = b.pair_start[ci] - s0, cn = b.pair_start[ci + 1] - b.pair_start[ci];
+      const int cbase = b.pair_start[ci] - s0, cn = pair_stop_of(b, ci) - b.pair_start[ci];
       const int k0 = 2 * cbase + (item - cbase);
       f.xf[k0] = f.xf[k0 + cn] = (float)v0.x;
       f.yf[k0] = f.yf[k0 + cn] = (float)v0.y;
@@ -555,16 +555,19 @@ __global__ __launch_bounds__(kBlock)
   stagger(flags);
   extern __shared__ double lds[];
   const Fields f = carve(lds, kCap, true);
-  const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
+  const int slot = b.blk_groups > 0 ? 16 * ((int)blockIdx.x % b.blk_groups) + (int)blockIdx.x / b.blk_groups
+                                    : (int)blockIdx.x;
+  const int c0 = b.blk_center[slot], c1 = b.blk_center[slot + 1];
+  if (c0 >= c1) return;  // an unused run slot of the MD step's packing (ta_nlist.hip::filter_group_kernel)
   const int s0 = b.pair_start[c0];
-  const int M = b.pair_start[c1] - s0;
+  const int M = pair_stop_of(b, c1 - 1) - s0;  // a workgroup's centres are contiguous in the list
   const double beta = ch.beta[0];
   if (b.job_count) {  // job counters and partial sums: cleared before the staging barrier
     char *raw = reinterpret_cast<char *>(lds);
     int *cnt = reinterpret_cast<int *>(raw + v2_counter_offset(kCap));
     if (threadIdx.x < 40) cnt[threadIdx.x] = 0;
     else if (threadIdx.x < 40 + 17 && (int)threadIdx.x - 40 <= c1 - c0)  // cstart[k]: first pair of centre c0 + k
-      cnt[threadIdx.x] = b.pair_start[c0 + threadIdx.x - 40] - b.pair_start[c0];
+      cnt[threadIdx.x] = ((int)threadIdx.x - 40 < c1 - c0 ? b.pair_start[c0 + threadIdx.x - 40] : s0 + M) - s0;
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * kCap; k += blockDim.x) P0[k] = 0.0;
   }
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(kBlock)
     } else {
       const int i = b.pair_i[p];
       base = b.pair_start[i] - s0;
-      n = b.pair_start[i + 1] - b.pair_start[i];
+      n = pair_stop_of(b, i) - b.pair_start[i];
     }
     const int a = item - base;
     const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item];
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(kBlock)
   int n_own = 0;
   if (active) {
     const int i = b.pair_i[s0 + item];
-    n_own = b.pair_start[i + 1] - b.pair_start[i];
+    n_own = pair_stop_of(b, i) - b.pair_start[i];
   }
   const bool one_pass = M <= (int)blockDim.x && !__syncthreads_or(active && (n_own >> 1) > 64);
   if (one_pass) {
@@ -840,14 +843,18 @@ __global__ __launch_bounds__(kBlock)
   const Fields f = carve(lds, kCap);
   // partner accumulators sit behind the float copies and species bytes, 8-byte aligned
   double *gacc = lds + kNF * kCap + (3 * (2 * kCap + kRingPad)) / 2 + kCap / 8;
-  const int c0 = b.blk_center[blockIdx.x], c1 = b.blk_center[blockIdx.x + 1];
+  const int slot = b.blk_groups > 0 ? 16 * ((int)blockIdx.x % b.blk_groups) + (int)blockIdx.x / b.blk_groups
+                                    : (int)blockIdx.x;
+  const int c0 = b.blk_center[slot], c1 = b.blk_center[slot + 1];
+  if (c0 >= c1) return;  // unused run slot
   const int s0 = b.pair_start[c0];
-  const int M = b.pair_start[c1] - s0;
+  const int M = pair_stop_of(b, c1 - 1) - s0;
   const double beta = ch.beta[0];
   for (int k = threadIdx.x; k < 3 * kCap; k += blockDim.x) gacc[k] = 0.0;
   // cstart[k]: first pair of centre c0 + k (see job_centre), in the kCap bytes in front of gacc
   int *cstart = reinterpret_cast<int *>(gacc) - 20;
-  if ((int)threadIdx.x <= c1 - c0 && threadIdx.x < 17) cstart[threadIdx.x] = b.pair_start[c0 + threadIdx.x] - s0;
+  if ((int)threadIdx.x <= c1 - c0 && threadIdx.x < 17)
+    cstart[threadIdx.x] = ((int)threadIdx.x < c1 - c0 ? b.pair_start[c0 + threadIdx.x] : s0 + M) - s0;
   // One-element default grid: the polynomial coefficients of dE/dG (see `pc` below) once per CENTRE,
   // by the last lanes of the workgroup while the others stage, instead of four dependent global loads
   // and twenty operations in the prologue of every job
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(kBlock)
     } else {
       i = b.pair_i[p];
       base = b.pair_start[i] - s0;
-      n = b.pair_start[i + 1] - b.pair_start[i];
+      n = pair_stop_of(b, i) - b.pair_start[i];
     }
     const int a = item - base;
     const double2 axy = f.xy[item], azr = f.zr[item], aih = f.ih[item], ags = f.gs[item];
@@ -1074,7 +1081,7 @@ __global__ __launch_bounds__(kBlock)
     int n_own = 0;
     if (active) {
       const int i = b.pair_i[s0 + item];
-      n_own = b.pair_start[i + 1] - b.pair_start[i];
+      n_own = pair_stop_of(b, i) - b.pair_start[i];
     }
     const bool one_pass = M <= (int)blockDim.x && !__syncthreads_or(active && (n_own >> 1) > 64);
     const int n_jobs = (one_pass && b.job_count) ? b.job_count[blockIdx.x] : -1;

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <stdexcept>
 #include <vector>
 
 #include "ta_device.h"
@@ -94,47 +95,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(int n, const int32_t *in, in
   if (t == 1023) {
     out[n] = incl;
     if (total) *total = incl;
-  }
-}
-
-// The MD step's variant: exclusive scan of the per-(atom, species) counts AND pair_start (every
-// (nel + 1)-th entry of the result) in one launch; the statistics finish_starts_kernel collects are
-// not read on that path.
-__global__ __launch_bounds__(1024) void scan_starts_kernel(int n_atoms, int nel, const int32_t *in,
-                                                           int32_t *out, int32_t *pair_start) {
-  __shared__ int wtot[16];
-  const int t = threadIdx.x;
-  const int n = n_atoms * (nel + 1);
-  // whole atoms per lane, so that a lane's first entry is an atom's first segment
-  const int apl = (n_atoms + 1023) / 1024;
-  const int a_lo = min(n_atoms, t * apl), a_hi = min(n_atoms, a_lo + apl);
-  const int lo = a_lo * (nel + 1), hi = a_hi * (nel + 1);
-  // eight loads in flight per lane: one workgroup does this, and it is latency all the way
-  int s = 0;
-  for (int k = lo; k < hi; k += 8) {
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = in[min(k + u, hi - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (k + u < hi) ? v[u] : 0;
-  }
-  const int incl = block_scan_1024(s, wtot);
-  int run = incl - s;
-  for (int k = lo; k < hi; k += 8) {
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = in[min(k + u, hi - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (k + u < hi) {
-        out[k + u] = run;
-        if ((k + u) % (nel + 1) == 0) pair_start[(k + u) / (nel + 1)] = run;
-        run += v[u];
-      }
-  }
-  if (t == 1023) {
-    out[n] = incl;
-    pair_start[n_atoms] = incl;
   }
 }
 
@@ -352,145 +312,136 @@ __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, 
   }
 }
 
-// Workgroup packing of the angular kernels on the device: runs of whole centres with <= cap pairs and
-// <= kMaxCentersPerBlock centres, greedy inside chunks of 32 consecutive centres (a chunk end closes
-// a run), one lane per chunk walking the chunk's offsets in LDS; the runs of all chunks are laid
-// out by a prefix sum. One workgroup, rounds of 8192 centres.
-constexpr int kPackChunk = 32, kPackRound = 8192;
-
-struct PackArgs {
-  int cap;
-  const int32_t *pair_start;
-  int32_t *blk_center, *n_blk_out;
-  int max_blk;
-};
-
-// body: one workgroup of 256 or 1024 lanes (lane t walks centres [32 t, 32 t + 32) of a round)
-__device__ __forceinline__ void pack_blocks_body(int n_atoms, const PackArgs &pk) {
-  __shared__ int ps[kPackRound + 1];
-  __shared__ int cnt[16];
-  __shared__ int total;
-  const int t = threadIdx.x, T = blockDim.x;
-  const int cap = pk.cap, max_blk = pk.max_blk;
-  const int32_t *pair_start = pk.pair_start;
-  int32_t *blk_center = pk.blk_center;
-  int base = 0;
-  for (int r0 = 0; r0 < n_atoms; r0 += kPackRound) {
-    const int nr = min(kPackRound, n_atoms - r0);
-    for (int idx = t; idx <= nr; idx += 8 * T) {  // eight loads in flight per lane
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pair_start[r0 + min(idx + u * T, nr)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (idx + u * T <= nr) ps[idx + u * T] = v[u];
-    }
-    __syncthreads();
-    const int lo = min(nr, t * kPackChunk), hi = min(nr, lo + kPackChunk);
-    int nb = 0, load = 0, nc = 0;
-    for (int i = lo; i < hi; ++i) {
-      const int k = ps[i + 1] - ps[i];
-      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
-        ++nb;
-        load = 0;
-        nc = 0;
-      }
-      load += k;
-      ++nc;
-    }
-    const int incl = block_scan_1024(nb, cnt);
-    int slot = base + incl - nb;
-    load = 0;
-    nc = 0;
-    for (int i = lo; i < hi; ++i) {
-      const int k = ps[i + 1] - ps[i];
-      if (i == lo || load + k > cap || nc >= kMaxCentersPerBlock) {
-        if (slot < max_blk) blk_center[slot] = r0 + i;
-        ++slot;
-        load = 0;
-        nc = 0;
-      }
-      load += k;
-      ++nc;
-    }
-    if (t == T - 1) total = base + incl;
-    __syncthreads();
-    base = total;
-    __syncthreads();
-  }
-  if (t == 0) {
-    const int nb = min(base, max_blk);
-    blk_center[nb] = n_atoms;
-    *pk.n_blk_out = nb;
-  }
-}
-
 // ---- MD loop: the exact list of a step from the resident skin list ------------------------------
 // The resident list covers rmax + skin (ta_set_skin); while it is valid, the pairs inside rmax at the
-// CURRENT positions are a subset of it. These kernels extract that subset, in the same order and
-// with the same layout as the builder's output (sorted by centre and neighbour species, reverse
-// index, workgroup packing), so that the evaluation kernels run on an exact list and never see the
-// skin: same traversal twice (count, fill) with ballots, as pairs_kernel.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void filter_kernel(int n_atoms, int nel, double rmax, const double *pos,
-                                                        const double *cells, const int32_t *frame_of_atom,
-                                                        const int32_t *seg_super, const int32_t *pj_super,
-                                                        const int32_t *ps_super, int32_t *counts,
-                                                        const int32_t *seg_exact, int32_t *pi_out,
-                                                        int32_t *pj_out, int32_t *ps_out, int32_t *map,
-                                                        unsigned long long *stats_zero, PackArgs pk) {
-  // side jobs that saved two launches on the MD step: the counting pass clears the statistics words
-  // the scan / finish_starts kernels behind it accumulate into; the filling pass has one extra
-  // workgroup (the last) that packs the angular kernels' workgroups from the new pair_start
-  if (MODE == 0 && stats_zero && blockIdx.x == 0 && threadIdx.x < 8) stats_zero[threadIdx.x] = 0ull;
-  if (MODE == 1 && pk.blk_center && blockIdx.x == gridDim.x - 1) {
-    pack_blocks_body(n_atoms, pk);
-    return;
+// CURRENT positions are a subset of it. These kernels extract that subset with the layout of the
+// builder's output (sorted by centre and neighbour species, reverse index, workgroup packing), so that
+// the evaluation kernels run on an exact list and never see the skin.
+//
+// Round 3: TWO launches instead of four (count, scan, fill + pack, reverse: 37 us of a 200 us MD step).
+// A global prefix sum over the centres is what forced count and fill apart, so there is none: every
+// GROUP of 16 consecutive centres (one 1024-lane workgroup, a wavefront per centre) compacts its pairs
+// in place, starting at the group's own offset in the skin list; inside a group the centres are
+// contiguous, between groups a few slots stay unused, and the kernels take the end of a centre from
+// `pair_stop` (DeviceBatch) instead of the next centre's start. (Leaving the 32-byte pair records
+// {D, r^2} of the kept pairs as well, for the forward kernel's staging to read instead of gathering
+// positions, shifts and cells again, was measured and bought nothing: 125.9 against 120.7 us per
+// evaluation with / without, MD step 0.186 against 0.184 ms; removed.)
+constexpr int kFilterGroup = 16;
+constexpr int kFilterMaxEl = 8;
+static_assert(kFilterGroup == kMaxCentersPerBlock, "a run of the angular kernels never crosses a group");
+
+__global__ __launch_bounds__(64 * kFilterGroup) void filter_group_kernel(
+    int n_atoms, int nel, double rmax, const double *pos, const double *cells,
+    const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super, const int32_t *pj_super,
+    const int32_t *ps_super, int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out,
+    int32_t *pj_out, int32_t *ps_out, int32_t *map, int cap, int32_t *blk_center) {
+  __shared__ int cnt[kFilterGroup][kFilterMaxEl + 1];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = blockIdx.x * kFilterGroup;
+  const int i = i0 + w;
+  const bool act = i < n_atoms;
+  double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ri[3] = {0, 0, 0};
+  const int32_t *seg = seg_super + (size_t)(act ? i : 0) * (nel + 1);
+  if (act) {
+    const double *hc = cells + 9 * (size_t)frame_of_atom[i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = hc[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ri[k] = pos[3 * (size_t)i + k];
   }
-  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (i >= n_atoms) return;
-  const double *h = cells + 9 * (size_t)frame_of_atom[i];
-  const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
-  const int32_t *seg = seg_super + (size_t)i * (nel + 1);
-  for (int s = 0; s < nel; ++s) {
+  // one pair of the skin list: D, and whether it is inside rmax (the builder's test, pairs_kernel)
+  auto probe = [&](int q, int &j, int (&S)[3], double (&D)[3]) {
+    j = pj_super[q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[c] = ps_super[3 * (size_t)q + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      D[c] = pos[3 * (size_t)j + c] - ri[c] + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+    return sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]) < rmax;
+  };
+  for (int s = 0; s < nel && act; ++s) {
     int running = 0;
     for (int q0 = seg[s]; q0 < seg[s + 1]; q0 += 64) {
       const int q = q0 + lane;
       bool valid = false;
-      int j = 0, Sx = 0, Sy = 0, Sz = 0;
       if (q < seg[s + 1]) {
-        j = pj_super[q];
-        Sx = ps_super[3 * (size_t)q];
-        Sy = ps_super[3 * (size_t)q + 1];
-        Sz = ps_super[3 * (size_t)q + 2];
-        const double Dx = pos[3 * (size_t)j] - rix + (Sx * h[0] + Sy * h[3] + Sz * h[6]);
-        const double Dy = pos[3 * (size_t)j + 1] - riy + (Sx * h[1] + Sy * h[4] + Sz * h[7]);
-        const double Dz = pos[3 * (size_t)j + 2] - riz + (Sx * h[2] + Sy * h[5] + Sz * h[8]);
-        valid = sqrt(Dx * Dx + Dy * Dy + Dz * Dz) < rmax;  // the builder's test (pairs_kernel)
+        int j, S[3];
+        double D[3];
+        valid = probe(q, j, S, D);
       }
+      running += __popcll(__ballot(valid));
+    }
+    if (lane == 0) cnt[w][s] = running;
+  }
+  if (!act && lane < nel) cnt[w][lane] = 0;
+  __syncthreads();
+  // Workgroup packing of the angular kernels (runs of whole centres with <= cap pairs), per group: a
+  // run never crosses a group (kFilterGroup = kMaxCentersPerBlock), so every group owns the 16 run slots
+  // [16 g, 16 g + 16); slots it does not need are empty runs (first centre = last), whose workgroups
+  // leave at once. No prefix sum over the batch, no separate packing launch.
+  if (blk_center && threadIdx.x == 0) {
+    int slot = i0, load = 0, nc = 0;
+    const int iend = min(i0 + kFilterGroup, n_atoms);
+    for (int k = 0; k < kFilterGroup && i0 + k < n_atoms; ++k) {
+      int n = 0;
+      for (int s = 0; s < nel; ++s) n += cnt[k][s];
+      if (k == 0 || load + n > cap || nc >= kMaxCentersPerBlock) {
+        blk_center[slot++] = i0 + k;
+        load = 0;
+        nc = 0;
+      }
+      load += n;
+      ++nc;
+    }
+    for (; slot < i0 + kFilterGroup; ++slot) blk_center[slot] = iend;
+    if (iend == n_atoms) blk_center[i0 + kFilterGroup] = n_atoms;  // closes the last group's last run
+  }
+  if (!act) return;
+  int off = start_super[i0];  // the group keeps its place in the skin list
+  for (int k = 0; k < w; ++k)
+    for (int s = 0; s < nel; ++s) off += cnt[k][s];
+  int32_t *sx = seg_exact + (size_t)i * (nel + 1);
+  {
+    int o = off;
+    for (int s = 0; s < nel; ++s) {
+      if (lane == 0) sx[s] = o;
+      o += cnt[w][s];
+    }
+    if (lane == 0) {
+      sx[nel] = o;
+      pair_start[i] = off;
+      pair_stop[i] = o;
+    }
+  }
+  for (int s = 0; s < nel; ++s) {
+    int running = off;
+    off += cnt[w][s];
+    for (int q0 = seg[s]; q0 < seg[s + 1]; q0 += 64) {
+      const int q = q0 + lane;
+      bool valid = false;
+      int j = 0, S[3] = {0, 0, 0};
+      double D[3] = {0, 0, 0};
+      if (q < seg[s + 1]) valid = probe(q, j, S, D);
       const unsigned long long m = __ballot(valid);
-      if (MODE == 1 && q < seg[s + 1]) {
+      if (q < seg[s + 1]) {
         int slot = -1;
         if (valid) {
-          slot = seg_exact[(size_t)i * (nel + 1) + s] + running + __popcll(m & ((1ull << lane) - 1ull));
+          slot = running + __popcll(m & ((1ull << lane) - 1ull));
           pi_out[slot] = i;
           pj_out[slot] = j;
-          ps_out[3 * (size_t)slot] = Sx;
-          ps_out[3 * (size_t)slot + 1] = Sy;
-          ps_out[3 * (size_t)slot + 2] = Sz;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ps_out[3 * (size_t)slot + c] = S[c];
         }
         map[q] = slot;
       }
       running += __popcll(m);
     }
-    if (MODE == 0 && lane == 0) counts[(size_t)i * (nel + 1) + s] = running;
   }
-  if (MODE == 0 && lane == 0) counts[(size_t)i * (nel + 1) + nel] = 0;
 }
 
-// reverse index of the exact list through the map (a pair and its reverse have the same length, so
-// both are inside rmax or neither is)
+// second launch: the reverse index of the exact list through the map (a pair and its reverse have the
+// same length, so both are inside rmax or neither is)
 __global__ __launch_bounds__(kBlock) void filter_rev_kernel(int64_t n_super, const int32_t *rev_super,
                                                             const int32_t *map, int32_t *rev_out) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -606,29 +557,24 @@ void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *p
 }
 
 // Exact list of the current positions out of the resident skin list (all device, no host round trip):
-// exact (i, j, S, rev), pair_start, seg_start; workgroup packing for the angular kernels when
-// `blk_center` is given. `seg_exact` doubles as the scan's output; `counts`, `map` are work buffers.
+// exact (i, j, S, rev), pair_start / pair_stop, seg_start, and the
+// workgroup packing for the angular kernels when `blk_center` is given ([nl_filter_blocks(n_atoms) + 1]
+// entries; the grid of those kernels is nl_filter_blocks(n_atoms)). `map` is a work buffer.
+int nl_filter_blocks(int n_atoms) { return (int)nblk(n_atoms, kFilterGroup) * kFilterGroup; }
+
 void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double *pos, const double *cells,
-               const int32_t *frame_of_atom, const int32_t *seg_super, const int32_t *pj_super,
-               const int32_t *ps_super, const int32_t *rev_super, int32_t *counts, int32_t *map,
-               int32_t *seg_exact, int32_t *pair_start, int32_t *pi_out, int32_t *pj_out, int32_t *ps_out,
-               int32_t *rev_out, unsigned long long *stats, int cap, int32_t *blk_center, int32_t *n_blk_dev,
-               int max_blk, hipStream_t s) {
+               const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super,
+               const int32_t *pj_super, const int32_t *ps_super, const int32_t *rev_super, int32_t *map,
+               int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out, int32_t *pj_out,
+               int32_t *ps_out, int32_t *rev_out, int cap, int32_t *blk_center, hipStream_t s) {
   if (n_atoms == 0) return;
-  const dim3 agrid(nblk((int64_t)n_atoms * 64, kBlock));
-  PackArgs none{};
-  hipLaunchKernelGGL(filter_kernel<0>, agrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
-                     seg_super, pj_super, ps_super, counts, (const int32_t *)nullptr, (int32_t *)nullptr,
-                     (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, stats, none);
-  hipLaunchKernelGGL(scan_starts_kernel, dim3(1), dim3(1024), 0, s, n_atoms, nel, counts, seg_exact, pair_start);
-  const PackArgs pk{cap, pair_start, blk_center, n_blk_dev, max_blk};
-  const dim3 fgrid(agrid.x + (blk_center ? 1u : 0u));
-  hipLaunchKernelGGL(filter_kernel<1>, fgrid, dim3(kBlock), 0, s, n_atoms, nel, rmax, pos, cells, frame_of_atom,
-                     seg_super, pj_super, ps_super, (int32_t *)nullptr, seg_exact, pi_out, pj_out, ps_out, map,
-                     (unsigned long long *)nullptr, pk);
+  if (nel > kFilterMaxEl) throw std::domain_error("the MD-step list filter handles at most 8 elements");
+  hipLaunchKernelGGL(filter_group_kernel, dim3(nblk(n_atoms, kFilterGroup)), dim3(64 * kFilterGroup), 0, s, n_atoms,
+                     nel, rmax, pos, cells, frame_of_atom, start_super, seg_super, pj_super, ps_super, seg_exact,
+                     pair_start, pair_stop, pi_out, pj_out, ps_out, map, cap, blk_center);
   if (n_super > 0)
-    hipLaunchKernelGGL(filter_rev_kernel, dim3(nblk(n_super, kBlock)), dim3(kBlock), 0, s, n_super, rev_super,
-                       map, rev_out);
+    hipLaunchKernelGGL(filter_rev_kernel, dim3(nblk(n_super, kBlock)), dim3(kBlock), 0, s, n_super, rev_super, map,
+                       rev_out);
 }
 
 }  // namespace ta
