@@ -387,6 +387,7 @@ constexpr size_t kWaveLdsLimit = 150 * 1024;
 // hidden layers when the four-wavefront latency kernel applies (same shapes as the one-wavefront
 // kernel, launches BELOW its tile threshold), else 0
 int mlp_quad_shape(const MlpDev &mlp, int n_tiles);
+int mlp_quad_tiles(const MlpDev &mlp);
 
 // ---- four wavefronts per 16 atoms, transposed GEMMs, one barrier per layer ------------------------
 // The LATENCY kernel for launches of few tiles (one frame: 250 tiles on 256 CUs). Same transposed
@@ -399,22 +400,29 @@ int mlp_quad_shape(const MlpDev &mlp, int n_tiles);
 // Activation derivatives of a wavefront's own tile stay in its registers for the backward sweep.
 // Weights are A operands read from global memory (L2 hits), first layer from G directly, scalar
 // output layer on the VALU. Shapes as for the one-wavefront kernel; one model per launch.
+// NT = 16-unit tiles per hidden layer = wavefronts per workgroup: 4 (hidden widths up to 64) or 8 (up to
+// 128, the 2 x 128 networks of the Ni-Mo benchmark, whose generic tile kernel runs at a quarter of the
+// matrix rate: 30 us for 245 tiles).
+template <int NT>
 struct QuadLds {
-  double h[2][16 * kWaveNT * kMlpRows];   // activations / dz, ping-pong: [unit][atom]
-  double ypart[4][kMlpRows];
+  double h[2][16 * NT * kMlpRows];   // activations / dz, ping-pong: [unit][atom]
+  double ypart[NT][kMlpRows];
 };
 
-// A operands of one GEMM phase of a wavefront's tile (at most 16 k-steps), fetched BEFORE the barrier
+// A operands of one GEMM phase of a wavefront's tile (at most 4 NT k-steps), fetched BEFORE the barrier
 // that precedes the phase: the L2 round trip overlaps the previous phase's tail and the barrier wait
-__device__ __forceinline__ void quad_fetch(double (&w)[16], const double *wcol, size_t stride, int n_tiles) {
+template <int NT>
+__device__ __forceinline__ void quad_fetch(double (&w)[4 * NT], const double *wcol, size_t stride, int n_tiles) {
 #pragma unroll
-  for (int t = 0; t < kWaveNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[4 * t + r] = t < n_tiles ? wcol[(size_t)(16 * t + 4 * r) * stride] : 0.0;
 }
-__device__ __forceinline__ mlp_f64x4 quad_gemm(const double (&w)[16], const double *bin, int n_tiles, mlp_f64x4 acc) {
+template <int NT>
+__device__ __forceinline__ mlp_f64x4 quad_gemm(const double (&w)[4 * NT], const double *bin, int n_tiles,
+                                               mlp_f64x4 acc) {
 #pragma unroll
-  for (int t = 0; t < kWaveNT; ++t)
+  for (int t = 0; t < NT; ++t)
     if (t < n_tiles) {
       double bq[4];
 #pragma unroll
@@ -425,13 +433,12 @@ __device__ __forceinline__ mlp_f64x4 quad_gemm(const double (&w)[16], const doub
   return acc;
 }
 
-template <int LH>
-__global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int ndim, const int32_t *atoms,
-                                                       int n_atoms, const double *__restrict__ G,
-                                                       double *__restrict__ dEdG, double *__restrict__ eatom) {
-  __shared__ QuadLds L;
+template <int LH, int NT>
+__device__ __forceinline__ void mlp_quad_body(const MlpDev &mlp, QuadLds<NT> &L, int act, int ndim,
+                                              const int32_t *atoms, int n_atoms, int a0,
+                                              const double *__restrict__ G, double *__restrict__ dEdG,
+                                              double *__restrict__ eatom) {
   const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
-  const int a0 = (int)blockIdx.x * kMlpRows;
   const bool valid = a0 + m < n_atoms;
   const int atom = atoms[valid ? a0 + m : a0];
   mlp_f64x4 dh[LH];  // act'(z) of this wavefront's tile in every hidden layer
@@ -465,24 +472,24 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
       }
     }
   }
-  double wnext[16];  // A operands of the next GEMM phase, in flight across the barrier
+  double wnext[4 * NT];  // A operands of the next GEMM phase, in flight across the barrier
   mlp_f64x4 bnext = {0.0, 0.0, 0.0, 0.0};
   __syncthreads();
   if (LH > 1) {
     const MlpLayerDev &nx = mlp.layer[1];
     const int tile = nt < nx.np / 16 ? nt : 0;
-    quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
+    quad_fetch<NT>(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
 #pragma unroll
     for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
   } else {
     const MlpLayerDev &l0 = mlp.layer[0];
-    quad_fetch(wnext, l0.wt + (size_t)kq * l0.kp + (16 * nt < ndim ? 16 * nt : 0) + m, l0.kp, l0.np / 16);
+    quad_fetch<NT>(wnext, l0.wt + (size_t)kq * l0.kp + (16 * nt < ndim ? 16 * nt : 0) + m, l0.kp, l0.np / 16);
   }
 #pragma unroll
   for (int l = 1; l < LH; ++l) {
     const MlpLayerDev &ly = mlp.layer[l];
     mlp_f64x4 acc = bnext;
-    if (nt < ly.np / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.kp / 16, acc);
+    if (nt < ly.np / 16) acc = quad_gemm<NT>(wnext, L.h[cur] + kq * kMlpRows + m, ly.kp / 16, acc);
     if (nt < ly.np / 16) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -498,12 +505,12 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     if (l + 1 < LH) {
       const MlpLayerDev &nx = mlp.layer[l + 1];
       const int tile = nt < nx.np / 16 ? nt : 0;
-      quad_fetch(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
+      quad_fetch<NT>(wnext, nx.w + (size_t)kq * nx.np + 16 * tile + m, nx.np, nx.kp / 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) bnext[r] = nx.b[16 * tile + kq + 4 * r];
     } else {
       const int tile = nt < ly.kp / 16 ? nt : 0;
-      quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + 16 * tile + m, ly.kp, ly.np / 16);
+      quad_fetch<NT>(wnext, ly.wt + (size_t)kq * ly.kp + 16 * tile + m, ly.kp, ly.np / 16);
     }
   }
   // scalar output layer: y = b + sum_k h[k] w[k][0]; dz of the last hidden layer = act' * w[k][0]
@@ -524,15 +531,23 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     if (kq == 0) L.ypart[nt][m] = y;
     cur ^= 1;  // h[cur] now holds dz of the last hidden layer
     __syncthreads();
-    if (nt == 0 && kq == 0 && valid)
-      eatom[atom] = ((L.ypart[0][m] + L.ypart[1][m]) + (L.ypart[2][m] + L.ypart[3][m])) + lo.b[0];
+    if (nt == 0 && kq == 0 && valid) {
+      double y4[NT / 4];  // fixed order: pairs of pairs, then the quartets in turn
+#pragma unroll
+      for (int q = 0; q < NT / 4; ++q)
+        y4[q] = (L.ypart[4 * q][m] + L.ypart[4 * q + 1][m]) + (L.ypart[4 * q + 2][m] + L.ypart[4 * q + 3][m]);
+      double ys = y4[0];
+#pragma unroll
+      for (int q = 1; q < NT / 4; ++q) ys += y4[q];
+      eatom[atom] = ys + lo.b[0];
+    }
   }
   // ---- backward: delta_{l-1}^T = W_l . dz_l^T, dz_{l-1} = delta_{l-1} * act'(z_{l-1}) ----
 #pragma unroll
   for (int l = LH - 1; l >= 1; --l) {
     const MlpLayerDev &ly = mlp.layer[l];
     mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    if (nt < ly.kp / 16) acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
+    if (nt < ly.kp / 16) acc = quad_gemm<NT>(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
     if (nt < ly.kp / 16) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) L.h[cur ^ 1][(16 * nt + kq + 4 * r) * kMlpRows + m] = acc[r] * dh[l - 1][r];
@@ -542,17 +557,17 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
     {  // weights of the next backward GEMM (layer l - 1, or the final dE/dG tiles of layer 0)
       const MlpLayerDev &nx = mlp.layer[l - 1];
       const int col = l > 1 ? (nt < nx.kp / 16 ? 16 * nt : 0) : (16 * nt < ndim ? 16 * nt : 0);
-      quad_fetch(wnext, nx.wt + (size_t)kq * nx.kp + col + m, nx.kp, nx.np / 16);
+      quad_fetch<NT>(wnext, nx.wt + (size_t)kq * nx.kp + col + m, nx.kp, nx.np / 16);
     }
   }
   {
     const MlpLayerDev &ly = mlp.layer[0];
     // dE/dG: 16 input channels per tile, tiles dealt to the wavefronts
-    for (int j0 = 16 * nt; j0 < ndim; j0 += 64) {
+    for (int j0 = 16 * nt; j0 < ndim; j0 += 16 * NT) {
       mlp_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-      // (the first tile's operands were fetched before the barrier; further tiles, D > 64, stream)
-      if (j0 != 16 * nt) quad_fetch(wnext, ly.wt + (size_t)kq * ly.kp + j0 + m, ly.kp, ly.np / 16);
-      acc = quad_gemm(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
+      // (the first tile's operands were fetched before the barrier; further tiles, D > 16 NT, stream)
+      if (j0 != 16 * nt) quad_fetch<NT>(wnext, ly.wt + (size_t)kq * ly.kp + j0 + m, ly.kp, ly.np / 16);
+      acc = quad_gemm<NT>(wnext, L.h[cur] + kq * kMlpRows + m, ly.np / 16, acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + kq + 4 * r;
@@ -567,6 +582,30 @@ __global__ __launch_bounds__(256) void mlp_quad_kernel(MlpDev mlp, int act, int 
       }
     }
   }
+}
+
+
+template <int LH, int NT>
+__global__ __launch_bounds__(64 * NT) void mlp_quad_kernel(MlpDev mlp, int act, int ndim, const int32_t *atoms,
+                                                           int n_atoms, const double *__restrict__ G,
+                                                           double *__restrict__ dEdG, double *__restrict__ eatom) {
+  __shared__ QuadLds<NT> L;
+  mlp_quad_body<LH, NT>(mlp, L, act, ndim, atoms, n_atoms, (int)blockIdx.x * kMlpRows, G, dEdG, eatom);
+}
+
+// every element of an alloy in ONE launch: blocks laid out element after element (as mlp_all_kernel)
+template <int LH, int NT>
+__global__ __launch_bounds__(64 * NT) void mlp_quad_all_kernel(const MlpDev *__restrict__ mlps, MlpTiles tiles,
+                                                               int act, int ndim, const int32_t *atoms,
+                                                               const double *__restrict__ G,
+                                                               double *__restrict__ dEdG,
+                                                               double *__restrict__ eatom) {
+  __shared__ QuadLds<NT> L;
+  int e = 0;
+  while (e + 1 < tiles.nel && (int)blockIdx.x >= tiles.tile_start[e + 1]) ++e;
+  mlp_quad_body<LH, NT>(mlps[e], L, act, ndim, atoms + tiles.elem_start[e],
+                        tiles.elem_start[e + 1] - tiles.elem_start[e],
+                        ((int)blockIdx.x - tiles.tile_start[e]) * kMlpRows, G, dEdG, eatom);
 }
 
 // The one-wavefront kernel is the THROUGHPUT kernel: 4000 tiles (16 frames of 4000 atoms) take 66 us
@@ -594,22 +633,36 @@ int mlp_wave_shape(const MlpDev &mlp, int n_tiles) {
 // Below one tile per CU the generic tile kernel is still the faster one in the angular pipeline
 // (4000-atom frame, 250 tiles: 18.2-18.9 us against 19.7-20.3 us for this kernel, same session),
 // although this kernel wins the isolated comparison on G2-only models (13.8 against 17.7 us); from
-// three frames on it is ahead in both (7.1 against 7.7 us per frame).
+// three frames on it is ahead in both (7.1 against 7.7 us per frame). Hidden layers wider than 64
+// (NT = 8) take this kernel from the first tile: there the generic kernel is the slow one.
 constexpr int kQuadMinTiles = 257;
+constexpr int kQuadMaxNT = 8;
 
-int mlp_quad_shape(const MlpDev &mlp, int n_tiles) {
-  if (getenv("TA_MLP_TILE_KERNEL") || getenv("TA_MLP_WAVE_KERNEL")) return 0;
-  if ((n_tiles >= kWaveMinTiles || n_tiles < kQuadMinTiles) && !getenv("TA_MLP_QUAD_KERNEL")) return 0;
+// tiles per hidden layer this kernel would run with (4 or 8), 0 = shape not covered
+int mlp_quad_tiles(const MlpDev &mlp) {
   const int lh = mlp.n_layers - 1;
   if (lh < 1 || lh > kWaveMaxHidden) return 0;
+  int widest = 0;
   for (int l = 0; l < lh; ++l) {
     const MlpLayerDev &ly = mlp.layer[l];
-    if (ly.np > 16 * kWaveNT || ly.res || !ly.act) return 0;
+    if (ly.np > 16 * kQuadMaxNT || ly.res || !ly.act) return 0;
     if (l > 0 && ly.kp != mlp.layer[l - 1].np) return 0;
+    widest = std::max(widest, ly.np);
   }
   const MlpLayerDev &lo = mlp.layer[lh];
   if (lo.n != 1 || lo.act || lo.res || lo.kp != mlp.layer[lh - 1].np) return 0;
-  return lh;
+  return widest <= 16 * kWaveNT ? kWaveNT : kQuadMaxNT;
+}
+
+// number of hidden layers when the four / eight-wavefront kernel applies to `n_tiles` tiles, else 0
+int mlp_quad_shape(const MlpDev &mlp, int n_tiles) {
+  if (getenv("TA_MLP_TILE_KERNEL") || getenv("TA_MLP_WAVE_KERNEL")) return 0;
+  const int nt = mlp_quad_tiles(mlp);
+  if (!nt) return 0;
+  if (getenv("TA_MLP_QUAD_KERNEL")) return mlp.n_layers - 1;
+  if (nt == kWaveNT && (n_tiles >= kWaveMinTiles || n_tiles < kQuadMinTiles)) return 0;
+  if (nt == kQuadMaxNT && n_tiles >= 4 * kWaveMinTiles) return 0;  // (no one-wavefront kernel at this width)
+  return mlp.n_layers - 1;
 }
 
 // more than 64 KB of dynamic LDS needs the attribute; set once per kernel and device (the call is
@@ -635,15 +688,20 @@ void launch_mlp_impl(const MlpDev &mlp, int activation, int ndim, const int32_t 
   if (n_atoms == 0) return;
   if (const int lh = mlp_quad_shape(mlp, (n_atoms + kMlpRows - 1) / kMlpRows)) {
     const unsigned qblocks = (unsigned)((n_atoms + kMlpRows - 1) / kMlpRows);
-    if (lh == 1)
-      hipLaunchKernelGGL(mlp_quad_kernel<1>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
-                         b.G, b.dEdG, b.eatom);
-    else if (lh == 2)
-      hipLaunchKernelGGL(mlp_quad_kernel<2>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
-                         b.G, b.dEdG, b.eatom);
-    else
-      hipLaunchKernelGGL(mlp_quad_kernel<3>, dim3(qblocks), dim3(256), 0, s, mlp, activation, ndim, atoms, n_atoms,
-                         b.G, b.dEdG, b.eatom);
+    const int nt = mlp_quad_tiles(mlp);
+#define TA_QUAD(LH, NT)                                                                                       \
+  hipLaunchKernelGGL((mlp_quad_kernel<LH, NT>), dim3(qblocks), dim3(64 * NT), 0, s, mlp, activation, ndim, atoms, \
+                     n_atoms, b.G, b.dEdG, b.eatom)
+    if (nt == kWaveNT) {
+      if (lh == 1) TA_QUAD(1, 4);
+      else if (lh == 2) TA_QUAD(2, 4);
+      else TA_QUAD(3, 4);
+    } else {
+      if (lh == 1) TA_QUAD(1, 8);
+      else if (lh == 2) TA_QUAD(2, 8);
+      else TA_QUAD(3, 8);
+    }
+#undef TA_QUAD
     return;
   }
   if (const int lh = mlp_wave_shape(mlp, (n_atoms + kMlpRows - 1) / kMlpRows)) {
@@ -711,6 +769,28 @@ void launch_mlp_all(const MlpDev *mlps_dev, const MlpDev *mlps_host, int nel, in
   t.elem_start[nel] = b.elem_start[nel];
   for (int e = nel + 1; e <= kMaxElements; ++e) t.tile_start[e] = t.elem_start[e] = 0;
   if (blocks == 0) return;
+  // every element's network fits the four / eight-wavefront kernel (same depth and tile count)
+  {
+    int qlh = mlp_quad_shape(mlps_host[0], blocks), qnt = mlp_quad_tiles(mlps_host[0]);
+    for (int e = 1; e < nel; ++e)
+      if (mlp_quad_shape(mlps_host[e], blocks) != qlh || mlp_quad_tiles(mlps_host[e]) != qnt) qlh = 0;
+    if (qlh) {
+#define TA_QUAD_ALL(LH, NT)                                                                                \
+  hipLaunchKernelGGL((mlp_quad_all_kernel<LH, NT>), dim3((unsigned)blocks), dim3(64 * NT), 0, s, mlps_dev, t, \
+                     activation, ndim, b.elem_atoms, b.G, b.dEdG, b.eatom)
+      if (qnt == kWaveNT) {
+        if (qlh == 1) TA_QUAD_ALL(1, 4);
+        else if (qlh == 2) TA_QUAD_ALL(2, 4);
+        else TA_QUAD_ALL(3, 4);
+      } else {
+        if (qlh == 1) TA_QUAD_ALL(1, 8);
+        else if (qlh == 2) TA_QUAD_ALL(2, 8);
+        else TA_QUAD_ALL(3, 8);
+      }
+#undef TA_QUAD_ALL
+      return;
+    }
+  }
   // every element's network has the same one-wavefront shape: one grid row per element
   int lh = mlp_wave_shape(mlps_host[0], blocks);
   size_t wlds = 0;
