@@ -28,7 +28,7 @@ def main(out):
         print(f"{k:50s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {sum(v)/1e6:10.3f}  {100*sum(v)/tot:5.1f}%")
     # PMC passes -> per-kernel average counter value
     counters = defaultdict(lambda: defaultdict(list))
-    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_grbm", "pmc_fetch", "pmc_write"):
         for f in find(os.path.join(out, sub), "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -256,8 +256,91 @@ def stress_loss(predictions, labels, method="rmse", weight=1.0):
     return float(weight * loss), mae, weight * d
 
 
+GPA = 1.0 / 160.21766208  # ase.units.GPa in eV/A^3 (the reference's pressure unit, nn/basic.py:403-405)
+
+
+def pressure_loss(predictions, labels, method="rmse", weight=1.0):
+    """(loss, mae, dloss/dP [B]) of nn/losses.py:459-505 (`get_pressure_loss`) on total pressures
+    in GPa: sqrt(mean(dP^2) + eps) or mean log-cosh of (labels - predictions); `rrmse` is refused as
+    the reference asserts."""
+    y = np.asarray(predictions, dtype=np.float64).ravel()
+    x = np.asarray(labels, dtype=np.float64).ravel()
+    diff = y - x
+    mae = float(np.mean(np.abs(diff)))
+    if method == "rmse":
+        loss = np.sqrt(float(np.mean(diff * diff)) + np.finfo(np.float64).eps)
+        d = diff / (diff.size * loss)
+    elif method == "logcosh":
+        e = x - y
+        loss = float(np.mean(e + np.logaddexp(0.0, -2.0 * e) - np.log(2.0)))
+        d = -np.tanh(e) / diff.size
+    else:
+        raise ValueError(f"loss method '{method}' is not available for the pressure loss")
+    return float(weight * loss), mae, weight * d
+
+
+def relative_forces_loss(predictions, labels, weight=1.0):
+    """(loss, None, [dloss/dF per frame]) of `_get_relative_rmse_loss` (nn/losses.py:53-68), the
+    `rrmse` method of the force loss: mean over the atoms of |F_label - F_pred| / |F_label|."""
+    P = np.concatenate([np.asarray(p, dtype=np.float64) for p in predictions])
+    L = np.concatenate([np.asarray(l, dtype=np.float64) for l in labels])
+    diff = L - P
+    upper = np.linalg.norm(diff, axis=1)
+    lower = np.linalg.norm(L, axis=1)
+    n = len(P)
+    loss = float(np.mean(upper / lower))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = np.where(upper[:, None] > 0.0, -diff / (upper * lower * n)[:, None], 0.0)
+    out, k = [], 0
+    for p in predictions:
+        out.append(weight * g[k:k + len(p)])
+        k += len(p)
+    return float(weight * loss), None, out
+
+
+def l2_regularization_loss(nn, theta, l2_weight, weight=0.01, step=0, decayed=True, decay_rate=0.99,
+                           decay_steps=1000):
+    """(loss, dloss/dtheta) of nn/losses.py:507-551 + the regularisers `convolution1x1` attaches
+    (convolutional.py:207-290): `l2_regularizer(l2_weight)` = l2_weight sum(w^2) / 2 on the kernel AND
+    the bias of every hidden layer and on the kernel (not the bias) of the output layer; the sum is
+    scaled by `weight`, exponentially decayed as weight * decay_rate ** (step / decay_steps) when
+    `decayed` (tf.train.exponential_decay, no staircase). `theta` in the C ABI's flat layout."""
+    theta = np.asarray(theta, dtype=np.float64)
+    sel = np.zeros_like(theta)
+    k = 0
+    for box, key in _networks(nn):
+        layers = box[key]
+        for l, (w, b) in enumerate(layers):
+            shape = np.shape(w)
+            n = shape[0] * shape[1]
+            sel[k:k + n] = 1.0
+            k += n
+            if b is not None and l < len(layers) - 1:
+                sel[k:k + shape[1]] = 1.0
+            k += shape[1]
+    lam = float(weight) * (decay_rate ** (step / decay_steps) if decayed else 1.0)
+    l2 = 0.5 * l2_weight * float(np.sum(sel * theta * theta))
+    return lam * l2, lam * l2_weight * sel * theta
+
+
+def loss_weight_at(weight, step=0, max_train_steps=None, logscale=True):
+    """`get_static_or_dyn_weight_tensor` (nn/losses.py:171-201): a float is the weight; a pair
+    (w0, w1) moves from w0 to w1 over `max_train_steps` steps, linearly in log10 when `logscale`
+    (the reference's default, `_LossOptions.logscaled_dynamic_weight`), else linearly."""
+    if isinstance(weight, (int, float)):
+        return float(weight)
+    w0, w1 = float(weight[0]), float(weight[1])
+    if max_train_steps is None:
+        raise ValueError("a dynamic loss weight needs max_train_steps")
+    if logscale:
+        l0, l1 = np.log10(w0), np.log10(w1)
+        return float(10.0 ** (l0 + (l1 - l0) / max_train_steps * step))
+    return w0 + (w1 - w0) / max_train_steps * step
+
+
 class Trainer:
-    """Energy + forces + stress loss (nn/basic.py `get_total_loss`: the sum of the weighted terms).
+    """Energy + forces + stress (+ total pressure, + L2) loss (nn/basic.py `get_total_loss`: the sum
+    of the weighted terms). Weights may be pairs (w0, w1): dynamic weights of the reference.
 
     The weight gradient of the force and stress terms needs second derivatives of the energy
     (the reference: `tf.gradients` through nn/losses.py:285-437). With u = dL/dF per atom and the
@@ -276,7 +359,9 @@ class Trainer:
     def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
                  energy_weight=1.0, forces_weight=1.0, stress_weight=1.0, method="rmse",
                  per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, analytic=None, fixed=None,
-                 **adam_kwargs):
+                 pressures=None, pressure_weight=1.0, forces_method=None, l2_weight=0.0, l2_loss_weight=0.01,
+                 l2_decayed=True, l2_decay_rate=0.99, l2_decay_steps=1000, max_train_steps=None,
+                 logscaled_dynamic_weight=True, **adam_kwargs):
         from .engine import Engine
         rank, local_rank, world = world_from_env()
         lo, hi = shard_range(len(frames), rank, world)
@@ -300,7 +385,13 @@ class Trainer:
         self.f_ref = None if forces is None else [np.asarray(f, dtype=np.float64) for f in forces[lo:hi]]
         self.s_ref = None if stresses is None else np.asarray(stresses, dtype=np.float64).reshape(-1, 6)[lo:hi]
         self.n_atoms = np.array([len(a) for a in self.frames], dtype=np.float64)
+        self.p_ref = None if pressures is None else np.asarray(pressures, dtype=np.float64).ravel()[lo:hi]
         self.weights = (energy_weight, forces_weight, stress_weight)
+        self.pressure_weight = pressure_weight
+        self.forces_method = forces_method or method   # "rrmse": relative RMSE (forces only)
+        self.l2 = dict(l2_weight=l2_weight, weight=l2_loss_weight, decayed=l2_decayed, decay_rate=l2_decay_rate,
+                       decay_steps=l2_decay_steps)
+        self.max_train_steps, self.logscale = max_train_steps, logscaled_dynamic_weight
         self.method, self.per_atom_loss, self.fd_step = method, per_atom_loss, fd_step
         if self.constants_mode:
             self.theta = nn.constants()
@@ -326,7 +417,9 @@ class Trainer:
             self._resident = self.analytic
             self._generation = eng.batch_generation
         pred_e = np.array([r["energy"] for r in res])
-        we, wf, ws = self.weights
+        step = self.opt.t
+        we, wf, ws = (loss_weight_at(w, step, self.max_train_steps, self.logscale) for w in self.weights)
+        wp = loss_weight_at(self.pressure_weight, step, self.max_train_steps, self.logscale)
         terms = {}
         loss_e, mae_e, c = energy_loss(pred_e, self.e_ref, self.n_atoms, self.method, self.per_atom_loss, we)
         terms["energy"] = loss_e
@@ -336,18 +429,30 @@ class Trainer:
         Y = [np.zeros((3, 3)) for _ in self.frames]
         second = False
         if self.f_ref is not None and wf != 0.0:
-            lf, _, du = forces_loss([r["forces"] for r in res], self.f_ref, self.method, wf)
+            if self.forces_method == "rrmse":
+                lf, _, du = relative_forces_loss([r["forces"] for r in res], self.f_ref, wf)
+            else:
+                lf, _, du = forces_loss([r["forces"] for r in res], self.f_ref, self.forces_method, wf)
             terms["forces"] = lf
             u = du
             second = True
+        ds = np.zeros((len(self.frames), 6))
         if self.s_ref is not None and ws != 0.0:
-            ls, _, ds = stress_loss(np.array([r["stress"] for r in res]), self.s_ref, self.method, ws)
+            ls, _, d = stress_loss(np.array([r["stress"] for r in res]), self.s_ref, self.method, ws)
             terms["stress"] = ls
+            ds += d
+            second = True
+        if self.p_ref is not None and wp != 0.0:
+            # total pressure P = -tr(stress) / 3 / GPa (nn/basic.py:394-408): dL/dstress_aa = -dL/dP / (3 GPa)
+            lp, _, dp = pressure_loss(np.array([r["total_pressure"] for r in res]), self.p_ref, self.method, wp)
+            terms["pressure"] = lp
+            ds[:, :3] += (-dp / (3.0 * GPA))[:, None]
+            second = True
+        if ds.any():
             for k, a in enumerate(self.frames):
                 V = abs(np.linalg.det(np.asarray(a.get_cell(complete=True))))
                 xx, yy, zz, yz, xz, xy = ds[k] / V
                 Y[k] = np.array([[xx, xy / 2, xz / 2], [xy / 2, yy, yz / 2], [xz / 2, yz / 2, zz]])
-            second = True
         if self.analytic:
             dR = np.concatenate([a.positions @ Y[k] - u[k] for k, a in enumerate(self.frames)]) \
                 if self.frames else np.zeros((0, 3))
@@ -369,6 +474,11 @@ class Trainer:
                     coeff.append(sgn / (2.0 * e))
             eng.set_frames(disp)
             grad = grad + eng.energy_gradient(np.array(coeff))
+        if self.l2["l2_weight"] > 0.0 and self.l2["weight"] != 0.0 and not self.constants_mode:
+            l2, g2 = l2_regularization_loss(self.nn, self.theta, step=step, **self.l2)
+            terms["l2"] = l2
+            # every replica adds the same regulariser: the mean over ranks (step) leaves it as it is
+            grad = grad + g2
         total = float(sum(terms.values()))
         return total, terms, grad * self.mask
 

@@ -305,6 +305,34 @@ class UniversalTransformer:
         """The reference keys TF placeholders; without TF the keys are the names."""
         return self.get_np_feed_dict(atoms)
 
+    def get_placeholder_features(self) -> Dict:
+        """The reference returns the dict of `tf.placeholder`s it feeds (transformer/base.py:191,
+        created by `_initialize_placeholders`, universal.py:728-785). Without TF a placeholder is its
+        specification: the same keys in the same order, each a `Placeholder(name, dtype, shape)` with
+        `None` for a dimension that varies with the structure and the tensor name the frozen graph
+        uses (`Placeholders/<key>:0`). `get_np_feed_dict` fills exactly these keys."""
+        from collections import namedtuple
+        Placeholder = namedtuple("Placeholder", ["name", "dtype", "shape"])
+        f, i = np.dtype(np.float64), np.dtype(np.int32)
+        spec = []
+        if self._use_computed_dists:
+            spec += [("positions", f, (None, 3)), ("cell", f, (3, 3)), ("volume", f, ())]
+        spec += [("n_atoms_vap", i, ()), ("nnl_max", i, ()), ("atom_masks", f, (None,)),
+                 ("etemperature", f, ()), ("row_splits", i, (self.n_elements + 1,)),
+                 ("g2.v2g_map", i, (None, 5))]
+        if self._use_computed_dists:
+            spec += [("g2.ilist", i, (None,)), ("g2.jlist", i, (None,)), ("g2.n1", f, (None, 3))]
+        else:
+            spec += [("g2.rij", f, (4, None))]
+        if self._angular:
+            spec += [("ij2k_max", i, ()), ("g4.v2g_map", i, (None, 5))]
+            if self._use_computed_dists:
+                spec += [("g4.ilist", i, (None,)), ("g4.jlist", i, (None,)), ("g4.klist", i, (None,)),
+                         ("g4.n1", f, (None, 3)), ("g4.n2", f, (None, 3)), ("g4.n3", f, (None, 3))]
+            else:
+                spec += [("g4.rijk", f, (12, None))]
+        return {k: Placeholder(f"Placeholders/{k}:0", dt, shape) for k, dt, shape in spec}
+
     def get_constant_features(self, atoms):
         return self.get_np_feed_dict(atoms)
 

@@ -444,3 +444,50 @@ def test_trainer_shortcut_notices_a_foreign_batch(lib):
     l1, _, g1 = tr.loss_and_gradient()
     tr.close()
     assert abs(l1 - l0) < 1e-12 and np.abs(g1 - g0).max() < 1e-10
+
+
+def test_pressure_rrmse_and_l2_terms_in_the_trainer(lib):
+    """The rest of the reference's total loss through the GPU trainer: total-pressure RMSE
+    (nn/losses.py:459-505), relative RMSE of the forces (:53-68), L2 regulariser (:507-551), dynamic
+    weights (:171-201). The gradient of the sum against central differences of the ORACLE's loss."""
+    from tensoralloy_amd.train import (GPA, Trainer, energy_loss, flatten_weights, l2_regularization_loss,
+                                       loss_weight_at, pressure_loss, relative_forces_loss, unflatten_weights)
+    nn = make_nn(["Mo", "Ni"], 5.0, True, [8, 8], seed=3)
+    teacher = make_nn(["Mo", "Ni"], 5.0, True, [8, 8], seed=11)
+    frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2), seed=1), _alloy(["Ni", "Mo"], rep=(2, 2, 2), seed=2)]
+    refs = [oracle_eval(teacher, a) for a in frames]
+    e_ref = np.array([o["energy"] for o in refs])
+    f_ref = [o["forces"] for o in refs]
+    p_ref = np.array([-(o["stress_voigt"][:3].sum()) / 3.0 / GPA for o in refs])  # nn/basic.py:394-408
+    n = np.array([len(a) for a in frames], dtype=float)
+    kw = dict(forces_weight=(0.5, 5.0), pressure_weight=0.01, max_train_steps=100)
+
+    def oracle_loss(model):
+        outs = [oracle_eval(model, a) for a in frames]
+        le = energy_loss(np.array([o["energy"] for o in outs]), e_ref, n)[0]
+        lf = relative_forces_loss([o["forces"] for o in outs], f_ref, loss_weight_at((0.5, 5.0), 0, 100))[0]
+        pp = np.array([-(o["stress_voigt"][:3].sum()) / 3.0 / GPA for o in outs])
+        lp = pressure_loss(pp, p_ref, "rmse", 0.01)[0]
+        l2 = l2_regularization_loss(model, flatten_weights(model), l2_weight=0.2, weight=0.05, step=0)[0]
+        return le + lf + lp + l2
+
+    tr = Trainer(nn, frames, e_ref, f_ref, None, device=0, pressures=p_ref, forces_method="rrmse", l2_weight=0.2,
+                 l2_loss_weight=0.05, **kw)
+    total, terms, grad = tr.loss_and_gradient()
+    tr.close()
+    assert set(terms) == {"energy", "forces", "pressure", "l2"}
+    assert abs(total - oracle_loss(nn)) < 1e-9
+    theta = flatten_weights(nn)
+    d = 1e-5
+    for k in np.random.RandomState(1).choice(len(theta), 6, replace=False):
+        if tr.mask[k] == 0.0:
+            continue
+        th = theta.copy(); th[k] += d
+        nn.weights = unflatten_weights(nn, th)
+        lp = oracle_loss(nn)
+        th[k] -= 2 * d
+        nn.weights = unflatten_weights(nn, th)
+        lm = oracle_loss(nn)
+        nn.weights = unflatten_weights(nn, theta)
+        fd = (lp - lm) / (2 * d)
+        assert abs(fd - grad[k]) < 2e-6 * max(1.0, abs(fd)), (k, fd, grad[k])

@@ -258,6 +258,18 @@ def test_transformer_surface():
     a = pd3o2()
     with pytest.raises(ValueError):
         clf.species_indices(a)          # Pd / O are not in this model
+    # get_placeholder_features (transformer/base.py:191): the keys get_np_feed_dict fills, in the
+    # reference's order, with its dtypes and static shapes (universal.py:728-785)
+    for kw in (dict(angular=True), dict(angular=False), dict(angular=True, use_computed_dists=False)):
+        t = UniversalTransformer(["Pd", "O"], rcut=4.0, **kw)
+        ph = t.get_placeholder_features()
+        feed = t.get_np_feed_dict(a)
+        assert list(ph) == list(feed)
+        for k, spec in ph.items():
+            v = np.asarray(feed[k])
+            assert spec.name == f"Placeholders/{k}:0" and v.dtype == spec.dtype and v.ndim == len(spec.shape)
+            assert all(d is None or d == n for d, n in zip(spec.shape, v.shape)), (k, spec.shape, v.shape)
+    assert ph["g4.rijk"].shape == (12, None) and ph["row_splits"].shape == (3,)
 
 
 def test_model_file_roundtrip(tmp_path):

@@ -178,3 +178,64 @@ def test_oracle_second_order_gradient_against_finite_differences():
                 vals.append(J(oracle_model(nn2)))
             fd = (vals[0] - vals[1]) / 2e-5
             assert abs(fd - g[k]) < 1e-8 * max(1.0, abs(fd)), (act, k)
+
+
+def test_pressure_relative_force_l2_and_dynamic_weights():
+    """The remaining terms of the reference's total loss (nn/losses.py): total-pressure RMSE / log-cosh
+    (:459-505), relative RMSE of the forces (:53-68), the L2 regulariser with its decayed weight
+    (:507-551; which variables it covers: convolutional.py:207-290) and the dynamic loss weights
+    (:171-201): values by the formulas, derivatives by central differences."""
+    from tensoralloy_amd.train import (flatten_weights, l2_regularization_loss, loss_weight_at, pressure_loss,
+                                       relative_forces_loss)
+    from tests.helpers import make_nn
+    rng = np.random.RandomState(9)
+    h = 1e-6
+    p_pred, p_lab = rng.randn(5), rng.randn(5)
+    for method in ("rmse", "logcosh"):
+        loss, mae, d = pressure_loss(p_pred, p_lab, method, weight=3.0)
+        q = p_pred.copy(); q[2] += h
+        lp = pressure_loss(q, p_lab, method, weight=3.0)[0]
+        q[2] -= 2 * h
+        lm = pressure_loss(q, p_lab, method, weight=3.0)[0]
+        assert abs((lp - lm) / (2 * h) - d[2]) < 1e-8
+        assert abs(mae - np.mean(np.abs(p_pred - p_lab))) < 1e-15
+    assert abs(pressure_loss(p_pred, p_lab)[0] - np.sqrt(np.mean((p_pred - p_lab) ** 2) + np.finfo(float).eps)) < 1e-15
+    with pytest.raises(ValueError):
+        pressure_loss(p_pred, p_lab, "rrmse")      # the reference asserts method != rrmse
+    pred = [rng.randn(4, 3), rng.randn(6, 3)]
+    lab = [rng.randn(4, 3), rng.randn(6, 3)]
+    loss, _, d = relative_forces_loss(pred, lab, weight=0.7)
+    P, L = np.concatenate(pred), np.concatenate(lab)
+    assert abs(loss - 0.7 * np.mean(np.linalg.norm(L - P, axis=1) / np.linalg.norm(L, axis=1))) < 1e-15
+    q = [x.copy() for x in pred]; q[1][2, 0] += h
+    lp = relative_forces_loss(q, lab, weight=0.7)[0]
+    q[1][2, 0] -= 2 * h
+    lm = relative_forces_loss(q, lab, weight=0.7)[0]
+    assert abs((lp - lm) / (2 * h) - d[1][2, 0]) < 1e-8
+    # L2: kernels and biases of the hidden layers, the kernel (not the bias) of the output layer
+    nn = make_nn(["Mo", "Ni"], 5.0, False, [6, 5])
+    theta = flatten_weights(nn)
+    expect = 0.0
+    for el in nn.elements:
+        layers = nn.weights[el]
+        for l, (w, b) in enumerate(layers):
+            expect += 0.5 * np.sum(np.asarray(w) ** 2)
+            if b is not None and l < len(layers) - 1:
+                expect += 0.5 * np.sum(np.asarray(b) ** 2)
+    lam = 0.01 * 0.99 ** (250 / 1000)
+    loss, g = l2_regularization_loss(nn, theta, l2_weight=0.3, weight=0.01, step=250)
+    assert abs(loss - lam * 0.3 * expect) < 1e-15 * max(1.0, expect)
+    k = int(np.argmax(np.abs(g)))
+    t = theta.copy(); t[k] += h
+    lp = l2_regularization_loss(nn, t, l2_weight=0.3, weight=0.01, step=250)[0]
+    t[k] -= 2 * h
+    lm = l2_regularization_loss(nn, t, l2_weight=0.3, weight=0.01, step=250)[0]
+    assert abs((lp - lm) / (2 * h) - g[k]) < 1e-9
+    assert abs(l2_regularization_loss(nn, theta, 0.3, 0.01, step=250, decayed=False)[0] - 0.01 * 0.3 * expect) < 1e-15 * expect
+    # dynamic weights
+    assert loss_weight_at(2.5) == 2.5
+    assert abs(loss_weight_at((1.0, 100.0), 0, 1000) - 1.0) < 1e-12
+    assert abs(loss_weight_at((1.0, 100.0), 500, 1000) - 10.0) < 1e-12          # linear in log10
+    assert abs(loss_weight_at((1.0, 100.0), 500, 1000, logscale=False) - 50.5) < 1e-12
+    with pytest.raises(ValueError):
+        loss_weight_at((1.0, 2.0), 3)
