@@ -1021,8 +1021,9 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
     std::vector<int32_t> fill(count.begin(), count.end() - 1);
     for (size_t i = 0; i < N; ++i) elem_atoms[fill[species[i]]++] = (int32_t)i;
   }
-  // Neighbour list: on the device when every frame has >= 3 linked-cell bins along its
-  // periodic axes (ta_nlist.hip), otherwise the host builder (ta_neighbor.cpp).
+  // Neighbour list: on the device (ta_nlist.hip; cells thinner than the cutoff along a periodic axis
+  // included since round 3: one bin there, several images of it), the host builder (ta_neighbor.cpp)
+  // only for singular / incomplete cells, cells below ~1 A of height, or TA_HOST_NL=1.
   const auto t_nl = std::chrono::steady_clock::now();
   int n_bins = 0;
   bool device_nl = N > 0 && !(std::getenv("TA_HOST_NL") && std::getenv("TA_HOST_NL")[0] == '1');

@@ -182,6 +182,10 @@ struct NlGrid {  // linked-cell grid of one frame, in fractional coordinates
   int32_t pbc[3];
   int32_t bin_offset;  // first bin of this frame in the batch-wide bin arrays
   int32_t pad_;
+  // neighbouring bins looked at along each axis: offsets -m .. m (1 unless the cell is thinner than the
+  // cutoff along a periodic axis: then nb = 1 there and m = floor(rmax / height) + 1 images of the one bin)
+  int32_t m[3];
+  int32_t pad2_;
 };
 struct NlRec {  // one atom, stored in bin order
   double x, y, z;

@@ -155,78 +155,86 @@ __global__ __launch_bounds__(kBlock) void pairs_kernel(int n_atoms, int nel, dou
   const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
   const int wix = wrap[3 * (size_t)i], wiy = wrap[3 * (size_t)i + 1], wiz = wrap[3 * (size_t)i + 2];
 
-  // lane k < 27: neighbouring bin (k / 9 - 1, k / 3 % 3 - 1, k % 3 - 1)
-  int lo = 0, len = 0, code = 13;
-  if (lane < 27) {
-    int c[3] = {bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1};
-    int sh[3] = {0, 0, 0};
-    bool ok = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (c[a] < 0 || c[a] >= g.nb[a]) {
-        if (!g.pbc[a]) ok = false;
-        sh[a] = c[a] < 0 ? -1 : 1;
-        c[a] -= sh[a] * g.nb[a];
-      }
-    }
-    if (ok) {
-      const int bin = g.bin_offset + (c[0] * g.nb[1] + c[1]) * g.nb[2] + c[2];
-      lo = bin_start[bin];
-      len = bin_start[bin + 1] - lo;
-      code = (sh[0] + 1) * 9 + (sh[1] + 1) * 3 + (sh[2] + 1);
-    }
-  }
-  // exclusive prefix of len over the lanes
-  int incl = len;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  const int excl = incl - len;
-  const int total = __builtin_amdgcn_readlane(incl, 26);
-  const int delta = lo - excl;  // record index = delta[k] + flat index
-
   int running[kMaxElements];
 #pragma unroll
   for (int s = 0; s < kMaxElements; ++s) running[s] = 0;
   const int32_t *seg = seg_start ? seg_start + (size_t)i * (nel + 1) : nullptr;
 
-  for (int base = 0; base < total; base += 64) {
-    const int f = base + lane;
-    int k = 0;
+  // (bin, image shift) combinations around the centre: offsets -m .. m per axis, 27 of them unless the
+  // cell is thinner than the cutoff along a periodic axis (NlGrid::m), handled 27 at a time by lanes 0..26
+  const int e0 = 2 * g.m[0] + 1, e1 = 2 * g.m[1] + 1, e2 = 2 * g.m[2] + 1;
+  const int n_combo = e0 * e1 * e2;
+  constexpr int kSelf = 0x888;  // code of the zero shift
+  for (int c0 = 0; c0 < n_combo; c0 += 27) {
+    int lo = 0, len = 0, code = kSelf;
+    if (lane < 27 && c0 + lane < n_combo) {
+      const int id = c0 + lane;
+      int c[3] = {bx + id / (e1 * e2) - g.m[0], by + (id / e2) % e1 - g.m[1], bz + id % e2 - g.m[2]};
+      int sh[3] = {0, 0, 0};
+      bool ok = true;
 #pragma unroll
-    for (int q = 1; q < 27; ++q) k += f >= __builtin_amdgcn_readlane(excl, q);
-    const int dl = __shfl(delta, k);
-    const int cd = __shfl(code, k);
-    bool valid = false;
-    int j = 0, Sx = 0, Sy = 0, Sz = 0, sj = 0;
-    if (f < total) {
-      const NlRec r = recs[dl + f];
-      const int sx = cd / 9 - 1, sy = (cd / 3) % 3 - 1, sz = cd % 3 - 1;
-      j = r.j;
-      sj = r.sp;
-      // shift relative to the positions as given: S = s - w_j + w_i
-      Sx = sx - r.wx + wix;
-      Sy = sy - r.wy + wiy;
-      Sz = sz - r.wz + wiz;
-      const double Dx = r.x - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
-      const double Dy = r.y - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
-      const double Dz = r.z - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
-      const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
-      valid = (sqrt(r2) < rmax) && !(j == i && cd == 13);
-    }
-    for (int s = 0; s < nel; ++s) {
-      const unsigned long long m = __ballot(valid && sj == s);
-      if (MODE == 1 && valid && sj == s) {
-        const int slot = seg[s] + running[s] + __popcll(m & ((1ull << lane) - 1ull));
-        pair_i[slot] = i;
-        pair_j[slot] = j;
-        pair_shift[3 * (size_t)slot] = Sx;
-        pair_shift[3 * (size_t)slot + 1] = Sy;
-        pair_shift[3 * (size_t)slot + 2] = Sz;
+      for (int a = 0; a < 3; ++a) {
+        if (c[a] < 0 || c[a] >= g.nb[a]) {
+          if (!g.pbc[a]) ok = false;
+          // floor division: how many cells the offset leaves the grid by
+          sh[a] = c[a] >= 0 ? c[a] / g.nb[a] : -((-c[a] + g.nb[a] - 1) / g.nb[a]);
+          c[a] -= sh[a] * g.nb[a];
+        }
       }
-      running[s] += __popcll(m);
+      if (ok) {
+        const int bin = g.bin_offset + (c[0] * g.nb[1] + c[1]) * g.nb[2] + c[2];
+        lo = bin_start[bin];
+        len = bin_start[bin + 1] - lo;
+        code = (sh[0] + 8) | ((sh[1] + 8) << 4) | ((sh[2] + 8) << 8);
+      }
+    }
+    // exclusive prefix of len over the lanes
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const int excl = incl - len;
+    const int total = __builtin_amdgcn_readlane(incl, 26);
+    const int delta = lo - excl;  // record index = delta[k] + flat index
+
+    for (int base = 0; base < total; base += 64) {
+      const int f = base + lane;
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < 27; ++q) k += f >= __builtin_amdgcn_readlane(excl, q);
+      const int dl = __shfl(delta, k);
+      const int cd = __shfl(code, k);
+      bool valid = false;
+      int j = 0, Sx = 0, Sy = 0, Sz = 0, sj = 0;
+      if (f < total) {
+        const NlRec r = recs[dl + f];
+        const int sx = (cd & 15) - 8, sy = ((cd >> 4) & 15) - 8, sz = ((cd >> 8) & 15) - 8;
+        j = r.j;
+        sj = r.sp;
+        // shift relative to the positions as given: S = s - w_j + w_i
+        Sx = sx - r.wx + wix;
+        Sy = sy - r.wy + wiy;
+        Sz = sz - r.wz + wiz;
+        const double Dx = r.x - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
+        const double Dy = r.y - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
+        const double Dz = r.z - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
+        const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
+        valid = (sqrt(r2) < rmax) && !(j == i && cd == kSelf);
+      }
+      for (int s = 0; s < nel; ++s) {
+        const unsigned long long m = __ballot(valid && sj == s);
+        if (MODE == 1 && valid && sj == s) {
+          const int slot = seg[s] + running[s] + __popcll(m & ((1ull << lane) - 1ull));
+          pair_i[slot] = i;
+          pair_j[slot] = j;
+          pair_shift[3 * (size_t)slot] = Sx;
+          pair_shift[3 * (size_t)slot + 1] = Sy;
+          pair_shift[3 * (size_t)slot + 2] = Sz;
+        }
+        running[s] += __popcll(m);
+      }
     }
   }
   if (MODE == 0 && lane == 0) {
@@ -483,10 +491,18 @@ bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g) {
     g.pbc[a] = fr.pbc[a] != 0;
     const double height = vol / norm(cr[a]);
     const double wfrac = rmax / height;  // bin width in fractional units (perpendicular width = rmax)
+    g.m[a] = 1;
     if (g.pbc[a]) {
       const int nb = (int)std::floor(1.0 / wfrac);
-      if (nb < 1) return false;  // cell thinner than rc: several images per bin, host builder
-      g.nb[a] = std::min(nb, 64);
+      if (nb < 1) {
+        // cell thinner than the cutoff along this axis: ONE bin, whose images -m .. m are all looked at
+        // (round 3; such cells took the host builder before). Two wrapped atoms are less than one cell
+        // apart along the axis, so images beyond floor(rmax / height) + 1 cannot be inside rmax.
+        const int m = (int)std::floor(rmax / height) + 1;
+        if (m > 7) return false;  // 4-bit shift codes in the kernel; below ~1 A of cell height: host builder
+        g.m[a] = m;
+      }
+      g.nb[a] = std::max(1, std::min(nb, 64));
       g.lo[a] = 0.0;
       g.inv_w[a] = (double)g.nb[a];
     } else {

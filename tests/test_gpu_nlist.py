@@ -103,10 +103,30 @@ def test_small_cells_self_images_and_fallback(lib):
     tri = [Atoms(symbols=["Ni"] * 40, positions=rng.rand(40, 3) @ cell * 1.7 - 3.0, cell=cell, pbc=True)]
     info, dev = _device_pairs(nn, tri, expect_device=True)
     assert np.array_equal(dev, _oracle_pairs(tri, 6.5))
-    # a cell thinner than rc goes to the host builder
+    # cells thinner than rc along one, two or three periodic axes stay on the device (round 3: one bin
+    # along the thin axis, images -m .. m of it; they took the host builder before): 3.5 A cubic cell
+    # (m = 2 everywhere, every atom sees itself 4 and 6 cells away), the 2.48 x 2.48 x 24.3 A cell of
+    # BASELINE config 1 (m = 4, 4, 1: 243 (bin, image) combinations), a sheared thin slab with atoms
+    # given two cells outside the box, and a batch that mixes thin and thick frames
     thin = [fcc(rep=(1, 2, 2))]
-    info, dev = _device_pairs(nn, thin, expect_device=False)
+    info, dev = _device_pairs(nn, thin, expect_device=True)
     assert np.array_equal(dev, _oracle_pairs(thin, 6.5))
+    tiny = [fcc(rep=(1, 1, 1))]
+    info, dev = _device_pairs(nn, tiny, expect_device=True)
+    assert np.array_equal(dev, _oracle_pairs(tiny, 6.5))
+    import os
+    from tensoralloy_amd.io import read_extxyz
+    c1 = read_extxyz(os.path.join(os.path.dirname(__file__), "golden", "snap_Ni_id11.extxyz"))[:1]
+    info, dev = _device_pairs(nn, c1, expect_device=True)
+    assert np.array_equal(dev, _oracle_pairs(c1, 6.5))
+    cell = np.array([[3.1, 0.0, 0.0], [1.2, 9.0, 0.0], [0.4, -0.8, 16.0]])
+    slab = [Atoms(symbols=["Ni"] * 30, positions=(rng.rand(30, 3) * 3.0 - 1.0) @ cell, cell=cell,
+                  pbc=[True, True, False])]
+    info, dev = _device_pairs(nn, slab, expect_device=True)
+    assert np.array_equal(dev, _oracle_pairs(slab, 6.5))
+    mixed = [fcc(rep=(1, 1, 2), seed=4), fcc(rep=(3, 3, 3), seed=5), c1[0]]
+    info, dev = _device_pairs(nn, mixed, expect_device=True)
+    assert np.array_equal(dev, _oracle_pairs(mixed, 6.5))
 
 
 def test_results_do_not_depend_on_the_builder(lib, monkeypatch):
