@@ -508,9 +508,7 @@ def main():
                 eng.synchronize()
                 t = time.perf_counter()
                 for _ in range(n):
-                    eng.update_positions(pos)
-                    eng.compute(want)
-                    eng.fetch(want)
+                    eng.step(pos, want)   # ta_step = ta_update_positions + ta_compute + ta_get_results
                 return (time.perf_counter() - t) / n
             loop(3)
             t_rebuild = loop(n_inc)

@@ -246,6 +246,13 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial,
 int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want,
             double *energy, double *forces, double *virial, double *atomic);
 
+/* One MD / relaxation step in ONE call: ta_update_positions + ta_compute + ta_get_results (what
+ * `TensorAlloyCalculator.calculate` does per call once the structure is resident, calculator.py:335-370;
+ * one library entry instead of three saves the binding's round trips between them). Arguments as
+ * those three; forces / virial / atomic / rebuilt may be NULL. */
+int ta_step(ta_handle h, const double *positions, const double *cells, uint32_t want, double *energy,
+            double *forces, double *virial, double *atomic, int32_t *rebuilt);
+
 /* Enqueue all further work of this handle on `stream` (a hipStream_t of the
  * handle's device owned by the caller, e.g. the stream a RCCL collective is
  * ordered against); NULL restores the handle's own stream (to name the legacy
@@ -329,6 +336,20 @@ int ta_get_constants(ta_handle h, double *constants, int64_t n_constants);
 int ta_update_constants(ta_handle h, const double *constants, int64_t n_constants);
 int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
                          double *grad, int64_t n_grad);
+
+/* Analytic second derivatives of the resident batch's energy: for each of `n_dir` directions
+ * (dR [n_dir][n_atoms_total][3] displacements of the atoms, dh [n_dir][n_frames][9] of the cells; either
+ * may be NULL; BOTH NULL = unit displacements first .. first + n_dir - 1 of the 3 N, direction d moving
+ * atom d / 3 along axis d % 3; `first` is ignored otherwise)
+ * the directional derivative of the forces, dF [n_dir][n_atoms_total][3] = d F / d eps = -(H v), and of
+ * the virials, dW [n_dir][n_frames][9] (may be NULL). Replaces `tf.hessians(energy, positions)`
+ * (nn/basic.py:411-421: Hessian column d = -dF[d]) and the cell derivative of the virial behind the
+ * elastic constants (nn/constraint/elastic.py:24-44: dh = unit matrices, dR = NULL). Forward-mode
+ * (dual-number) tangents through the analytic force kernels: exact, no step size. Available for plain
+ * EAM models whose functions are of the Zjw04 family or tabulated (TA_ERR_UNSUPPORTED otherwise: the
+ * caller then differences the analytic forces). At most 65535 directions per call. */
+int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *dR, const double *dh, double *dF,
+                       double *dW);
 
 /* "nn" pair functions of an EAM / ADP model (rho(r), phi(r), u(r), w(r) as `convolution1x1` networks of
  * the pair distance, nn/eam/eam.py:174-190 — the reference's DEFAULT potentials, alloy.py:110-112):

@@ -18,7 +18,10 @@ with Engine(ni_model()) as eng:
         if k == 5:
             eng.synchronize()
             t0 = time.perf_counter()
-        eng.update_positions(pos)
-        eng.compute(want)
-        eng.fetch(want)
+        if os.environ.get("TA_MD_THREE_CALLS"):
+            eng.update_positions(pos)
+            eng.compute(want)
+            eng.fetch(want)
+        else:
+            eng.step(pos, want)
     print("ms per step", (time.perf_counter() - t0) / steps * 1e3)

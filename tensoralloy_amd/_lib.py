@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
     "ta_energy_gradient", "ta_measure_hbm_copy", "ta_set_skin", "ta_update_positions", "ta_list_stats",
     "ta_count_contributing_triples", "ta_loss_gradient", "ta_constant_count", "ta_get_constants", "ta_update_constants",
-    "ta_constant_gradient", "ta_list_sizes", "ta_abi_version", "ta_model_desc_size", "ta_set_nn_tables",
+    "ta_constant_gradient", "ta_list_sizes", "ta_abi_version", "ta_model_desc_size", "ta_set_nn_tables", "ta_step", "ta_hessian_vectors",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -217,6 +217,8 @@ def load():
     lib.ta_list_stats.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.ta_list_sizes.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.ta_set_nn_tables.argtypes = [H, C.c_int]
+    lib.ta_hessian_vectors.argtypes = [H, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]
+    lib.ta_step.argtypes = [H, _dp, _dp, C.c_uint32, _dp, _dp, _dp, _dp, _ip]
     lib.ta_free.argtypes = [C.c_void_p]
     lib.ta_eam_tabulate.argtypes = [H, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.ta_free.restype = None

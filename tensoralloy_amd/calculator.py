@@ -233,7 +233,11 @@ class TensorAlloyCalculator(BaseCalculator):
         d = self._FD_STEP
         want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
         H = np.zeros((n, 3, n, 3))
-        jobs = [(i, a, sgn) for i in range(n) for a in range(3) for sgn in (1.0, -1.0)]
+        analytic = self._analytic_hessian(atoms)
+        if analytic is not None:
+            H = analytic
+        jobs = [] if analytic is not None else \
+            [(i, a, sgn) for i in range(n) for a in range(3) for sgn in (1.0, -1.0)]
         chunk = max(2, min(len(jobs), (1 << 18) // max(n, 1) // 2 * 2))
         for k0 in range(0, len(jobs), chunk):
             part = jobs[k0:k0 + chunk]
@@ -252,6 +256,21 @@ class TensorAlloyCalculator(BaseCalculator):
         out[np.ix_(idx, range(3), idx, range(3))] = H
         return out
 
+    def _analytic_hessian(self, atoms):
+        """H[i, a, j, b] = d^2 E / dR_ia dR_jb from `ta_hessian_vectors` (dual-number tangents through the
+        analytic force kernels: exact, no step), or None where the model has no analytic path."""
+        n = len(atoms)
+        try:
+            self._engine.set_frames([atoms])
+            H = np.zeros((n, 3, n, 3))
+            dF = self._engine.hessian_vectors()          # [3 n, n, 3] = d F / d R_(k, a)
+        except ValueError:
+            return None
+        for k in range(n):
+            for a in range(3):
+                H[k, a] = -dF[3 * k + a]
+        return H
+
     def _elastic(self, atoms):
         """C[vi, vj] = ((dW_ij/dh)^T h)_kl / V / GPa with the positions held fixed, as the reference's
         op differentiates the virial with respect to the cell placeholder
@@ -259,18 +278,31 @@ class TensorAlloyCalculator(BaseCalculator):
         d = self._FD_STEP
         want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL
         h = np.asarray(atoms.get_cell(complete=True), dtype=np.float64)
-        frames, keys = [], []
-        for a in range(3):
-            for b in range(3):
-                for sgn in (1.0, -1.0):
-                    cell = h.copy()
-                    cell[a, b] += sgn * d
-                    frames.append(self._displaced(atoms, cell=cell))
-                    keys.append((a, b, sgn))
-        res = self._engine.evaluate(frames, want=want)
         dW = np.zeros((3, 3, 3, 3))  # [i, j, a, b] = dW_ij / dh_ab
-        for (a, b, sgn), r in zip(keys, res):
-            dW[:, :, a, b] += sgn * r["virial"] / (2.0 * d)
+        try:   # analytic: the nine unit cell directions, positions fixed (`ta_hessian_vectors`)
+            self._engine.set_frames([atoms])
+            dh = np.zeros((9, 1, 3, 3))
+            for a in range(3):
+                for b in range(3):
+                    dh[3 * a + b, 0, a, b] = 1.0
+            _, dWa = self._engine.hessian_vectors(dh=dh, want_virial=True)
+            for a in range(3):
+                for b in range(3):
+                    dW[:, :, a, b] = dWa[3 * a + b, 0]
+            frames = []
+        except ValueError:
+            frames, keys = [], []
+            for a in range(3):
+                for b in range(3):
+                    for sgn in (1.0, -1.0):
+                        cell = h.copy()
+                        cell[a, b] += sgn * d
+                        frames.append(self._displaced(atoms, cell=cell))
+                        keys.append((a, b, sgn))
+        if frames:
+            res = self._engine.evaluate(frames, want=want)
+            for (a, b, sgn), r in zip(keys, res):
+                dW[:, :, a, b] += sgn * r["virial"] / (2.0 * d)
         volume = abs(np.linalg.det(h))
         pairs = [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
         C = np.zeros((6, 6))

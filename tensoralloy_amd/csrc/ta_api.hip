@@ -60,6 +60,9 @@ void eam_compute(EamModel *, const DeviceBatch &b, uint32_t want, hipStream_t s,
 void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test */);
 bool eam_is_plain(const EamModel *);
 void eam_set_nn_tables(EamModel *, bool on);
+bool eam_hvp_supported(const EamModel *);
+void eam_hvp(EamModel *, const DeviceBatch &b, int n_dir, bool unit, int first, const double *dR, const double *dh,
+             double *dFdot, double *fdot, double *wdot, hipStream_t s);
 bool eam_nn_tables_on(const EamModel *);
 void eam_mark_trained(EamModel *);
 int64_t eam_param_count(const EamModel *);
@@ -213,6 +216,7 @@ struct ta_context {
   // device neighbour list (ta_nlist.hip)
   DevBuf<int32_t> nl_wrap, nl_binid, nl_bin_count, nl_bin_start, nl_bin_cursor, nl_bin_atoms, nl_counts;
   DevBuf<unsigned long long> nl_stats;
+  DevBuf<double> hvp_buf;  // ta_hessian_vectors: tangents in, force / virial tangents out
   DevBuf<ta::NlRec> nl_recs;
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
   bool descriptors_valid = false;  // db.G holds the resident batch's descriptors
@@ -871,6 +875,7 @@ int ta_destroy(ta_handle h) {
                   &h->nl_bin_atoms, &h->nl_counts})
     b->release();
   h->nl_stats.release();
+  h->hvp_buf.release();
   h->nl_recs.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1293,6 +1298,15 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, 
     if (atomic && N) std::memcpy(atomic, stage + 10 * F, N * sizeof(double));
     if (forces && N) std::memcpy(forces, stage + 10 * F + N, 3 * N * sizeof(double));
   });
+}
+
+int ta_step(ta_handle h, const double *positions, const double *cells, uint32_t want, double *energy,
+            double *forces, double *virial, double *atomic, int32_t *rebuilt) {
+  int rc = ta_update_positions(h, positions, cells, rebuilt);
+  if (rc != TA_OK) return rc;
+  rc = ta_compute(h, want);
+  if (rc != TA_OK) return rc;
+  return ta_get_results(h, energy, forces, virial, atomic, nullptr);
 }
 
 int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want, double *energy,
@@ -1809,6 +1823,60 @@ int ta_neighbor_list(const ta_frame *frame, int32_t n_elements, double rc, int64
 }
 
 void ta_free(void *p) { std::free(p); }
+
+int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *dR, const double *dh, double *dF,
+                       double *dW) {
+  if (!h || !dF || n_dir < 0) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  if (!h->eam || !ta::eam_hvp_supported(h->eam))
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives exist for EAM models whose "
+                                       "functions are of the Zjw04 family or tabulated");
+  const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+  const bool unit = !dR && !dh;
+  if (unit && (first < 0 || (size_t)first + (size_t)n_dir > 3 * N))
+    return fail(h, TA_ERR_INVALID, "ta_hessian_vectors: without dR / dh the directions are unit displacements "
+                                   "first .. first + n_dir - 1 of the 3 N");
+  if ((size_t)n_dir > 65535) return fail(h, TA_ERR_INVALID, "ta_hessian_vectors: at most 65535 directions per call");
+  return guarded(h, [&]() {
+    if (n_dir == 0 || N == 0) return;
+    hipStream_t s = h->stream;
+    compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // F'(rho_i) of the resident positions
+    const size_t nd = (size_t)n_dir;
+    h->hvp_buf.ensure(nd * N * (1 + 3 + (dW ? 9 : 0)) + (dR ? nd * N * 3 : 0) + (dh ? nd * F * 9 : 0) + 8);
+    double *p = h->hvp_buf.ptr;
+    double *dFdot = p; p += nd * N;
+    double *fdot = p; p += nd * N * 3;
+    double *wdot = nullptr;
+    if (dW) { wdot = p; p += nd * N * 9; }
+    double *d_dR = nullptr, *d_dh = nullptr;
+    if (dR) {
+      d_dR = p; p += nd * N * 3;
+      HIP_CHECK(hipMemcpyAsync(d_dR, dR, nd * N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    if (dh) {
+      d_dh = p; p += nd * F * 9;
+      HIP_CHECK(hipMemcpyAsync(d_dh, dh, nd * F * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    ta::eam_hvp(h->eam, h->db, n_dir, unit, first, d_dR, d_dh, dFdot, fdot, wdot, s);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(dF, fdot, nd * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    std::vector<double> wat;
+    if (dW) {
+      wat.resize(nd * N * 9);
+      HIP_CHECK(hipMemcpyAsync(wat.data(), wdot, nd * N * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (dW) {  // per-frame sums of the per-atom rows, in atom order
+      std::fill(dW, dW + nd * F * 9, 0.0);
+      const std::vector<int32_t> &foa = h->hp.frame_of_atom;
+      for (size_t d = 0; d < nd; ++d)
+        for (size_t i = 0; i < N; ++i) {
+          const size_t f = (size_t)foa[i];
+          for (int k = 0; k < 9; ++k) dW[(d * F + f) * 9 + k] += wat[(d * N + i) * 9 + k];
+        }
+    }
+  });
+}
 
 int ta_set_nn_tables(ta_handle h, int on) {
   if (!h) return TA_ERR_INVALID;

@@ -134,8 +134,10 @@ __host__ __device__ __forceinline__ int slot_pair(int nel, int cls /* 1 phi, 2 u
 
 // f(r) = a exp(-b (r/re - 1)) / (1 + (r/re - c)^20)   (generic.py:102-117)
 // 1 / re is loop-invariant in every caller (one division per wavefront, not two per pair)
-template <typename T>
-__device__ __forceinline__ void zhou_exp(double r, T a, T b, T c, T re, T &f, T &df) {
+// R = type of the distance: double, or Dual for the second derivatives (forward-mode tangent along a
+// displacement direction: df then carries f''(r) r-dot), where the constants are lifted to Dual too
+template <typename T, typename R = double>
+__device__ __forceinline__ void zhou_exp(R r, T a, T b, T c, T re, T &f, T &df) {
   const T inv_re = 1.0 / re;
   const T x = r * inv_re;
   const T t = x - c;
@@ -172,41 +174,41 @@ __device__ __forceinline__ void zjw_rho_phi_aa(const T *p, double r, T &rho, T &
   dphi = dfa - fb * dlog;
 }
 
-template <typename T>
-__device__ __forceinline__ void zjw_rho(const T *p, double r, T &f, T &df) {
-  zhou_exp<T>(r, p[F_EQ], p[BETA], p[LAMDA], p[R_EQ], f, df);
+template <typename T, typename R = double>
+__device__ __forceinline__ void zjw_rho(const T *p, R r, T &f, T &df) {
+  zhou_exp<T, R>(r, p[F_EQ], p[BETA], p[LAMDA], p[R_EQ], f, df);
 }
-template <typename T>
-__device__ __forceinline__ void zjw_phi_aa(const T *p, double r, T &f, T &df) {
+template <typename T, typename R = double>
+__device__ __forceinline__ void zjw_phi_aa(const T *p, R r, T &f, T &df) {
   T fa, dfa, fb, dfb;
-  zhou_exp<T>(r, p[PA], p[ALPHA], p[KAPPA], p[R_EQ], fa, dfa);
-  zhou_exp<T>(r, p[PB], p[BETA], p[LAMDA], p[R_EQ], fb, dfb);
+  zhou_exp<T, R>(r, p[PA], p[ALPHA], p[KAPPA], p[R_EQ], fa, dfa);
+  zhou_exp<T, R>(r, p[PB], p[BETA], p[LAMDA], p[R_EQ], fb, dfb);
   f = fa - fb;
   df = dfa - dfb;
 }
 // phi_AB = 0.5 (rho_A/rho_B phi_BB + rho_B/rho_A phi_AA)   (zjw04.py:229-243)
-template <typename T>
+template <typename T, typename R = double>
 __device__ __forceinline__ void zjw_phi(const EamParams &P, const T (*el)[20], const T (*phx)[7], int sa, int sb,
-                                        double r, T &f, T &df) {
+                                        R r, T &f, T &df) {
   if (sa == sb) {
-    zjw_phi_aa<T>(el[sa], r, f, df);
+    zjw_phi_aa<T, R>(el[sa], r, f, df);
     return;
   }
   const int pt = pair_type(sa, sb, P.nel);
   if (P.phi_kind[pt] == 1) {  // zjw04.py:689-693
     const T *q = phx[pt];
     T fa, dfa, fb, dfb;
-    zhou_exp<T>(r, q[1], q[3], q[5], q[0], fa, dfa);
-    zhou_exp<T>(r, q[2], q[4], q[6], q[0], fb, dfb);
+    zhou_exp<T, R>(r, q[1], q[3], q[5], q[0], fa, dfa);
+    zhou_exp<T, R>(r, q[2], q[4], q[6], q[0], fb, dfb);
     f = fa - fb;
     df = dfa - dfb;
     return;
   }
   T pha, dpha, phb, dphb, ra, dra, rb, drb;
-  zjw_phi_aa<T>(el[sa], r, pha, dpha);
-  zjw_phi_aa<T>(el[sb], r, phb, dphb);
-  zjw_rho<T>(el[sa], r, ra, dra);
-  zjw_rho<T>(el[sb], r, rb, drb);
+  zjw_phi_aa<T, R>(el[sa], r, pha, dpha);
+  zjw_phi_aa<T, R>(el[sb], r, phb, dphb);
+  zjw_rho<T, R>(el[sa], r, ra, dra);
+  zjw_rho<T, R>(el[sb], r, rb, drb);
   const T q1 = ra / rb, q2 = rb / ra;
   const T dq1 = (dra * rb - ra * drb) / (rb * rb);
   const T dq2 = (drb * ra - rb * dra) / (ra * ra);
@@ -1279,6 +1281,188 @@ __global__ __launch_bounds__(kBlock) void hermite_coef_kernel(int n, double dx, 
   c[4 * (size_t)k + 3] = (d0 + d1 - 2.0 * slope) * inv * inv;
 }
 
+// ---- analytic second derivatives: Hessian-vector products ------------------------------------------
+// d/d eps of the forces (and per-atom virial rows) along a direction (dR, dh) of positions and cells:
+// forward-mode tangents (Dual, ta_dual.h) through the reverse-mode force expression of eam_force_kernel,
+//   F_i = sum_p [ (F'(rho_i) rho_b'(r) + F'(rho_j) rho_a'(r) + phi'(r)) / r ] D_p,
+// with D_p, r, rho', phi' and F' all dual: rho'(r) of a dual r carries rho''(r) r-dot, F'(rho_i) of the
+// dual density carries F''(rho_i) rho_i-dot. Replaces the reference's `tf.hessians(E, R)`
+// (nn/basic.py:411-421; H v = -dF/d eps) and the cell derivative of the virial behind the elastic
+// constants (nn/constraint/elastic.py:24-44), which round 2 took by central differences with a 1e-4 A
+// step. Plain EAM models whose functions are of the Zjw04 family or tabulated (setfl tables, nn pair
+// functions through their tables); everything else reports "unsupported" and keeps the differences.
+__device__ __forceinline__ void spline_eval_dual(const TabDev &t, Dual x, Dual &f, Dual &df) {
+  int k = (int)(x.v * t.inv_dx);
+  k = k < 0 ? 0 : (k > t.n - 2 ? t.n - 2 : k);
+  const double tt = x.v - (double)k * t.dx;
+  const double2 *c = reinterpret_cast<const double2 *>(t.c + 4 * (size_t)k);
+  const double2 a = c[0], b = c[1];
+  const double d1 = fma(fma(3.0 * b.y, tt, 2.0 * b.x), tt, a.y);
+  const double d2 = fma(6.0 * b.y, tt, 2.0 * b.x);
+  f = make_dual(fma(fma(fma(b.y, tt, b.x), tt, a.y), tt, a.x), d1 * x.d);
+  df = make_dual(d1, d2 * x.d);
+}
+
+struct HvpArgs {
+  int n_dir, unit;     // unit: direction d displaces atom (first + d) / 3 along axis (first + d) % 3 (dR null)
+  int first;
+  const double *dR;    // [n_dir][N][3] or null
+  const double *dh;    // [n_dir][F][9] or null
+  double eps;
+};
+
+// tangent of the pair vector D = Rj - Ri + S.h along direction `dir`
+__device__ __forceinline__ void hvp_pair_tangent(const HvpArgs &a, const DeviceBatch &b, int dir, int64_t i, int j,
+                                                 int fr, const int *S, double (&T)[3]) {
+  T[0] = T[1] = T[2] = 0.0;
+  if (a.unit) {
+    const int k = (a.first + dir) / 3, c = (a.first + dir) % 3;
+    T[c] = (j == k ? 1.0 : 0.0) - (i == k ? 1.0 : 0.0);
+    return;
+  }
+  if (a.dR) {
+    const double *ui = a.dR + ((size_t)dir * b.n_atoms + i) * 3, *uj = a.dR + ((size_t)dir * b.n_atoms + j) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[c] = uj[c] - ui[c];
+  }
+  if (a.dh) {
+    const double *g = a.dh + ((size_t)dir * b.n_frames + fr) * 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[c] += S[0] * g[c] + S[1] * g[3 + c] + S[2] * g[6 + c];
+  }
+}
+
+// pass 1: F''(rho_i) rho_i-dot per (direction, atom); one wavefront per atom, grid.y = direction
+__global__ __launch_bounds__(kBlock) void eam_hvp_atom_kernel(EamParams P, DeviceBatch b, HvpArgs a,
+                                                              const TabDev *__restrict__ tabs, double *dFdot) {
+  __shared__ Dual el[kMaxEamElements][20];
+  const int nel = P.nel;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, dir = blockIdx.y;
+  if (i >= b.n_atoms) return;
+  const int fr = b.frame_of_atom[i];
+  double *out = dFdot + (size_t)dir * b.n_atoms + i;
+  if (a.unit && b.frame_of_atom[(a.first + dir) / 3] != fr) {  // another structure of the batch: no coupling
+    if (lane == 0) *out = 0.0;
+    return;
+  }
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  const double *h = b.cells + 9 * (size_t)fr;
+  const double *ri = b.pos + 3 * (size_t)i;
+  double rho = 0.0, rhodot = 0.0;
+  for (int sb = 0; sb < nel; ++sb) {
+    const bool rho_tab = (P.tab_rho >> sb) & 1u;
+    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+      const int j = b.pair_j[q];
+      const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
+      const double *rj = b.pos + 3 * (size_t)j;
+      double D[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) D[c] = (rj[c] - ri[c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+      const double r2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2] + a.eps;
+      if (P.list_rc2 > 0.0 && !(r2 < P.list_rc2)) continue;
+      const double r = sqrt(r2);
+      double T[3];
+      hvp_pair_tangent(a, b, dir, i, j, fr, S, T);
+      const double rdot = (D[0] * T[0] + D[1] * T[1] + D[2] * T[2]) / r;
+      double f, df;
+      if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
+      else zjw_rho<double>(P.el[sb], r, f, df);
+      rho += f;
+      rhodot = fma(df, rdot, rhodot);
+    }
+  }
+  rho = wave_sum(rho);
+  rhodot = wave_sum(rhodot);
+  if (lane == 0) {
+    Dual F, dF;
+    if ((P.tab_embed >> sA) & 1u) spline_eval_dual(tabs[slot_embed(nel, sA)], make_dual(rho, 1.0), F, dF);
+    else zjw_embed<Dual>(el[sA], P.embed_kind[sA], make_dual(rho, 1.0), F, dF);
+    *out = dF.d * rhodot;  // F''(rho_i) rho_i-dot
+  }
+}
+
+// pass 2: d forces / d eps per (direction, atom) and, when asked for, the per-atom virial rows' tangents
+__global__ __launch_bounds__(kBlock) void eam_hvp_force_kernel(EamParams P, DeviceBatch b, HvpArgs a,
+                                                               const TabDev *__restrict__ tabs,
+                                                               const double *__restrict__ dF,
+                                                               const double *__restrict__ dFdot, double *fdot,
+                                                               double *wdot) {
+  __shared__ Dual el[kMaxEamElements][20];
+  __shared__ Dual phx[kMaxPairTypes][7];
+  const int nel = P.nel, npt = nel * (nel + 1) / 2;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
+  for (int t = threadIdx.x; t < npt * 7; t += kBlock) phx[t / 7][t % 7] = make_dual(P.phi[t / 7][t % 7]);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, dir = blockIdx.y;
+  if (i >= b.n_atoms) return;
+  const int fr = b.frame_of_atom[i];
+  double *fo = fdot + ((size_t)dir * b.n_atoms + i) * 3;
+  double *wo = wdot ? wdot + ((size_t)dir * b.n_atoms + i) * 9 : nullptr;
+  double fd[3] = {0, 0, 0}, wd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!(a.unit && b.frame_of_atom[(a.first + dir) / 3] != fr)) {
+    const int sA = b.species[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    const double *h = b.cells + 9 * (size_t)fr;
+    const double *ri = b.pos + 3 * (size_t)i;
+    const Dual dFi = make_dual(dF[i], dFdot[(size_t)dir * b.n_atoms + i]);
+    const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    for (int sb = 0; sb < nel; ++sb) {
+      const int pt = pair_type(sA, sb, nel);
+      const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+        const int j = b.pair_j[q];
+        const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
+        const double *rj = b.pos + 3 * (size_t)j;
+        double Dv[3], T[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Dv[c] = (rj[c] - ri[c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+        const double r2v = Dv[0] * Dv[0] + Dv[1] * Dv[1] + Dv[2] * Dv[2] + a.eps;
+        if (P.list_rc2 > 0.0 && !(r2v < P.list_rc2)) continue;
+        hvp_pair_tangent(a, b, dir, i, j, fr, S, T);
+        const Dual D[3] = {make_dual(Dv[0], T[0]), make_dual(Dv[1], T[1]), make_dual(Dv[2], T[2])};
+        const Dual r = t_sqrt(make_dual(r2v, 2.0 * (Dv[0] * T[0] + Dv[1] * T[1] + Dv[2] * T[2])));
+        const Dual dFj = make_dual(dF[j], dFdot[(size_t)dir * b.n_atoms + j]);
+        Dual fn, drhoB, drhoA, dphi;
+        if (rhoB_tab) spline_eval_dual(tabs[slot_rho(sb)], r, fn, drhoB);
+        else zjw_rho<Dual, Dual>(el[sb], r, fn, drhoB);
+        if (sb == sA) drhoA = drhoB;
+        else if (rhoA_tab) spline_eval_dual(tabs[slot_rho(sA)], r, fn, drhoA);
+        else zjw_rho<Dual, Dual>(el[sA], r, fn, drhoA);
+        if (phi_tab) spline_eval_dual(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
+        else zjw_phi<Dual, Dual>(P, el, phx, sA, sb, r, fn, dphi);
+        const Dual inv_r = 1.0 / r;
+        const Dual own = (dFi * drhoB + 0.5 * dphi) * inv_r;              // g[p] = own D
+        const Dual both = own + (dFj * drhoA + 0.5 * dphi) * inv_r;       // g[p] - g[rev p] = both D
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          fd[c] += (both * D[c]).d;
+          if (wo) {
+            const Dual od = own * D[c];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wd[3 * c + e] += (od * D[e]).d;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) fd[k] = wave_sum(fd[k]);
+  if (wo) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd[k] = wave_sum(wd[k]);
+  }
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) fo[k] = fd[k];
+    if (wo)
+      for (int k = 0; k < 9; ++k) wo[k] = wd[k];
+  }
+}
+
 constexpr int kNetThreads = 256;
 // Knots of an nn function's table over [0, rcut]: dx = rcut / 32768 (2e-4 A at rcut = 6.5). Cubic
 // Hermite error: value dx^4 / 384 |f''''|, derivative about dx^3 / 72 |f''''| (1e-17 / 1e-13 per unit of
@@ -2025,6 +2209,24 @@ void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *fram
     hipLaunchKernelGGL(eam_const_grad_kernel<false>, dim3(blocks, (unsigned)nq), dim3(kBlock), 0, s, P, b,
                        frame_coeff, dR, dh, m->eps, m->gpartial);
   hipLaunchKernelGGL(eam_const_reduce_kernel, dim3((unsigned)nq), dim3(64), 0, s, m->gpartial, (int)blocks, grad);
+}
+
+// Hessian-vector products on the resident batch (the forward pass of eam_compute must have run: F'(rho)
+// in m->dF). Device pointers; `dFdot` [n_dir][N] scratch. False = this model keeps the central differences.
+bool eam_hvp_supported(const EamModel *m) {
+  if (m->p.adp || m->pair_nets || m->embed_nets) return false;
+  for (int e = 0; e < m->p.nel; ++e)
+    if (m->p.el_kind[e] != 0) return false;  // sutton90 / Be/1 / grimes: first derivatives only
+  return true;
+}
+void eam_hvp(EamModel *m, const DeviceBatch &b, int n_dir, bool unit, int first, const double *dR, const double *dh,
+             double *dFdot, double *fdot, double *wdot, hipStream_t s) {
+  if (b.n_atoms == 0 || n_dir == 0) return;
+  const HvpArgs a{n_dir, unit ? 1 : 0, first, dR, dh, m->eps};
+  const dim3 grid((unsigned)((b.n_atoms + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)n_dir);
+  hipLaunchKernelGGL(eam_hvp_atom_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, dFdot);
+  hipLaunchKernelGGL(eam_hvp_force_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, m->dF, dFdot, fdot,
+                     wdot);
 }
 
 void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {

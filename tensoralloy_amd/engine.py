@@ -114,6 +114,46 @@ class Engine:
             self.info.n_pairs, self.info.n_triples, self.info.nnl_max = n_pairs.value, n_triples.value, nnl.value
         return bool(rebuilt.value)
 
+    def step(self, positions, want: int, cells=None) -> dict:
+        """One MD step of the resident batch in one library call (`ta_step`): new coordinates in,
+        evaluation, results out. Same result dict as `fetch`; the output arrays are reused from call to
+        call (copy what must outlive the next step)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        N, F = int(self.info.n_atoms), int(self.info.n_frames)
+        if pos.size != 3 * N:
+            raise ValueError("positions for every atom of the resident batch are needed")
+        buf = getattr(self, "_step_buf", None)
+        if buf is None or buf[0] != (N, F):
+            buf = ((N, F), np.empty(F), np.empty((N, 3)), np.empty((F, 3, 3)), np.empty(N))
+            self._step_buf = buf
+        _, energy, forces, virial, atomic = buf
+        null = C.POINTER(C.c_double)()
+        cptr = null
+        if cells is not None:
+            cells = np.ascontiguousarray(cells, dtype=np.float64).reshape(-1, 3, 3)
+            if len(cells) != F:
+                raise ValueError("one cell per resident frame")
+            cptr = _lib.as_dp(cells)
+        want_f = bool(want & (_lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL))
+        rebuilt = C.c_int32(0)
+        self._check(self._lib.ta_step(
+            self._handle, _lib.as_dp(pos), cptr, int(want), _lib.as_dp(energy),
+            _lib.as_dp(forces) if want_f else null, _lib.as_dp(virial) if want_f else null,
+            _lib.as_dp(atomic) if want & _lib.TA_WANT_ATOMIC else null, C.byref(rebuilt)))
+        self.batch_generation += 1
+        if cells is not None:
+            self._volumes = np.abs(np.linalg.det(cells))
+        if rebuilt.value:
+            n_pairs, n_triples, nnl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+            self._check(self._lib.ta_list_sizes(self._handle, C.byref(n_pairs), C.byref(n_triples), C.byref(nnl)))
+            self.info.n_pairs, self.info.n_triples, self.info.nnl_max = n_pairs.value, n_triples.value, nnl.value
+        out = {"energy": energy}
+        if want_f:
+            out["forces"], out["virial"] = forces, virial
+        if want & _lib.TA_WANT_ATOMIC:
+            out["atomic"] = atomic
+        return out
+
     def list_stats(self):
         """(lists built, lists reused) by this engine."""
         a, b = C.c_int64(0), C.c_int64(0)
@@ -213,6 +253,12 @@ class Engine:
         pbc = tuple(bool(x) for x in atoms.pbc) if periodic else (False, False, False)
         sig = (len(atoms), np.asarray(atoms.numbers).tobytes(), pbc)
         cell = np.ascontiguousarray(atoms.get_cell(complete=True), dtype=np.float64).reshape(3, 3)
+        if sig == self._md_sig and self.info is not None and not descriptors:
+            same_cell = np.array_equal(cell, self._md_cell)
+            res = self.step(atoms.positions, want, None if same_cell else cell[None])
+            self._md_cell = cell
+            # (the step buffers are reused by the next call: hand out copies)
+            return self._per_frame({k: v.copy() for k, v in res.items()})[0]
         if sig == self._md_sig and self.info is not None:
             same_cell = np.array_equal(cell, self._md_cell)
             self.update_positions(atoms.positions, None if same_cell else cell[None])
@@ -331,6 +377,35 @@ class Engine:
         grad = np.zeros(self.constant_count())
         self._check(self._lib.ta_constant_gradient(self._handle, cp, rp, hp, _lib.as_dp(grad), len(grad)))
         return grad
+
+    def hessian_vectors(self, dR=None, dh=None, want_virial=False):
+        """Analytic directional derivatives of the forces (and virials) of the resident batch
+        (`ta_hessian_vectors`): dR [n_dir, N, 3] and / or dh [n_dir, F, 3, 3]; both None = the 3 N unit
+        displacements. Returns dF [n_dir, N, 3] (= -H v) and, with `want_virial`, dW [n_dir, F, 3, 3].
+        Raises ValueError for models without the analytic path."""
+        N, F = int(self.info.n_atoms), int(self.info.n_frames)
+        null = C.POINTER(C.c_double)()
+        rp = hp = null
+        if dR is None and dh is None:
+            n_dir = 3 * N
+        else:
+            n_dir = len(dR) if dR is not None else len(dh)
+        if dR is not None:
+            dR = np.ascontiguousarray(dR, dtype=np.float64).reshape(n_dir, N, 3)
+            rp = _lib.as_dp(dR)
+        if dh is not None:
+            dh = np.ascontiguousarray(dh, dtype=np.float64).reshape(n_dir, F, 9)
+            hp = _lib.as_dp(dh)
+        dF = np.zeros((n_dir, N, 3))
+        dW = np.zeros((n_dir, F, 3, 3)) if want_virial else None
+        # at most 65535 directions per library call; the unit displacements are chunked by `first`
+        chunk = 32768 if (dR is None and dh is None) else n_dir
+        for first in range(0, n_dir, max(chunk, 1)):
+            m = min(chunk, n_dir - first)
+            self._check(self._lib.ta_hessian_vectors(
+                self._handle, m, first, rp, hp, _lib.as_dp(dF[first:]),
+                _lib.as_dp(dW[first:]) if want_virial else null))
+        return (dF, dW) if want_virial else dF
 
     def energies(self, reuse_descriptors=True) -> np.ndarray:
         """Frame energies of the resident batch; with `reuse_descriptors` only the MLP is re-run."""

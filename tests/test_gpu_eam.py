@@ -327,3 +327,69 @@ def test_device_functions_reproduce_the_reference_setfl_tables(lib, tmp_path):
     for key, ref in d["rphi"].items():
         got = back["rphi"][key][d["r_index"]][1:]
         assert np.abs(got - np.array(ref)[1:]).max() < 1e-12 * max(1, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("kind", ["zjw04", "zjw04_binary_skin", "setfl", "nn_tables"])
+def test_analytic_hessian_vectors(lib, tmp_path, kind):
+    """`ta_hessian_vectors` (dual-number tangents through the analytic EAM force kernels; replaces
+    tf.hessians, nn/basic.py:411-421, and the cell derivative of the virial behind the elastic
+    constants, nn/constraint/elastic.py:24-44) against central differences of the GPU's own analytic
+    forces and virials along random directions of positions AND cell, and the symmetry of the Hessian
+    from the unit directions. Models: Zjw04 Ni; Mo-Ni with the cross pair term, a sheared cell and a
+    Verlet skin; the Al-Cu setfl tables as splines; nn pair functions through their Hermite tables."""
+    from tensoralloy_amd import Atoms, Engine
+    from tensoralloy_amd.eam import EamAlloyNN
+    if kind == "zjw04":
+        nn, atoms = make_eam(["Ni"], 6.0), fcc(rep=(2, 2, 2), seed=3)
+    elif kind == "zjw04_binary_skin":
+        nn = make_eam(["Mo", "Ni"], 6.0)
+        atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 3), seed=5)
+        cell = np.asarray(atoms.get_cell(complete=True)).copy()
+        cell[1, 0] = 0.2 * cell[0, 0]
+        atoms = Atoms(symbols=atoms.get_chemical_symbols(), positions=atoms.positions, cell=cell, pbc=True)
+    elif kind == "setfl":
+        from tensoralloy_amd import UniversalTransformer
+        nn = EamAlloyNN.from_setfl(golden_setfl("Zhou_AlCu.alloy.eam", tmp_path))
+        nn.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=5.99))
+        atoms = _alloy(["Al", "Cu"], rep=(2, 2, 2), a=3.9, seed=7)
+    else:
+        nn = make_eam(["Ni"], 6.0, potential={"Ni": {"rho": "nn", "embed": "zjw04"}, "NiNi": {"phi": "nn"}},
+                      hidden_sizes=[16, 16])
+        atoms = fcc(rep=(2, 2, 2), seed=9)
+    n = len(atoms)
+    h = np.asarray(atoms.get_cell(complete=True), dtype=float)
+    rng = np.random.RandomState(2)
+    dR = rng.normal(size=(2, n, 3))
+    dh = rng.normal(size=(2, 1, 3, 3)) * 0.3
+    dR[1] = 0.0        # second direction: the cell alone (the elastic-constant case)
+    want = 1 | 2 | 4
+    eps = 1e-4
+    with Engine(nn) as eng:
+        if kind == "zjw04_binary_skin":
+            eng.set_skin(0.4)
+        eng.set_frames([atoms])
+        dF, dW = eng.hessian_vectors(dR=dR, dh=dh, want_virial=True)
+        H = -eng.hessian_vectors()                  # [3 n, n, 3]
+        for d in range(2):
+            fd_F, fd_W = 0.0, 0.0
+            for sgn in (1.0, -1.0):
+                a = Atoms(symbols=atoms.get_chemical_symbols(), positions=atoms.positions + sgn * eps * dR[d],
+                          cell=h + sgn * eps * dh[d, 0], pbc=True)
+                r = eng.evaluate([a], want=want)[0]
+                fd_F = fd_F + sgn * r["forces"] / (2 * eps)
+                fd_W = fd_W + sgn * r["virial"] / (2 * eps)
+            tol_f = 2e-6 * max(1.0, np.abs(fd_F).max())
+            assert np.abs(dF[d] - fd_F).max() < tol_f, (d, np.abs(dF[d] - fd_F).max())
+            assert np.abs(dW[d, 0] - fd_W).max() < 2e-6 * max(1.0, np.abs(fd_W).max())
+    Hm = H.reshape(3 * n, 3 * n)
+    assert np.abs(Hm - Hm.T).max() < 1e-9 * max(1.0, np.abs(Hm).max())
+    assert np.abs(Hm.sum(axis=1)).max() < 1e-8          # acoustic sum rule: a rigid shift costs nothing
+
+
+def test_hessian_vectors_refuse_models_without_the_analytic_path(lib):
+    from tensoralloy_amd import Engine
+    for nn in (make_eam(["Ni"], 6.0, adp=True), make_eam(["Ni"], 6.0, potential=None)):   # ADP; nn embedding
+        with Engine(nn) as eng:
+            eng.set_frames([fcc(rep=(1, 1, 1))])
+            with pytest.raises(ValueError, match="analytic second derivatives"):
+                eng.hessian_vectors()
