@@ -175,7 +175,12 @@ def read_constants(path: str) -> Dict[str, object]:
         if op == "Const" and name is not None and value is not None:
             try:
                 out[name] = _tensor(value)
-            except ValueError:
+            except ValueError as exc:
+                # a constant this reader cannot decode (an encoding it does not know): harmless for
+                # the graph's own bookkeeping nodes, but never for a constant of the MODEL -- dropping
+                # one silently would load a model that runs and returns wrong energies
+                if name.startswith(("Atomic/", "EAM/", "ADP/", "Transformer/", "Metadata/")):
+                    raise ValueError(f"{path}: constant '{name}' cannot be decoded: {exc}") from exc
                 continue
     return out
 

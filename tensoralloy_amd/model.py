@@ -564,6 +564,13 @@ def load_graph_def(path: str):
         return nn, clf, meta
     if not any(n.startswith("Atomic/") for n in names):
         raise ValueError(f"{path}: neither an EAM nor an AtomicNN graph")
+    # AtomicNN graphs: the reference ships no such frozen file, so what follows reads the STRUCTURE the
+    # reference's exporter writes (scopes, constant names, which ops appear) but has no fixture that
+    # pins it end to end. It refuses whatever it cannot identify unambiguously and says what it assumed.
+    import warnings
+    warnings.warn(f"{path}: AtomicNN GraphDef import is structural (cutoff, activation, ResNet and bias flags "
+                  f"are inferred from the graph's ops); check a known energy, or export the model as "
+                  f"<name>.json + <name>.npz", RuntimeWarning, stacklevel=2)
     node_ops = read_node_ops(path)
     if any("/Filters/" in n or "/Moment" in n for n in names):
         raise ValueError(f"{path}: GRAP graphs are not read from GraphDef files; use the native .npz "
@@ -598,7 +605,9 @@ def load_graph_def(path: str):
         raise ValueError(f"{path}: cannot identify the activation function (found {acts})")
     weights, minmax = {}, {}
     for el in clf.elements:
-        layers, j = [], 0
+        # hidden layers are scoped `Conv1d1`, `Conv1d2`, ... by the reference (`Conv{rank}d{j + 1}`,
+        # convolutional.py:262); a count from 0 is accepted as well
+        layers, j = [], (0 if f"Atomic/{el}/Conv1d0/kernel" in consts else 1)
         while f"Atomic/{el}/Conv1d{j}/kernel" in consts:
             w = np.asarray(consts[f"Atomic/{el}/Conv1d{j}/kernel"], dtype=np.float64)
             b = consts.get(f"Atomic/{el}/Conv1d{j}/bias")
