@@ -217,6 +217,9 @@ struct ta_context {
   DevBuf<int32_t> nl_wrap, nl_binid, nl_bin_count, nl_bin_start, nl_bin_cursor, nl_bin_atoms, nl_counts;
   DevBuf<unsigned long long> nl_stats;
   DevBuf<double> hvp_buf;  // ta_hessian_vectors: tangents in, force / virial tangents out
+#ifdef TA_PHASE_STAMPS
+  DevBuf<unsigned long long> stamp_buf;
+#endif
   DevBuf<ta::NlRec> nl_recs;
   bool pairs_on_device = false;  // hp holds only the counts; ta_get_pairs downloads on demand
   bool descriptors_valid = false;  // db.G holds the resident batch's descriptors
@@ -620,8 +623,37 @@ void fill_pairs_on_device(ta_context *h) {
   HIP_CHECK(hipGetLastError());
 }
 
+#ifdef TA_PHASE_STAMPS
+// diagnostic builds: phase stamps of the angular kernels of the LAST evaluation, written to the file
+// named by TA_PHASE_STAMPS_OUT at ta_destroy (scripts/phase_stamps.sh)
+static void dump_stamps(ta_context *h) {
+  const char *path = std::getenv("TA_PHASE_STAMPS_OUT");
+  if (!path || !h->db.stamps || h->db.n_blk <= 0) return;
+  const size_t n = (size_t)2 * h->db.n_blk * 8;
+  std::vector<unsigned long long> v(n);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipMemcpy(v.data(), h->db.stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  FILE *fp = std::fopen(path, "w");
+  if (!fp) return;
+  for (int k = 0; k < 2; ++k)
+    for (int b = 0; b < h->db.n_blk; ++b) {
+      std::fprintf(fp, "%d %d", k, b);
+      for (int q = 0; q < 8; ++q) std::fprintf(fp, " %llu", v[((size_t)k * h->db.n_blk + b) * 8 + q]);
+      std::fprintf(fp, "\n");
+    }
+  std::fclose(fp);
+}
+#endif
+
 void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
   using namespace ta;
+#ifdef TA_PHASE_STAMPS
+  if (h->db.n_blk > 0) {
+    h->stamp_buf.ensure((size_t)2 * h->db.n_blk * 8 + 8);
+    h->db.stamps = h->stamp_buf.ptr;
+    (void)hipMemsetAsync(h->db.stamps, 0, (size_t)2 * h->db.n_blk * 8 * sizeof(unsigned long long), h->stream);
+  }
+#endif
   h->db.rec4 = nullptr;  // only the second-generation angular path below sets it
   h->db.own_sums = 0;    // likewise
   const DeviceBatch &db = h->db;
@@ -855,6 +887,9 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
 int ta_destroy(ta_handle h) {
   if (!h) return TA_OK;
   (void)hipSetDevice(h->device);
+#ifdef TA_PHASE_STAMPS
+  dump_stamps(h);
+#endif
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->model_allocs) (void)hipFree(p);
   if (h->eam) ta::eam_destroy(h->eam);

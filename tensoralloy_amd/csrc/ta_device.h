@@ -113,6 +113,11 @@ struct DeviceBatch {
   // per-centre reduction cost what the gather saved, profiles/r02_tuning_notes.md.)
   double *fown = nullptr;
   int own_sums = 0;
+#ifdef TA_PHASE_STAMPS
+  // diagnostic builds only (scripts/phase_stamps.sh): s_memrealtime (100 MHz) at the phase boundaries
+  // of the angular kernels, [kernel 0 / 1][workgroup][8]
+  unsigned long long *stamps = nullptr;
+#endif
   double *bpart = nullptr;  // [ceil(N / 16)][10] {E, W[9]} of every group of 16 consecutive atoms
   double *energy = nullptr; // [F]
   double *virial = nullptr; // [F][9]

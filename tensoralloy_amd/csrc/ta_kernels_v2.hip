@@ -59,6 +59,16 @@ __device__ __forceinline__ bool kProbe(int flags, int bit) { return (flags >> bi
 __device__ __forceinline__ constexpr bool kProbe(int, int) { return false; }
 #endif
 
+#ifdef TA_PHASE_STAMPS
+#define TA_STAMP(b, kernel, k)                                                                          \
+  do {                                                                                                  \
+    if ((b).stamps && threadIdx.x == 0)                                                                 \
+      (b).stamps[((size_t)(kernel) * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TA_STAMP(b, kernel, k) do {} while (0)
+#endif
+
 __device__ __forceinline__ int angular_term2(int s1, int s2, int nel) {
   int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
   return a * nel - (a * (a - 1)) / 2 + (b - a);
@@ -571,7 +581,9 @@ __global__ __launch_bounds__(kBlock)
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * kCap; k += blockDim.x) P0[k] = 0.0;
   }
+  TA_STAMP(b, 0, 0);
   stage<HD>(sf, ch, beta, b, f, s0, M, geom, true);
+  TA_STAMP(b, 0, 1);
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(kBlock)
       if (smax > 0 && !(flags & (1 << 25))) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
       if (b.masks) b.masks[p] = mask;
     }
+    TA_STAMP(b, 0, 2);
     if (b.job_count) {
       // job mode (see make_jobs): build the list once, leave it for the backward kernel, sweep it
       char *raw = reinterpret_cast<char *>(lds);
@@ -740,9 +753,11 @@ __global__ __launch_bounds__(kBlock)
       jl.start = jl.hist + 20;
       double *P = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
       const int n_jobs = make_jobs(jl, active, item, active ? b.pair_i[s0 + item] - c0 : 0, mask);
+      TA_STAMP(b, 0, 3);
       const size_t jbase = (size_t)blockIdx.x * b.job_stride;
       if (threadIdx.x == 0) b.job_count[blockIdx.x] = n_jobs;
       for (int slot = threadIdx.x; slot < n_jobs; slot += blockDim.x) b.job_word[jbase + slot] = jl.word[slot];
+      TA_STAMP(b, 0, 4);
       if (!(flags & (1 << 27)))
         for (int r = 0; r * (int)blockDim.x < n_jobs; ++r) {
           const int slot = job_slot(r, threadIdx.x, blockDim.x);
@@ -752,8 +767,10 @@ __global__ __launch_bounds__(kBlock)
           }
         }
       __syncthreads();
+      TA_STAMP(b, 0, 5);
       if (flags & 4) {
         assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0, kCap);
+        TA_STAMP(b, 0, 6);
         return;
       }
       // several forward launches (one per beta): the sums travel through part4 as before
@@ -897,7 +914,9 @@ __global__ __launch_bounds__(kBlock)
       rtab[ci * kRTab + rem] = b.dEdG[(size_t)i * sf.ndim + radial_term2(b.species[i], sb) * sf.n_rad + c];
     }
   }
+  TA_STAMP(b, 1, 0);
   stage<HD>(sf, ch, beta, b, f, s0, M);
+  TA_STAMP(b, 1, 1);
   const int nel = sf.n_elements;
 
   auto run_item = [&](int item, bool have_mask, unsigned long long mask0, auto is_job) {
@@ -1095,12 +1114,14 @@ __global__ __launch_bounds__(kBlock)
         const int slot = job_slot(r, threadIdx.x, blockDim.x);
         jws[r] = slot < n_jobs ? b.job_word[jbase + slot] : 0u;
       }
+      TA_STAMP(b, 1, 2);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r * (int)blockDim.x >= n_jobs) break;
         const int slot = job_slot(r, threadIdx.x, blockDim.x);
         if (slot < n_jobs) run_item(job_item(jws[r]), true, jws[r], std::true_type{});
       }
+      TA_STAMP(b, 1, 3);
     } else if (one_pass) {  // see deal_by_popcount
       unsigned long long mask = 0ull;
       if (active) {
@@ -1118,6 +1139,7 @@ __global__ __launch_bounds__(kBlock)
     }
   }
   __syncthreads();
+  TA_STAMP(b, 1, 4);
   for (int item = threadIdx.x; item < M; item += blockDim.x) {
     const int64_t p = (int64_t)s0 + item;
     double gx = gacc[item], gy = gacc[kCap + item], gz = gacc[2 * kCap + item];
@@ -1161,6 +1183,7 @@ __global__ __launch_bounds__(kBlock)
     b.g[4 * (size_t)p + 1] = gy;
     b.g[4 * (size_t)p + 2] = gz;
   }
+  TA_STAMP(b, 1, 5);
 }
 
 template <int NSPEC, int NG, int NZ>
