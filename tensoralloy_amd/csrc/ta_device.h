@@ -169,7 +169,7 @@ void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s);
 size_t g4_lds_bytes(int nnl_max);
 
 // second-generation angular kernels (ta_kernels_v2.hip); `ch` holds one beta
-size_t v2_lds_bytes(bool backward, int cap, int n_local = 0);
+size_t v2_lds_bytes(bool backward, int cap, int n_local = 0, int nspec = 0);
 int v2_job_stride(int cap);
 // `reduce`: last forward launch of an evaluation, also assembles the descriptor vectors
 void launch_g4_forward_v2(const SFParams &sf, const AngChunk &ch, int ng, int nz, bool geometry,

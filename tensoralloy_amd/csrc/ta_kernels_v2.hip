@@ -46,7 +46,12 @@ constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
 constexpr int kNF = 8;   // backward: {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
 constexpr int kNFf = 7;  // forward: the last record is the species alone (8 bytes): 1.5 KB of LDS less,
                          // which with the trimmed job counters lets 7 workgroups share a CU instead of 6
-constexpr int kJobCtlBytes = 240;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs, cstart[17 (+3)]
+constexpr int kJobCtlBytes = 320;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs, cstart[17 (+3)], cslot[17 (+3)]
+// One-element models: the per-pair partial G4 sums of the forward sweep are kept per GROUP OF FOUR pairs of
+// a centre (they are only ever summed over the centre), 4 x (cap / 4 + 16) doubles instead of 4 x cap:
+// 22.0 -> 18.0 KB of LDS per workgroup, i.e. 8 instead of 7 workgroups per CU -- with 6 wavefronts per SIMD
+// (80 VGPRs) all 2006 workgroups of the 4000-atom frame are resident at once instead of 1536 + a second round.
+__host__ __device__ inline int v2_pcols(int cap, int nspec) { return nspec == 1 ? cap / 4 + kMaxCentersPerBlock : cap; }
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 constexpr int kRTab = 8;      // backward: radial dE/dG values per centre kept in LDS (neighbour species x radial channels)
 
@@ -97,9 +102,11 @@ __device__ __forceinline__ Fields carve(double *lds, int cap, bool forward = fal
   f.ih = f.xy + cap;
   f.gs = forward ? nullptr : f.ih + cap;
   f.sp1 = forward ? reinterpret_cast<double *>(f.ih + cap) : nullptr;
-  f.xf = forward ? reinterpret_cast<float *>(f.sp1 + cap) : reinterpret_cast<float *>(f.gs + cap);
-  f.yf = f.xf + (2 * cap + kRingPad);
-  f.zf = f.yf + (2 * cap + kRingPad);
+  // the single-precision rings exist in the forward kernel only: the backward kernel never scans (it
+  // takes the forward's job list, or its candidate masks from `b.masks`)
+  f.xf = forward ? reinterpret_cast<float *>(f.sp1 + cap) : nullptr;
+  f.yf = forward ? f.xf + (2 * cap + kRingPad) : nullptr;
+  f.zf = forward ? f.yf + (2 * cap + kRingPad) : nullptr;
   return f;
 }
 
@@ -191,7 +198,7 @@ __device__ __forceinline__ void stage(const SFParams &sf, const AngChunk &ch, do
     }
     f.xy[item] = v0;
     f.zr[item] = v1;
-    {
+    if (forward) {
       const int ci = b.pair_i[s0 + item];
       const int cbase = b.pair_start[ci] - s0, cn = pair_stop_of(b, ci) - b.pair_start[ci];
       const int k0 = 2 * cbase + (item - cbase);
@@ -468,8 +475,8 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
 // column of partner species B over the pairs of species A, summed by the same row (one store).
 template <int NSPEC, int NG, int NZ>
 __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b,
-                                              const Fields &f, const double *P, int c0, int c1, int s0,
-                                              int item, bool active, bool skip_radial, int cap) {
+                                              const Fields &f, const double *P, const int *cslot, int c0, int c1,
+                                              int s0, int item, bool active, bool skip_radial, int cap) {
   constexpr int kGZ = NG * NZ;
   constexpr int kTerms = NSPEC * (NSPEC + 1) / 2;
   double *R = reinterpret_cast<double *>(f.xy);  // xy, ih, sp1 (5 cap doubles) are dead after the sweep
@@ -525,11 +532,17 @@ __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk
         int sa = 0, sb = 0;  // term index -> (sa <= sb), row-major upper triangle
         for (int rem = term, len = NSPEC; rem >= len; rem -= len, --len) ++sa;
         sb = term - (sa * NSPEC - (sa * (sa - 1)) / 2) + sa;
-        const double *colA = P + (size_t)(sa * kGZ + gz) * cap;  // partner species sa, pairs of species sb
-        for (int q = seg[sb] - s0 + l; q < seg[sb + 1] - s0; q += 16) v += colA[q];
-        if (sa != sb) {
-          const double *colB = P + (size_t)(sb * kGZ + gz) * cap;
-          for (int q = seg[sa] - s0 + l; q < seg[sa + 1] - s0; q += 16) v += colB[q];
+        if constexpr (NSPEC == 1) {
+          // one partial-sum slot per four pairs of the centre (v2_pcols, cslot)
+          const double *colA = P + (size_t)gz * v2_pcols(cap, 1);
+          for (int q = cslot[ci] + l; q < cslot[ci + 1]; q += 16) v += colA[q];
+        } else {
+          const double *colA = P + (size_t)(sa * kGZ + gz) * cap;  // partner species sa, pairs of species sb
+          for (int q = seg[sb] - s0 + l; q < seg[sb + 1] - s0; q += 16) v += colA[q];
+          if (sa != sb) {
+            const double *colB = P + (size_t)(sb * kGZ + gz) * cap;
+            for (int q = seg[sa] - s0 + l; q < seg[sa + 1] - s0; q += 16) v += colB[q];
+          }
         }
         v = row16_sum(v);
         if (l == 0) Gi[sf.n_radial_dim + term * sf.n_ang + ch.chan[gz]] = v * sf.ang_scale;
@@ -554,9 +567,10 @@ __device__ __forceinline__ void stagger(int flags) {
 // With CAP known the LDS arrays sit at constant offsets from each other, so the random partner reads
 // and the accumulator updates of the triple bodies address them as one shifted index + immediate
 // offsets instead of one address computation each (six VALU instructions per backward triple).
-template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP>
+// WPE: wavefronts per SIMD asked of the register allocator (0 = the compiler's choice)
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP, int WPE = (DEFZ && NSPEC == 1 ? 5 : 0)>
 __global__ __launch_bounds__(kBlock)
-    __attribute__((amdgpu_waves_per_eu(DEFZ && NSPEC == 1 ? 5 : 1, 8))) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
+    __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, 8))) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
                                                                DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int kCap = CAP > 0 ? CAP : b.cap;
@@ -579,11 +593,23 @@ __global__ __launch_bounds__(kBlock)
     else if (threadIdx.x < 40 + 17 && (int)threadIdx.x - 40 <= c1 - c0)  // cstart[k]: first pair of centre c0 + k
       cnt[threadIdx.x] = ((int)threadIdx.x - 40 < c1 - c0 ? b.pair_start[c0 + threadIdx.x - 40] : s0 + M) - s0;
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
-    for (int k = threadIdx.x; k < NSPEC * NG * NZ * kCap; k += blockDim.x) P0[k] = 0.0;
+    for (int k = threadIdx.x; k < NSPEC * NG * NZ * v2_pcols(kCap, NSPEC); k += blockDim.x) P0[k] = 0.0;
   }
   TA_STAMP(b, 0, 0);
   stage<HD>(sf, ch, beta, b, f, s0, M, geom, true);
   TA_STAMP(b, 0, 1);
+  if (NSPEC == 1 && b.job_count && threadIdx.x == 0) {
+    // cslot[k]: first partial-sum slot of centre c0 + k (one slot per four pairs, see v2_pcols); read by the
+    // sweep and the assembly, both behind the barriers of make_jobs
+    int *ctl = reinterpret_cast<int *>(reinterpret_cast<char *>(lds) + v2_counter_offset(kCap));
+    const int *cs = ctl + 40;
+    int *cslot = ctl + 60;
+    int acc = 0;
+    for (int k = 0; k <= c1 - c0; ++k) {
+      cslot[k] = acc;
+      if (k < c1 - c0) acc += (cs[k + 1] - cs[k] + 3) >> 2;
+    }
+  }
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
   // `out`: null = store the partial sums in part4 (global), else hand them back to the caller
@@ -594,11 +620,13 @@ __global__ __launch_bounds__(kBlock)
     constexpr bool kJob = decltype(is_job)::value;
     const int64_t p = (int64_t)s0 + item;
     int base, n;
+    int pslot = item;  // column index of this pair's partial sums in `pacc`
     if constexpr (kJob) {
       const int *cstart = reinterpret_cast<const int *>(reinterpret_cast<const char *>(lds) + v2_counter_offset(kCap)) + 40;
       const int ci = job_centre((uint32_t)mask0);
       base = cstart[ci];
       n = cstart[ci + 1] - base;
+      if constexpr (NSPEC == 1) pslot = cstart[20 + ci] + ((item - base) >> 2);
     } else {
       const int i = b.pair_i[p];
       base = b.pair_start[i] - s0;
@@ -717,7 +745,7 @@ __global__ __launch_bounds__(kBlock)
           const int c = ch.chan[ig * NZ + iz];
           const double v = acc[sp][ig][iz] * ch.kz[iz];
           if (pacc) {
-            if (v != 0.0) atomicAdd(&pacc[(size_t)((sp * NG + ig) * NZ + iz) * kCap + item], v);
+            if (v != 0.0) atomicAdd(&pacc[(size_t)((sp * NG + ig) * NZ + iz) * v2_pcols(kCap, NSPEC) + pslot], v);
           } else if (out)
             out[(sp * NG + ig) * NZ + iz] = v;
           else
@@ -742,7 +770,7 @@ __global__ __launch_bounds__(kBlock)
       const int base = b.pair_start[i] - s0;
       const int smax = (f.ih[item].y != 0.0) ? n_own / 2 : 0;
       if (smax > 0 && !(flags & (1 << 25))) mask = partner_mask(sf, f, base, n_own, item - base, 1, smax);
-      if (b.masks) b.masks[p] = mask;
+      if (b.masks && !b.job_count) b.masks[p] = mask;  // (with a job list the backward kernel reads that instead)
     }
     TA_STAMP(b, 0, 2);
     if (b.job_count) {
@@ -769,18 +797,27 @@ __global__ __launch_bounds__(kBlock)
       __syncthreads();
       TA_STAMP(b, 0, 5);
       if (flags & 4) {
-        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, c0, c1, s0, item, active, (flags & (1 << 26)) != 0, kCap);
+        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, jl.hist + 60, c0, c1, s0, item, active,
+                                     (flags & (1 << 26)) != 0, kCap);
         TA_STAMP(b, 0, 6);
         return;
       }
       // several forward launches (one per beta): the sums travel through part4 as before
       if (active) {
         const int64_t p = (int64_t)s0 + threadIdx.x;
+        int pidx = threadIdx.x;
+        bool holds = true;  // NSPEC == 1: the first pair of every group of four carries the group's sum
+        if constexpr (NSPEC == 1) {
+          const int ci = b.pair_i[p] - c0, rel = (int)threadIdx.x - jl.hist[40 + ci];
+          pidx = jl.hist[60 + ci] + (rel >> 2);
+          holds = (rel & 3) == 0;
+        }
 #pragma unroll
         for (int sp = 0; sp < NSPEC; ++sp)
 #pragma unroll
           for (int gz = 0; gz < NG * NZ; ++gz)
-            b.part4[(size_t)(sp * sf.n_ang + ch.chan[gz]) * b.n_pairs + p] = P[(size_t)(sp * NG * NZ + gz) * kCap + threadIdx.x];
+            b.part4[(size_t)(sp * sf.n_ang + ch.chan[gz]) * b.n_pairs + p] =
+                holds ? P[(size_t)(sp * NG * NZ + gz) * v2_pcols(kCap, NSPEC) + pidx] : 0.0;
       }
     } else {
     deal_by_popcount(f, kCap, M, item, mask);
@@ -843,13 +880,13 @@ __global__ __launch_bounds__(kBlock)
   }
 }
 
-template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP>
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP, int WPE = (DEFZ ? (NSPEC <= 2 ? 5 : 4) : 0)>
 // Occupancy: the backward body is latency-bound at the 3 wavefronts per SIMD the compiler settles for
 // (133 VGPRs); asking for 5 (96 VGPRs, 10 spilled) measured 72 -> 66 us on the benchmark frame and
 // 51 -> 45 us per frame in batches (4: 69 / 47, 6: 68 / 45). Only the default-grid instantiations
 // are constrained; the generic ones keep the compiler's choice.
 __global__ __launch_bounds__(kBlock)
-    __attribute__((amdgpu_waves_per_eu(DEFZ ? (NSPEC <= 2 ? 5 : 4) : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
+    __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, 8))) void backward_v2_kernel(SFParams sf, AngChunk ch,
                                                              DeviceBatch b, int flags) {
   static_assert(!DEFZ || NZ == 2, "DEFZ needs the two-zeta grid");
   const int first = flags & 1;
@@ -858,8 +895,8 @@ __global__ __launch_bounds__(kBlock)
   extern __shared__ double lds[];
   const int kCap = CAP > 0 ? CAP : b.cap;  // multiple of 64
   const Fields f = carve(lds, kCap);
-  // partner accumulators sit behind the float copies and species bytes, 8-byte aligned
-  double *gacc = lds + kNF * kCap + (3 * (2 * kCap + kRingPad)) / 2 + kCap / 8;
+  // partner accumulators behind the fields (kCap bytes in between hold the centres' first pairs, `cstart`)
+  double *gacc = lds + kNF * kCap + kCap / 8;
   const int slot = b.blk_groups > 0 ? 16 * ((int)blockIdx.x % b.blk_groups) + (int)blockIdx.x / b.blk_groups
                                     : (int)blockIdx.x;
   const int c0 = b.blk_center[slot], c1 = b.blk_center[slot + 1];
@@ -1078,9 +1115,7 @@ __global__ __launch_bounds__(kBlock)
     } else {
     const int smax = (Ha != 0.0) ? n / 2 : 0;
     for (int sc = 1; sc <= smax; sc += 64) {
-      unsigned long long mask = have_mask ? mask0
-                                : (b.masks ? b.masks[(size_t)(sc >> 6) * b.n_pairs + p]
-                                           : partner_mask(sf, f, base, n, a, sc, smax));
+      unsigned long long mask = have_mask ? mask0 : b.masks[(size_t)(sc >> 6) * b.n_pairs + p];
       if (flags & (1 << 24)) mask = 0ull;
       while (mask) {
         const int k = __ffsll((long long)mask) - 1;
@@ -1126,13 +1161,11 @@ __global__ __launch_bounds__(kBlock)
       unsigned long long mask = 0ull;
       if (active) {
         const int64_t p = (int64_t)s0 + item;
-        const int i = b.pair_i[p];
-        const int base = b.pair_start[i] - s0;
         const int smax = (f.ih[item].y != 0.0) ? n_own / 2 : 0;
-        if (smax > 0)
-          mask = b.masks ? b.masks[p] : partner_mask(sf, f, base, n_own, item - base, 1, smax);
+        if (smax > 0) mask = b.masks[p];  // the forward kernel's candidate mask (always stored)
       }
-      deal_by_popcount(f, kCap, M, item, mask);
+      // (no re-dealing by popcount here: its scratch lived in the rings, which this kernel no longer has;
+      // this path runs only with TA_NO_JOBS=1)
       if (active) run_item(item, true, mask, std::false_type{});
     } else {
       for (int it = threadIdx.x; it < M; it += blockDim.x) run_item(it, false, 0ull, std::false_type{});
@@ -1189,12 +1222,26 @@ __global__ __launch_bounds__(kBlock)
 template <int NSPEC, int NG, int NZ>
 void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geom, hipStream_t s) {
   const dim3 grid((unsigned)b.n_blk), block((unsigned)(b.cap < kBlock ? b.cap : kBlock));
-  const size_t lds = v2_lds_bytes(false, b.cap, b.job_count ? NSPEC * NG * NZ : 0);
+  const size_t lds = v2_lds_bytes(false, b.cap, b.job_count ? NSPEC * NG * NZ : 0, NSPEC);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      if (b.cap == kCapMin)
+      if (b.cap == kCapMin) {
+        // One-element models take the 80-register build (6 wavefronts per SIMD, 19 spilled dwords): with the
+        // compact partial sums (18 KB of LDS) 8 workgroups share a CU and the 2006 workgroups of the
+        // 4000-atom frame are resident at once (they enter within 1.7 us instead of 22 us: before, 1536 ran
+        // and the rest followed as a second lock-step round) -- forward 45.3 -> 41.6 us for one frame, and
+        // 26.9 -> 24.8 us per frame in 64-frame batches, where the extra wavefront per SIMD hides more of
+        // the LDS latency of the sweep. TA_FWD_WPE=5 selects the 96-register build (A/B).
+        static const int force = getenv("TA_FWD_WPE") ? atoi(getenv("TA_FWD_WPE")) : 0;
+        if constexpr (NSPEC == 1) {
+          if (force != 5) {
+            hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin, 6>), grid, block, lds, s, sf, ch,
+                               b, geom);
+            return;
+          }
+        }
         hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin>), grid, block, lds, s, sf, ch, b, geom);
-      else
+      } else
         hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, 0>), grid, block, lds, s, sf, ch, b, geom);
       return;
     }
@@ -1216,9 +1263,20 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
   const size_t lds = v2_lds_bytes(true, b.cap);
   if constexpr (NZ == 2) {
     if (ch.n_hd == 12 && ch.zeta_int[0] == 1 && ch.zeta_int[1] == 4) {
-      if (b.cap == kCapMin)
+      if (b.cap == kCapMin) {
+        // (the 80-register build of this kernel, which also lets every workgroup of one frame be resident at
+        // once, measured the same as the 96-register one: 48.9-49.3 against 49.5 us for one frame, 33.1
+        // against 33.1 us per frame in batches; TA_BWD_WPE=6 selects it)
+        static const int force = getenv("TA_BWD_WPE") ? atoi(getenv("TA_BWD_WPE")) : 0;
+        if constexpr (NSPEC == 1) {
+          if (force == 6) {
+            hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin, 6>), grid, block, lds, s, sf, ch,
+                               b, first);
+            return;
+          }
+        }
         hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin>), grid, block, lds, s, sf, ch, b, first);
-      else
+      } else
         hipLaunchKernelGGL((backward_v2_kernel<NSPEC, NG, NZ, 12, true, 0>), grid, block, lds, s, sf, ch, b, first);
       return;
     }
@@ -1238,10 +1296,13 @@ void bwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int fir
 }  // namespace
 
 // n_local > 0: forward launch in job mode (counters + per-pair partial sums behind the fields)
-size_t v2_lds_bytes(bool backward, int cap, int n_local) {
-  if (!backward && n_local > 0) return v2_counter_offset(cap) + kJobCtlBytes + (size_t)n_local * cap * sizeof(double);
-  return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap +
-         (backward ? 3 * (size_t)cap * sizeof(double) + kMaxCentersPerBlock * (5 + kRTab) * sizeof(double) : 0);
+size_t v2_lds_bytes(bool backward, int cap, int n_local, int nspec) {
+  if (!backward && n_local > 0)
+    return v2_counter_offset(cap) + kJobCtlBytes + (size_t)n_local * v2_pcols(cap, nspec) * sizeof(double);
+  if (backward)  // fields, cstart gap, three accumulator planes, the per-centre tables
+    return (size_t)cap * kNF * sizeof(double) + cap + 3 * (size_t)cap * sizeof(double) +
+           kMaxCentersPerBlock * (5 + kRTab) * sizeof(double);
+  return (size_t)cap * kNF * sizeof(double) + 3 * (size_t)(2 * cap + kRingPad) * sizeof(float) + cap;
 }
 int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 
