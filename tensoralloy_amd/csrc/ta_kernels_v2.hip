@@ -46,12 +46,19 @@ constexpr int kBlock = 256;  // upper bound; launched with min(cap, 256) lanes
 constexpr int kNF = 8;   // backward: {z r2} {x y} {inv_r H} {G species}: four 16-byte records per pair
 constexpr int kNFf = 7;  // forward: the last record is the species alone (8 bytes): 1.5 KB of LDS less,
                          // which with the trimmed job counters lets 7 workgroups share a CU instead of 6
-constexpr int kJobCtlBytes = 320;  // hist[17 (+3)], start[17 (+3)] ints of make_jobs, cstart[17 (+3)], cslot[17 (+3)]
-// One-element models: the per-pair partial G4 sums of the forward sweep are kept per GROUP OF FOUR pairs of
-// a centre (they are only ever summed over the centre), 4 x (cap / 4 + 16) doubles instead of 4 x cap:
-// 22.0 -> 18.0 KB of LDS per workgroup, i.e. 8 instead of 7 workgroups per CU -- with 6 wavefronts per SIMD
-// (80 VGPRs) all 2006 workgroups of the 4000-atom frame are resident at once instead of 1536 + a second round.
-__host__ __device__ inline int v2_pcols(int cap, int nspec) { return nspec == 1 ? cap / 4 + kMaxCentersPerBlock : cap; }
+// control words of the forward kernel's job mode, as ints: hist[20] start[20] (make_jobs), cstart[20] (first
+// pair of every centre of the workgroup), then segl[16][kSegW] (first pair of every (centre, neighbour species)
+// segment, + the centre's end) and sslot[16][kSegW] (first partial-sum slot of the segment)
+constexpr int kSegW = 6;  // up to 5 species + the end
+constexpr int kJobCtlBytes = (60 + 2 * kMaxCentersPerBlock * kSegW) * 4;
+// The per-pair partial G4 sums of the forward sweep are only ever summed over a (centre, neighbour species)
+// segment, so they are kept per GROUP OF FOUR pairs of a segment: n_local x (cap / 4 + 16 nspec) doubles
+// instead of n_local x cap (one element: 22.0 -> 18.0 KB of LDS per workgroup, 8 instead of 7 workgroups per
+// CU -- with 6 wavefronts per SIMD all 2006 workgroups of the 4000-atom frame are resident at once; two
+// elements: 28.7 -> 22.3 KB).
+__host__ __device__ inline int v2_pcols(int cap, int nspec) {
+  return nspec >= 1 ? cap / 4 + kMaxCentersPerBlock * nspec : cap;
+}
 constexpr int kRingPad = 64;  // floats readable past the last ring (masked candidates)
 constexpr int kRTab = 8;      // backward: radial dE/dG values per centre kept in LDS (neighbour species x radial channels)
 
@@ -475,7 +482,7 @@ __device__ __forceinline__ void reduce_angular_from_lds(const SFParams &sf, cons
 // column of partner species B over the pairs of species A, summed by the same row (one store).
 template <int NSPEC, int NG, int NZ>
 __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b,
-                                              const Fields &f, const double *P, const int *cslot, int c0, int c1,
+                                              const Fields &f, const double *P, const int *sslot, int c0, int c1,
                                               int s0, int item, bool active, bool skip_radial, int cap) {
   constexpr int kGZ = NG * NZ;
   constexpr int kTerms = NSPEC * (NSPEC + 1) / 2;
@@ -532,17 +539,13 @@ __device__ __forceinline__ void assemble_flat(const SFParams &sf, const AngChunk
         int sa = 0, sb = 0;  // term index -> (sa <= sb), row-major upper triangle
         for (int rem = term, len = NSPEC; rem >= len; rem -= len, --len) ++sa;
         sb = term - (sa * NSPEC - (sa * (sa - 1)) / 2) + sa;
-        if constexpr (NSPEC == 1) {
-          // one partial-sum slot per four pairs of the centre (v2_pcols, cslot)
-          const double *colA = P + (size_t)gz * v2_pcols(cap, 1);
-          for (int q = cslot[ci] + l; q < cslot[ci + 1]; q += 16) v += colA[q];
-        } else {
-          const double *colA = P + (size_t)(sa * kGZ + gz) * cap;  // partner species sa, pairs of species sb
-          for (int q = seg[sb] - s0 + l; q < seg[sb + 1] - s0; q += 16) v += colA[q];
-          if (sa != sb) {
-            const double *colB = P + (size_t)(sb * kGZ + gz) * cap;
-            for (int q = seg[sa] - s0 + l; q < seg[sa + 1] - s0; q += 16) v += colB[q];
-          }
+        // one partial-sum slot per four pairs of a (centre, neighbour species) segment (v2_pcols, sslot)
+        const int *ss = sslot + ci * kSegW;
+        const double *colA = P + (size_t)(sa * kGZ + gz) * v2_pcols(cap, NSPEC);  // partner species sa, pairs of sb
+        for (int q = ss[sb] + l; q < ss[sb + 1]; q += 16) v += colA[q];
+        if (sa != sb) {
+          const double *colB = P + (size_t)(sb * kGZ + gz) * v2_pcols(cap, NSPEC);
+          for (int q = ss[sa] + l; q < ss[sa + 1]; q += 16) v += colB[q];
         }
         v = row16_sum(v);
         if (l == 0) Gi[sf.n_radial_dim + term * sf.n_ang + ch.chan[gz]] = v * sf.ang_scale;
@@ -568,7 +571,7 @@ __device__ __forceinline__ void stagger(int flags) {
 // and the accumulator updates of the triple bodies address them as one shifted index + immediate
 // offsets instead of one address computation each (six VALU instructions per backward triple).
 // WPE: wavefronts per SIMD asked of the register allocator (0 = the compiler's choice)
-template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP, int WPE = (DEFZ && NSPEC == 1 ? 5 : 0)>
+template <int NSPEC, int NG, int NZ, int HD, bool DEFZ, int CAP, int WPE = (DEFZ && NSPEC <= 2 ? 5 : 0)>
 __global__ __launch_bounds__(kBlock)
     __attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, 8))) void g4_forward_v2_kernel(SFParams sf, AngChunk ch,
                                                                DeviceBatch b, int flags) {
@@ -592,23 +595,28 @@ __global__ __launch_bounds__(kBlock)
     if (threadIdx.x < 40) cnt[threadIdx.x] = 0;
     else if (threadIdx.x < 40 + 17 && (int)threadIdx.x - 40 <= c1 - c0)  // cstart[k]: first pair of centre c0 + k
       cnt[threadIdx.x] = ((int)threadIdx.x - 40 < c1 - c0 ? b.pair_start[c0 + threadIdx.x - 40] : s0 + M) - s0;
+    else if (threadIdx.x >= 64 && (int)threadIdx.x - 64 < (c1 - c0) * (NSPEC + 1)) {  // segl[k][sg]
+      const int k = ((int)threadIdx.x - 64) / (NSPEC + 1), sg = ((int)threadIdx.x - 64) % (NSPEC + 1);
+      cnt[60 + k * kSegW + sg] = b.seg_start[(size_t)(c0 + k) * (NSPEC + 1) + sg] - s0;
+    }
     double *P0 = reinterpret_cast<double *>(raw + v2_counter_offset(kCap) + kJobCtlBytes);
     for (int k = threadIdx.x; k < NSPEC * NG * NZ * v2_pcols(kCap, NSPEC); k += blockDim.x) P0[k] = 0.0;
   }
   TA_STAMP(b, 0, 0);
   stage<HD>(sf, ch, beta, b, f, s0, M, geom, true);
   TA_STAMP(b, 0, 1);
-  if (NSPEC == 1 && b.job_count && threadIdx.x == 0) {
-    // cslot[k]: first partial-sum slot of centre c0 + k (one slot per four pairs, see v2_pcols); read by the
-    // sweep and the assembly, both behind the barriers of make_jobs
+  if (b.job_count && threadIdx.x == 0) {
+    // sslot[k][sg]: first partial-sum slot of segment (centre c0 + k, neighbour species sg), one slot per
+    // four pairs (v2_pcols); read by the sweep and the assembly, both behind the barriers of make_jobs
     int *ctl = reinterpret_cast<int *>(reinterpret_cast<char *>(lds) + v2_counter_offset(kCap));
-    const int *cs = ctl + 40;
-    int *cslot = ctl + 60;
+    const int *segl = ctl + 60;
+    int *sslot = ctl + 60 + kMaxCentersPerBlock * kSegW;
     int acc = 0;
-    for (int k = 0; k <= c1 - c0; ++k) {
-      cslot[k] = acc;
-      if (k < c1 - c0) acc += (cs[k + 1] - cs[k] + 3) >> 2;
-    }
+    for (int k = 0; k < c1 - c0; ++k)
+      for (int sg = 0; sg <= NSPEC; ++sg) {
+        sslot[k * kSegW + sg] = acc;
+        if (sg < NSPEC) acc += (segl[k * kSegW + sg + 1] - segl[k * kSegW + sg] + 3) >> 2;
+      }
   }
 
   // one job = one directed pair (i, a); `have_mask`: the single scan pass was done up front
@@ -626,7 +634,11 @@ __global__ __launch_bounds__(kBlock)
       const int ci = job_centre((uint32_t)mask0);
       base = cstart[ci];
       n = cstart[ci + 1] - base;
-      if constexpr (NSPEC == 1) pslot = cstart[20 + ci] + ((item - base) >> 2);
+      {
+        const int *segl = cstart + 20, *sslot = segl + kMaxCentersPerBlock * kSegW;
+        const int sg = NSPEC == 1 ? 0 : (int)f.sp1[item];
+        pslot = sslot[ci * kSegW + sg] + ((item - segl[ci * kSegW + sg]) >> 2);
+      }
     } else {
       const int i = b.pair_i[p];
       base = b.pair_start[i] - s0;
@@ -797,7 +809,7 @@ __global__ __launch_bounds__(kBlock)
       __syncthreads();
       TA_STAMP(b, 0, 5);
       if (flags & 4) {
-        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, jl.hist + 60, c0, c1, s0, item, active,
+        assemble_flat<NSPEC, NG, NZ>(sf, ch, b, f, P, jl.hist + 60 + kMaxCentersPerBlock * kSegW, c0, c1, s0, item, active,
                                      (flags & (1 << 26)) != 0, kCap);
         TA_STAMP(b, 0, 6);
         return;
@@ -805,13 +817,12 @@ __global__ __launch_bounds__(kBlock)
       // several forward launches (one per beta): the sums travel through part4 as before
       if (active) {
         const int64_t p = (int64_t)s0 + threadIdx.x;
-        int pidx = threadIdx.x;
-        bool holds = true;  // NSPEC == 1: the first pair of every group of four carries the group's sum
-        if constexpr (NSPEC == 1) {
-          const int ci = b.pair_i[p] - c0, rel = (int)threadIdx.x - jl.hist[40 + ci];
-          pidx = jl.hist[60 + ci] + (rel >> 2);
-          holds = (rel & 3) == 0;
-        }
+        // the first pair of every group of four carries the group's sum, the others zero
+        const int ci = b.pair_i[p] - c0, sg = NSPEC == 1 ? 0 : (int)f.sp1[threadIdx.x];
+        const int *segl = jl.hist + 60, *sslot = segl + kMaxCentersPerBlock * kSegW;
+        const int rel = (int)threadIdx.x - segl[ci * kSegW + sg];
+        const int pidx = sslot[ci * kSegW + sg] + (rel >> 2);
+        const bool holds = (rel & 3) == 0;
 #pragma unroll
         for (int sp = 0; sp < NSPEC; ++sp)
 #pragma unroll
@@ -1233,8 +1244,8 @@ void fwd_t(const SFParams &sf, const AngChunk &ch, const DeviceBatch &b, int geo
         // 26.9 -> 24.8 us per frame in 64-frame batches, where the extra wavefront per SIMD hides more of
         // the LDS latency of the sweep. TA_FWD_WPE=5 selects the 96-register build (A/B).
         static const int force = getenv("TA_FWD_WPE") ? atoi(getenv("TA_FWD_WPE")) : 0;
-        if constexpr (NSPEC == 1) {
-          if (force != 5) {
+        if constexpr (NSPEC <= 2) {
+          if (force != 5) {  // (two elements: 55.6 -> 54.2 us for one Ni-Mo frame, 34.9 -> 34.1 us per frame at 16)
             hipLaunchKernelGGL((g4_forward_v2_kernel<NSPEC, NG, NZ, 12, true, kCapMin, 6>), grid, block, lds, s, sf, ch,
                                b, geom);
             return;
@@ -1309,8 +1320,10 @@ int v2_job_stride(int cap) { return v2_max_jobs(cap); }
 #ifdef TA_V2_FEW  // experiment builds (ISA inspection, quick A/B): the benchmark shape only
 #define TA_DISPATCH_V2(FN, ...)                                   \
   do {                                                            \
-    if (nspec * 100 + ng * 10 + nz != 122) throw std::domain_error("TA_V2_FEW build"); \
-    FN<1, 2, 2>(__VA_ARGS__);                                     \
+    const int key = nspec * 100 + ng * 10 + nz;                   \
+    if (key == 122) FN<1, 2, 2>(__VA_ARGS__);                     \
+    else if (key == 222) FN<2, 2, 2>(__VA_ARGS__);                \
+    else throw std::domain_error("TA_V2_FEW build");              \
   } while (0)
 #else
 #define TA_DISPATCH_V2(FN, ...)                                   \
