@@ -11,7 +11,7 @@ want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 atoms = ni_frame(611)
 with Engine(ni_model()) as eng:
-    eng.set_skin(0.5)
+    eng.set_skin(float(os.environ.get("TA_MD_SKIN", "0.5")))   # 0: a new list every step
     eng.set_frames([atoms])
     pos = np.ascontiguousarray(atoms.positions)
     for k in range(steps + 5):

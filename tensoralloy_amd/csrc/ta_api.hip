@@ -150,6 +150,26 @@ void staged_copy(double *dst, const double *src, size_t n, bool to_host, hipStre
   HIP_CHECK(hipGetLastError());
 }
 
+// Wait for the stream on the latency-critical paths (one MD step has three waits around ~50 us kernels):
+// poll the stream for a short while before blocking, since a blocked thread is woken by an interrupt
+// many microseconds after the work is done. TA_SYNC_BLOCKING=1 goes straight to the blocking wait.
+void wait_stream(hipStream_t s) {
+  static const bool blocking = std::getenv("TA_SYNC_BLOCKING") && std::getenv("TA_SYNC_BLOCKING")[0] == '1';
+  if (!blocking) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) {
+        (void)hipGetLastError();
+        break;  // let the blocking wait report it
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
 // grow-only page-locked host buffer (staging for the packed uploads / downloads)
 struct PinnedBuf {
   char *ptr = nullptr;
@@ -215,7 +235,9 @@ struct ta_context {
   ta::NlGrid *d_grids = nullptr;  // view into inbuf
   // device neighbour list (ta_nlist.hip)
   DevBuf<int32_t> nl_wrap, nl_binid, nl_bin_count, nl_bin_start, nl_bin_cursor, nl_bin_atoms, nl_counts;
-  DevBuf<unsigned long long> nl_stats;
+  DevBuf<unsigned long long> nl_stats, nl_zero;
+  unsigned long long *nl_stats_ptr = nullptr;  // statistics block of the builder that made the list
+  bool nl_sorted = false;  // list in key order (one-pass builder): reverse pairs by binary search
   DevBuf<double> hvp_buf;  // ta_hessian_vectors: tangents in, force / virial tangents out
 #ifdef TA_PHASE_STAMPS
   DevBuf<unsigned long long> stamp_buf;
@@ -567,9 +589,14 @@ ta::NlWork nl_work(ta_context *h) {
                     h->seg_start.ptr,     h->nl_stats.ptr};
 }
 
-// Neighbour list on the device, part 1: bins, per-atom counts, segment offsets. Leaves the
-// counts in h->hp (n_pairs, n_triples, nnl_max, pair_start) for the sizing done by the caller.
-// The packed input (positions, species, grids ...) is already on its way to the device.
+// Neighbour list on the device, part 1. Leaves the counts in h->hp (n_pairs, n_triples, nnl_max,
+// pair_start) for the sizing done by the caller. The packed input (positions, species, grids ...) is
+// already on its way to the device.
+//
+// One-pass builder (ta_nlist.hip::nl_build) first: it also WRITES the pairs (key order) while they fit
+// the pair arrays as they stand; when they do not (first batch, or a list that grew) the arrays grow and
+// it runs again. The two-pass builder (count, sizes to the host, fill) stays for what the one-pass one
+// declines: more than 384 neighbours per atom, shifts beyond +-511 cells, TA_NL_TWO_PASS=1.
 void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   using namespace ta;
   HostPairs &hp = h->hp;
@@ -577,31 +604,65 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   const int nel = h->n_elements;
   h->nl_wrap.ensure(3 * N);
   h->nl_binid.ensure(N);
-  h->nl_bin_count.ensure((size_t)n_bins + 1);
   h->nl_bin_start.ensure((size_t)n_bins + 1);
-  h->nl_bin_cursor.ensure((size_t)n_bins + 1);
   h->nl_bin_atoms.ensure(N);
   h->nl_recs.ensure(N);
-  h->nl_counts.ensure(N * (nel + 1) + 1);
   h->seg_start.ensure(N * (nel + 1) + 1);
   h->pair_start.ensure(N + 1);
-  h->nl_stats.ensure(8);
-  NlWork w = nl_work(h);
-  nl_count((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
-           h->pair_start.ptr, s);
-  HIP_CHECK(hipGetLastError());
   // counts and per-atom offsets come back through page-locked memory
   h->stage_out.ensure(64 + (N + 1) * sizeof(int32_t));
   unsigned long long *stats = reinterpret_cast<unsigned long long *>(h->stage_out.ptr);
   int32_t *starts = reinterpret_cast<int32_t *>(h->stage_out.ptr + 64);
-  HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipMemcpyAsync(starts, h->pair_start.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
   const int32_t *si = reinterpret_cast<const int32_t *>(stats);
-  if (stats[4] > (unsigned long long)INT32_MAX || si[4] < 0 || (unsigned long long)si[4] != stats[4])
-    throw std::runtime_error("batch too large for 32-bit pair indices");
+  const bool two_pass_only = std::getenv("TA_NL_TWO_PASS") && std::getenv("TA_NL_TWO_PASS")[0] == '1';
+  h->nl_sorted = false;
+  const bool kernel_writes_host = !(std::getenv("TA_NL_COPY_STARTS") && std::getenv("TA_NL_COPY_STARTS")[0] == '1');
+  if (!two_pass_only) {
+    h->nl_zero.ensure(nl_build_zero_words((int)N, n_bins));
+    for (int attempt = 0; attempt < 2 && !h->nl_sorted; ++attempt) {
+      const size_t capacity = std::min(std::min(h->pair_i.cap, h->pair_j.cap), h->pair_shift.cap / 3);
+      NlWork w = nl_work(h);
+      // the kernel writes the per-atom offsets to the page-locked buffer itself; the statistics follow
+      // in one small copy kernel once every group is through
+      nl_build((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
+               h->nl_zero.ptr, (long long)std::min<size_t>(capacity, (size_t)INT32_MAX), h->pair_start.ptr,
+               kernel_writes_host ? starts : nullptr, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr, s);
+      HIP_CHECK(hipGetLastError());
+      if (!kernel_writes_host)
+        staged_copy(reinterpret_cast<double *>(starts), reinterpret_cast<const double *>(h->pair_start.ptr),
+                    (N + 2) / 2, true, s);
+      staged_copy(reinterpret_cast<double *>(stats), reinterpret_cast<const double *>(h->nl_zero.ptr), 8, true, s);
+      wait_stream(s);
+      if (si[3] != 0) break;  // beyond the one-pass builder's limits
+      if (stats[4] > (unsigned long long)INT32_MAX) throw std::runtime_error("batch too large for 32-bit pair indices");
+      if (stats[4] <= capacity) {
+        h->nl_sorted = true;
+      } else {
+        h->pair_i.ensure((size_t)stats[4]);
+        h->pair_j.ensure((size_t)stats[4]);
+        h->pair_shift.ensure(3 * (size_t)stats[4]);
+      }
+    }
+    if (h->nl_sorted) h->nl_stats_ptr = h->nl_zero.ptr;
+  }
+  if (!h->nl_sorted) {
+    h->nl_bin_count.ensure((size_t)n_bins + 1);
+    h->nl_bin_cursor.ensure((size_t)n_bins + 1);
+    h->nl_counts.ensure(N * (nel + 1) + 1);
+    h->nl_stats.ensure(8);
+    NlWork w = nl_work(h);
+    nl_count((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
+             h->pair_start.ptr, s);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(stats, h->nl_stats.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(starts, h->pair_start.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (stats[4] > (unsigned long long)INT32_MAX || si[4] < 0 || (unsigned long long)si[4] != stats[4])
+      throw std::runtime_error("batch too large for 32-bit pair indices");
+    h->nl_stats_ptr = h->nl_stats.ptr;
+  }
   hp.n_atoms = (int64_t)N;
-  hp.n_pairs = si[4];
+  hp.n_pairs = (int64_t)stats[4];
   hp.n_triples = (int64_t)stats[0];
   hp.nnl_max = si[2];
   hp.pair_start.assign(starts, starts + N + 1);
@@ -613,13 +674,18 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   h->pairs_on_device = true;
 }
 
-// part 2, after the pair buffers are sized: write the pairs and the reverse index
+// part 2, after the pair buffers are sized: the pairs (two-pass builder only) and the reverse index
 void fill_pairs_on_device(ta_context *h) {
   using namespace ta;
-  NlWork w = nl_work(h);
-  nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->r_list, h->db.pos, h->db.species,
-          h->db.frame_of_atom, h->d_grids, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
-          h->pair_rev.ptr, h->stream);
+  if (h->nl_sorted) {
+    nl_reverse_sorted(h->hp.n_pairs, h->n_elements, h->db.species, h->seg_start.ptr, h->pair_i.ptr,
+                      h->pair_j.ptr, h->pair_shift.ptr, h->pair_rev.ptr, h->nl_stats_ptr, h->stream);
+  } else {
+    NlWork w = nl_work(h);
+    nl_fill((int)h->hp.n_atoms, h->hp.n_pairs, h->n_elements, h->r_list, h->db.pos, h->db.species,
+            h->db.frame_of_atom, h->d_grids, w, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
+            h->pair_rev.ptr, h->stream);
+  }
   HIP_CHECK(hipGetLastError());
 }
 
@@ -910,6 +976,7 @@ int ta_destroy(ta_handle h) {
                   &h->nl_bin_atoms, &h->nl_counts})
     b->release();
   h->nl_stats.release();
+  h->nl_zero.release();
   h->hvp_buf.release();
   h->nl_recs.release();
   for (auto &e : h->ev)
@@ -1100,8 +1167,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   if (h->pairs_on_device) {
     fill_pairs_on_device(h);
     // "reverse pair missing" counter, read after the synchronisation below
-    HIP_CHECK(hipMemcpyAsync(h->stage_out.ptr, h->nl_stats.ptr, 8 * sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost, h->stream));
+    staged_copy(reinterpret_cast<double *>(h->stage_out.ptr), reinterpret_cast<const double *>(h->nl_stats_ptr),
+                8, true, h->stream);
   }
   // second-generation angular kernels: workgroups own whole centres (<= kCap pairs)
   // second-generation kernels: 1-3 elements for every channel grid; 4 and 5 elements for
@@ -1150,7 +1217,7 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   } else {
     ta::eam_ensure(h->eam, h->db);
   }
-  HIP_CHECK(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next call
+  wait_stream(h->stream);  // staging buffers are reused by the next call
   if (h->pairs_on_device) {
     nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
     if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
@@ -1327,7 +1394,7 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, 
     if (descriptors && N)
       HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double),
                                hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     if (energy && F) std::memcpy(energy, stage, F * sizeof(double));
     if (virial && F) std::memcpy(virial, stage + F, 9 * F * sizeof(double));
     if (atomic && N) std::memcpy(atomic, stage + 10 * F, N * sizeof(double));

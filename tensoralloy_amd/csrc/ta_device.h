@@ -218,6 +218,14 @@ int nl_bins(const NlGrid &g);
 void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, int32_t *pair_start,
               hipStream_t s);
+size_t nl_build_zero_words(int n_atoms, int n_bins);
+void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
+              const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
+              long long capacity, int32_t *pair_start, int32_t *host_pair_start, int32_t *pair_i,
+              int32_t *pair_j, int32_t *pair_shift, hipStream_t s);
+void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
+                       const int32_t *pair_i, const int32_t *pair_j, const int32_t *pair_shift,
+                       int32_t *pair_rev, unsigned long long *stats, hipStream_t s);
 int nl_filter_blocks(int n_atoms);
 void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double *pos, const double *cells,
                const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super,

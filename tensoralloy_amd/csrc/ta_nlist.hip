@@ -35,7 +35,8 @@ constexpr int kBlock = 256;
 __global__ __launch_bounds__(kBlock) void bin_atoms_kernel(int n_atoms, const double *pos,
                                                            const int32_t *frame_of_atom,
                                                            const NlGrid *grids, int32_t *wrap,
-                                                           int32_t *binid, int32_t *bin_count) {
+                                                           int32_t *binid, int32_t *bin_count,
+                                                           int32_t *slot_in_bin) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_atoms) return;
   const NlGrid &g = grids[frame_of_atom[i]];
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(kBlock) void bin_atoms_kernel(int n_atoms, const do
   }
   const int id = g.bin_offset + (b[0] * g.nb[1] + b[1]) * g.nb[2] + b[2];
   binid[i] = id;
-  atomicAdd(&bin_count[id], 1);
+  const int sl = atomicAdd(&bin_count[id], 1);
+  if (slot_in_bin) slot_in_bin[i] = sl;  // one-pass builder: place in the bin as the atomics arrive
 }
 
 // inclusive scan of one int per lane over the 1024 lanes of a workgroup: wavefront scans by
@@ -320,6 +322,302 @@ __global__ __launch_bounds__(kBlock) void reverse_pairs_kernel(int64_t n_pairs, 
   }
 }
 
+// ---- One-pass builder (round 3) ------------------------------------------------------------------
+// The two-pass builder above traverses the bins twice (count, prefix sum over the batch, fill) and then
+// finds every reverse pair by a linear search: 108 us of a 4000-atom frame's 155 us. Here ONE traversal
+// per centre keeps the neighbours it finds in LDS as 64-bit keys {species, j, S}, a workgroup of 16
+// centres learns its offset in the pair arrays from the groups before it (decoupled look-back over one
+// 64-bit word per group, a wavefront reading 64 predecessors at a time), and the neighbours leave in
+// KEY ORDER: sorted by species, then j, then S. The order inside a (centre, species) segment is thereby
+// canonical (independent of the binning and of the order atomics arrived in, so the bins need no
+// ranking pass), and the reverse pair (j -> i, -S) is a binary search in j's segment.
+//
+// Limits of this path (the two-pass builder takes over beyond them, see `bad` below): at most
+// kBuildStash neighbours per centre, |S| < kShiftBias per axis.
+constexpr int kBuildGroup = 16;    // centres per workgroup, one wavefront each
+constexpr int kBuildStash = 384;   // neighbours per centre kept in LDS
+constexpr int kShiftBias = 512;    // S + bias in 10 bits per axis
+constexpr unsigned long long kStateMask = (1ull << 62) - 1ull;
+constexpr unsigned long long kStateSum = 1ull << 62;     // value = pairs of this group
+constexpr unsigned long long kStatePrefix = 2ull << 62;  // value = pairs of groups 0 .. this one
+constexpr int kSpinLimit = 1 << 19;  // look-back polls before giving up (a second or so)
+
+__device__ __forceinline__ unsigned long long nl_key(int sp, int j, int sx, int sy, int sz) {
+  return ((unsigned long long)(unsigned)sp << 61) | ((unsigned long long)(unsigned)j << 30) |
+         ((unsigned long long)(unsigned)(sx + kShiftBias) << 20) |
+         ((unsigned long long)(unsigned)(sy + kShiftBias) << 10) | (unsigned long long)(unsigned)(sz + kShiftBias);
+}
+
+__global__ __launch_bounds__(kBlock) void place_recs_kernel(int n_atoms, const double *pos,
+                                                            const int32_t *species, const int32_t *wrap,
+                                                            const int32_t *binid, const int32_t *bin_start,
+                                                            const int32_t *slot_in_bin, NlRec *recs) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_atoms) return;
+  NlRec r;
+  r.x = pos[3 * (size_t)i];
+  r.y = pos[3 * (size_t)i + 1];
+  r.z = pos[3 * (size_t)i + 2];
+  r.wx = wrap[3 * (size_t)i];
+  r.wy = wrap[3 * (size_t)i + 1];
+  r.wz = wrap[3 * (size_t)i + 2];
+  r.j = i;
+  r.sp = species[i];
+  r.pad_ = 0;
+  recs[bin_start[binid[i]] + slot_in_bin[i]] = r;
+}
+
+// stats (8 x u64, zero before the launch): [0] triples; as int32: [2] nnl_max, [3] `bad` (a centre beyond
+// the limits, or the look-back gave up: use the two-pass builder), [6] reverse pairs missing; [4] pairs.
+__global__ __launch_bounds__(64 * kBuildGroup) void build_pairs_kernel(
+    int n_atoms, int nel, double rmax, const double *pos, const int32_t *frame_of_atom, const NlGrid *grids,
+    const int32_t *wrap, const int32_t *binid, const int32_t *bin_start, const NlRec *recs,
+    unsigned long long *gstate, long long capacity, int32_t *seg_start, int32_t *pair_start,
+    int32_t *host_pair_start, int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift,
+    unsigned long long *stats) {
+  __shared__ unsigned long long stash[kBuildGroup][kBuildStash];
+  __shared__ unsigned short rank16[kBuildGroup][kBuildStash];
+  __shared__ int cnt[kBuildGroup], cstart[kBuildGroup];
+  __shared__ long long s_base;
+  __shared__ int s_write;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * kBuildGroup + w);
+  const bool act = i < n_atoms;
+  unsigned long long *mine = stash[w];
+  int n = 0;
+  bool bad = false;
+  if (act) {
+    const NlGrid &g = grids[__builtin_amdgcn_readfirstlane(frame_of_atom[i])];
+    const int local = binid[i] - g.bin_offset;
+    const int bz = local % g.nb[2], by = (local / g.nb[2]) % g.nb[1], bx = local / (g.nb[2] * g.nb[1]);
+    const double rix = pos[3 * (size_t)i], riy = pos[3 * (size_t)i + 1], riz = pos[3 * (size_t)i + 2];
+    const int wix = wrap[3 * (size_t)i], wiy = wrap[3 * (size_t)i + 1], wiz = wrap[3 * (size_t)i + 2];
+    const double rmax2 = rmax * rmax;
+    const int e0 = 2 * g.m[0] + 1, e1 = 2 * g.m[1] + 1, e2 = 2 * g.m[2] + 1;
+    const int n_combo = e0 * e1 * e2;
+    constexpr int kSelf = 0x888;
+    for (int c0 = 0; c0 < n_combo; c0 += 27) {
+      int lo = 0, len = 0, code = kSelf;
+      if (lane < 27 && c0 + lane < n_combo) {
+        const int id = c0 + lane;
+        int c[3] = {bx + id / (e1 * e2) - g.m[0], by + (id / e2) % e1 - g.m[1], bz + id % e2 - g.m[2]};
+        int sh[3] = {0, 0, 0};
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (c[a] < 0 || c[a] >= g.nb[a]) {
+            if (!g.pbc[a]) ok = false;
+            sh[a] = c[a] >= 0 ? c[a] / g.nb[a] : -((-c[a] + g.nb[a] - 1) / g.nb[a]);
+            c[a] -= sh[a] * g.nb[a];
+          }
+        }
+        if (ok) {
+          const int bin = g.bin_offset + (c[0] * g.nb[1] + c[1]) * g.nb[2] + c[2];
+          lo = bin_start[bin];
+          len = bin_start[bin + 1] - lo;
+          code = (sh[0] + 8) | ((sh[1] + 8) << 4) | ((sh[2] + 8) << 8);
+        }
+      }
+      int incl = len;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+      }
+      const int excl = incl - len;
+      const int total = __builtin_amdgcn_readlane(incl, 26);
+      const int delta = lo - excl;
+      for (int base = 0; base < total; base += 64) {
+        const int f = base + lane;
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 27; ++q) k += f >= __builtin_amdgcn_readlane(excl, q);
+        const int dl = __shfl(delta, k);
+        const int cd = __shfl(code, k);
+        bool valid = false;
+        unsigned long long key = 0;
+        if (f < total) {
+          const NlRec r = recs[dl + f];
+          const int Sx = (cd & 15) - 8 - r.wx + wix, Sy = ((cd >> 4) & 15) - 8 - r.wy + wiy,
+                    Sz = ((cd >> 8) & 15) - 8 - r.wz + wiz;
+          const double Dx = r.x - rix + (Sx * g.h[0] + Sy * g.h[3] + Sz * g.h[6]);
+          const double Dy = r.y - riy + (Sx * g.h[1] + Sy * g.h[4] + Sz * g.h[7]);
+          const double Dz = r.z - riz + (Sx * g.h[2] + Sy * g.h[5] + Sz * g.h[8]);
+          const double r2 = Dx * Dx + Dy * Dy + Dz * Dz;
+          // the two-pass builder's test is sqrt(r2) < rmax; away from the boundary r2 decides, next to it
+          // (relative 1e-14) the square root does, so both builders keep exactly the same pairs
+          valid = r2 < rmax2 * (1.0 - 1e-14) || (r2 <= rmax2 * (1.0 + 1e-14) && sqrt(r2) < rmax);
+          valid = valid && !(r.j == i && cd == kSelf);
+          if (valid) {
+            if (abs(Sx) >= kShiftBias || abs(Sy) >= kShiftBias || abs(Sz) >= kShiftBias) bad = true;
+            key = nl_key(r.sp, r.j, Sx, Sy, Sz);
+          }
+        }
+        const unsigned long long m = __ballot(valid);
+        const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && at < kBuildStash) mine[at] = key;
+        n += __popcll(m);
+      }
+    }
+    if (n > kBuildStash) bad = true;
+    bad = __any(bad);
+  }
+  const int nn = bad ? 0 : n;  // a centre beyond the limits writes nothing; the host falls back
+  if (lane == 0) cnt[w] = nn;
+  __syncthreads();
+
+  // offsets: the centres of the group by a scan over 16 lanes, the group by looking back
+  if (w == 0) {
+    const int c = lane < kBuildGroup ? cnt[lane] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < kBuildGroup; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane < kBuildGroup) cstart[lane] = incl - c;
+    {  // statistics: ONE set of atomics per group (they all hit the same two words)
+      unsigned long long tri = (unsigned long long)c * (unsigned long long)(c > 0 ? c - 1 : 0) / 2ull;
+      int mx = c;
+#pragma unroll
+      for (int off = 1; off < kBuildGroup; off <<= 1) {
+        tri += __shfl_xor(tri, off);
+        mx = max(mx, __shfl_xor(mx, off));
+      }
+      if (lane == 0) {
+        if (tri) atomicAdd(stats, tri);
+        if (mx) atomicMax(reinterpret_cast<int32_t *>(stats) + 2, mx);
+      }
+    }
+    const unsigned long long total = (unsigned long long)__builtin_amdgcn_readlane(incl, kBuildGroup - 1);
+    const int gi = blockIdx.x;
+    if (lane == 0)
+      __hip_atomic_store(&gstate[gi], (gi == 0 ? kStatePrefix : kStateSum) | total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long before = 0;
+    bool gave_up = false;
+    int spins = 0;
+    for (int hi = gi - 1; hi >= 0;) {
+      const int k = hi - lane;
+      // below group 0: a prefix of zero, so the walk always ends
+      const unsigned long long v =
+          k >= 0 ? __hip_atomic_load(&gstate[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatePrefix;
+      const unsigned fl = (unsigned)(v >> 62);
+      const unsigned long long m_prefix = __ballot(fl == 2), m_empty = __ballot(fl == 0);
+      const int first = m_prefix ? __builtin_ctzll(m_prefix) : 63;  // lanes 0 .. first are what is needed
+      const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+      if (m_empty & need) {
+        if (++spins > kSpinLimit) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      unsigned long long part = lane <= first ? (v & kStateMask) : 0ull;
+#pragma unroll
+      for (int off = 32; off; off >>= 1) part += __shfl_xor(part, off);
+      before += part;
+      if (m_prefix) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      // after giving up: still publish a prefix, so that the groups behind do not wait as well
+      if (gi > 0)
+        __hip_atomic_store(&gstate[gi], kStatePrefix | ((before + total) & kStateMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_base = (long long)before;
+      s_write = !gave_up && (long long)(before + total) <= capacity;
+      if (gave_up) atomicOr(reinterpret_cast<int32_t *>(stats) + 3, 1);
+      const int last = min(gi * kBuildGroup + kBuildGroup, n_atoms);
+      if (last == n_atoms) {  // the group of the last centre closes the arrays
+        const unsigned long long all = before + total;
+        pair_start[n_atoms] = (int32_t)all;
+        if (host_pair_start) host_pair_start[n_atoms] = (int32_t)all;
+        seg_start[(size_t)n_atoms * (nel + 1)] = (int32_t)all;
+        stats[4] = all;
+      }
+    }
+  }
+  // order of the neighbours inside the centre: rank of each key among the centre's keys (they are
+  // distinct); n is about a hundred, so n^2 / 64 compares per lane beat a sorting network's bookkeeping
+  for (int e = lane; e < nn; e += 64) {
+    const unsigned long long key = mine[e];
+    int r = 0;
+#pragma unroll 4
+    for (int k = 0; k < nn; ++k) r += mine[k] < key;
+    rank16[w][e] = (unsigned short)r;
+  }
+  if (act && __any(bad) && lane == 0) atomicOr(reinterpret_cast<int32_t *>(stats) + 3, 1);
+  __syncthreads();
+  if (!act) return;
+  const long long at = s_base + cstart[w];
+  // segment offsets: lane s counts the keys of species s
+  int segc = 0;
+  for (int e0 = 0; e0 < nn; e0 += 64) {
+    const int e = e0 + lane;
+    const int sp = e < nn ? (int)(mine[e] >> 61) : -1;
+    for (int s = 0; s < nel; ++s) {
+      const int c = __popcll(__ballot(sp == s));
+      if (lane == s) segc += c;
+    }
+  }
+  int incl = segc;
+#pragma unroll
+  for (int off = 1; off <= kMaxElements; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane <= nel) seg_start[(size_t)i * (nel + 1) + lane] = (int32_t)(at + incl - segc);
+  if (lane == 0) {
+    pair_start[i] = (int32_t)at;
+    if (host_pair_start) host_pair_start[i] = (int32_t)at;
+  }
+  if (!s_write) return;
+  for (int e = lane; e < nn; e += 64) {
+    const unsigned long long key = mine[e];
+    const long long slot = at + rank16[w][e];
+    pair_i[slot] = i;
+    pair_j[slot] = (int32_t)((key >> 30) & 0x7fffffffull);
+    pair_shift[3 * slot] = (int)((key >> 20) & 1023) - kShiftBias;
+    pair_shift[3 * slot + 1] = (int)((key >> 10) & 1023) - kShiftBias;
+    pair_shift[3 * slot + 2] = (int)(key & 1023) - kShiftBias;
+  }
+}
+
+// reverse pair in a list in key order: lower bound of i among the js of j's segment of species(i), then
+// the (few) images of i
+__global__ __launch_bounds__(kBlock) void reverse_sorted_kernel(int64_t n_pairs, int nel,
+                                                                const int32_t *species,
+                                                                const int32_t *seg_start,
+                                                                const int32_t *pair_i, const int32_t *pair_j,
+                                                                const int32_t *pair_shift, int32_t *pair_rev,
+                                                                int32_t *n_missing) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int i = pair_i[p], j = pair_j[p];
+  const int sx = pair_shift[3 * p], sy = pair_shift[3 * p + 1], sz = pair_shift[3 * p + 2];
+  const int32_t *seg = seg_start + (size_t)j * (nel + 1);
+  const int si = species[i];
+  int lo = seg[si];
+  const int end = seg[si + 1];
+  int hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_j[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  int found = -1;
+  for (int q = lo; q < end && pair_j[q] == i; ++q)
+    if (pair_shift[3 * (size_t)q] == -sx && pair_shift[3 * (size_t)q + 1] == -sy &&
+        pair_shift[3 * (size_t)q + 2] == -sz) {
+      found = q;
+      break;
+    }
+  pair_rev[p] = found;
+  if (found < 0) atomicAdd(n_missing, 1);
+}
+
 // ---- MD loop: the exact list of a step from the resident skin list ------------------------------
 // The resident list covers rmax + skin (ta_set_skin); while it is valid, the pairs inside rmax at the
 // CURRENT positions are a subset of it. These kernels extract that subset with the layout of the
@@ -540,7 +838,7 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
   (void)hipMemsetAsync(w.stats, 0, 8 * sizeof(unsigned long long), s);
   if (n_atoms == 0) return;
   hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
-                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count);
+                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, (int32_t *)nullptr);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
                      (int32_t *)nullptr);
   hipLaunchKernelGGL(fill_bins_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms,
@@ -570,6 +868,44 @@ void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *p
     hipLaunchKernelGGL(reverse_pairs_kernel, dim3(nblk(n_pairs * 8, kBlock)), dim3(kBlock), 0, s, n_pairs,
                        nel, species, w.seg_start, pair_i, pair_j, pair_shift, pair_rev,
                        reinterpret_cast<int32_t *>(w.stats) + 6);
+}
+
+// One-pass builder. `zero` is one block the caller sized with nl_build_zero_words(): statistics, the
+// look-back words and the bin histogram, cleared by ONE memset. Pairs are written only while they fit
+// `capacity` (entries of pair_i / pair_j / pair_rev; pair_shift holds three times as many): the caller
+// reads stats[4] (pairs) and the `bad` flag, grows the arrays and calls again when they did not fit.
+size_t nl_build_zero_words(int n_atoms, int n_bins) {
+  return 8 + (size_t)nblk(n_atoms, kBuildGroup) + 1 + ((size_t)n_bins + 2 + 1) / 2;
+}
+
+void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
+              const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
+              long long capacity, int32_t *pair_start, int32_t *host_pair_start, int32_t *pair_i,
+              int32_t *pair_j, int32_t *pair_shift, hipStream_t s) {
+  const size_t n_groups = nblk(n_atoms, kBuildGroup);
+  (void)hipMemsetAsync(zero, 0, nl_build_zero_words(n_atoms, n_bins) * sizeof(unsigned long long), s);
+  w.stats = zero;
+  unsigned long long *gstate = zero + 8;
+  w.bin_count = reinterpret_cast<int32_t *>(zero + 8 + n_groups + 1);
+  if (n_atoms == 0) return;
+  hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
+                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, w.bin_atoms);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
+                     (int32_t *)nullptr);
+  hipLaunchKernelGGL(place_recs_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
+                     species, w.wrap, w.binid, w.bin_start, w.bin_atoms, w.recs);
+  hipLaunchKernelGGL(build_pairs_kernel, dim3(n_groups), dim3(64 * kBuildGroup), 0, s, n_atoms, nel, rmax,
+                     pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start, w.recs, gstate, capacity,
+                     w.seg_start, pair_start, host_pair_start, pair_i, pair_j, pair_shift, zero);
+}
+
+void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
+                       const int32_t *pair_i, const int32_t *pair_j, const int32_t *pair_shift,
+                       int32_t *pair_rev, unsigned long long *stats, hipStream_t s) {
+  if (n_pairs > 0)
+    hipLaunchKernelGGL(reverse_sorted_kernel, dim3(nblk(n_pairs, kBlock)), dim3(kBlock), 0, s, n_pairs, nel,
+                       species, seg_start, pair_i, pair_j, pair_shift, pair_rev,
+                       reinterpret_cast<int32_t *>(stats) + 6);
 }
 
 // Exact list of the current positions out of the resident skin list (all device, no host round trip):

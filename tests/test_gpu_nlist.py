@@ -187,3 +187,47 @@ def test_reference_statistics_through_set_frames(lib):
                            ij2k=int(info.nnl_max) - 1)[stat]
                 assert got == d["value"], (key, stat, got, d)
     assert on_device > 0  # at least the large cells went through the GPU builder
+
+
+def test_one_pass_builder_key_order_and_two_pass_fallback(lib, monkeypatch):
+    """Round 3: the one-pass builder (ta_nlist.hip::build_pairs_kernel) leaves every centre's neighbours
+    sorted by (species, j, S); the two-pass builder takes over on request and beyond 384 neighbours per
+    atom. Same set of pairs from both, and the same energies / forces."""
+    from tensoralloy_amd import Engine
+    nn = make_nn(["Mo", "Ni"], 6.5, True, [16])
+    base = _sheared(rep=(6, 6, 6), seed=8)
+    sym = ["Mo" if k % 3 == 0 else "Ni" for k in range(len(base))]
+    atoms = Atoms(symbols=sym, positions=base.positions, cell=base.get_cell(complete=True), pbc=True)
+    sp = np.array([0 if s == "Mo" else 1 for s in sym])
+    with Engine(nn) as eng:
+        eng.set_frames([atoms])
+        i, j, S = eng.pairs()
+        one = eng.evaluate([atoms])[0]
+    S = np.asarray(S).reshape(-1, 3)
+    order = np.lexsort((S[:, 2], S[:, 1], S[:, 0], j, sp[j], i))
+    assert np.array_equal(order, np.arange(len(i)))  # already in key order
+    ref = _oracle_pairs([atoms], 6.5)
+    assert np.array_equal(_triplets(i, j, S), ref)
+    monkeypatch.setenv("TA_NL_TWO_PASS", "1")
+    with Engine(nn) as eng:
+        eng.set_frames([atoms])
+        i2, j2, S2 = eng.pairs()
+        two = eng.evaluate([atoms])[0]
+    assert np.array_equal(_triplets(i2, j2, S2), ref)
+    assert not np.array_equal(np.asarray(j2), np.asarray(j))  # traversal order, not key order
+    assert abs(one["energy"] - two["energy"]) < 1e-9
+    assert np.abs(one["forces"] - two["forces"]).max() < 1e-10
+    monkeypatch.delenv("TA_NL_TWO_PASS")
+    # 445 neighbours per atom: beyond the one-pass builder's LDS, the two-pass builder runs by itself
+    wide = make_nn(["Ni"], 10.5, False, [8])
+    big = [fcc(rep=(6, 6, 6), seed=2)]
+    info, dev = _device_pairs(wide, big)
+    assert info.nnl_max > 384
+    assert np.array_equal(dev, _oracle_pairs(big, 10.5))
+    # growing lists: the pair arrays are re-sized and the builder runs again
+    with Engine(nn) as eng:
+        a = eng.set_frames([fcc(rep=(3, 3, 3), seed=1)]).n_pairs
+        b = eng.set_frames([atoms]).n_pairs
+        assert b > 4 * a
+        i3, j3, S3 = eng.pairs()
+        assert np.array_equal(_triplets(i3, j3, S3), ref)
