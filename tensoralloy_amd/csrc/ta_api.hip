@@ -263,7 +263,10 @@ struct ta_context {
   DevBuf<int32_t> ex_pair_i, ex_pair_j, ex_pair_shift, ex_pair_rev, ex_pair_start, ex_pair_stop, ex_seg_start, ex_counts,
       ex_map, ex_blk;
   bool filtered = false;                       // db points at the ex_* arrays
-  hipEvent_t ev_upload = nullptr;              // last H2D copy out of stage_in
+  // a copy out of stage_in may still be in flight (set by ta_update_positions, cleared by every wait
+  // for the stream on the step path): whoever rewrites stage_in waits for the stream first. (An event
+  // recorded behind the copy cost a 5 us bubble between the copy and the next kernel of every MD step.)
+  bool upload_pending = false;
   int64_t n_list_builds = 0, n_list_reuses = 0;
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
@@ -914,7 +917,6 @@ int ta_create(const ta_model_desc *model, int device, ta_handle *out) {
     HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     for (auto &e : h->ev) HIP_CHECK(hipEventCreate(&e));
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming));
     if (model->kind == TA_MODEL_SF_MLP) {
       build_sf_model(h, model);
     } else if (model->kind == TA_MODEL_GRAP_MLP) {
@@ -981,7 +983,6 @@ int ta_destroy(ta_handle h) {
   h->nl_recs.release();
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return TA_OK;
@@ -1062,7 +1063,10 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
       throw std::invalid_argument("frame " + std::to_string(f) + ": null array");
   }
   const auto t_begin = std::chrono::steady_clock::now();
-  if (h->ev_upload) HIP_CHECK(hipEventSynchronize(h->ev_upload));  // stage_in is about to be rewritten
+  if (h->upload_pending) {  // stage_in is about to be rewritten
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->upload_pending = false;
+  }
   // no batch is resident until this call has succeeded: a failure below (allocation, too many
   // neighbours, asymmetric list ...) must not leave the previous batch's flags standing over
   // buffers that were already regrown or repointed
@@ -1218,6 +1222,7 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
     ta::eam_ensure(h->eam, h->db);
   }
   wait_stream(h->stream);  // staging buffers are reused by the next call
+  h->upload_pending = false;
   if (h->pairs_on_device) {
     nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
     if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
@@ -1308,11 +1313,14 @@ int ta_update_positions(ta_handle h, const double *positions, const double *cell
     if (keep) {
       // same list: only the coordinates travel (one H2D copy out of page-locked memory); the
       // forward kernels recompute the pair geometry from positions + shifts
-      HIP_CHECK(hipEventSynchronize(h->ev_upload));  // the staging buffer is free again
+      if (h->upload_pending) {  // the staging buffer must be free again
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->upload_pending = false;
+      }
       double *stage = reinterpret_cast<double *>(h->stage_in.ptr + h->o_pos);
       std::memcpy(stage, positions, 3 * N * sizeof(double));
       staged_copy(h->db.pos, stage, 3 * N, false, h->stream);
-      HIP_CHECK(hipEventRecord(h->ev_upload, h->stream));
+      h->upload_pending = true;
       if (h->filtered) apply_filter(h);  // the exact list of the new positions, on the device
       h->descriptors_valid = false;
       h->jvp_valid = false;
@@ -1395,6 +1403,7 @@ int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, 
       HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double),
                                hipMemcpyDeviceToHost, s));
     wait_stream(s);
+    h->upload_pending = false;
     if (energy && F) std::memcpy(energy, stage, F * sizeof(double));
     if (virial && F) std::memcpy(virial, stage + F, 9 * F * sizeof(double));
     if (atomic && N) std::memcpy(atomic, stage + 10 * F, N * sizeof(double));
@@ -1585,6 +1594,7 @@ int ta_set_stream(ta_handle h, void *stream) {
   if (!h) return TA_ERR_INVALID;
   return guarded(h, [&]() {
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->upload_pending = false;
     h->stream = stream ? (hipStream_t)stream : h->own_stream;
   });
 }
