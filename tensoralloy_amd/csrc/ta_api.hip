@@ -74,6 +74,9 @@ void eam_constant_gradient(EamModel *, const DeviceBatch &b, const double *frame
                            const double *dh, double *grad, hipStream_t s);
 void eam_energy_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, double *grad,
                          hipStream_t s);
+bool eam_loss_gradient_supported(const EamModel *);
+void eam_loss_gradient(EamModel *, const DeviceBatch &b, const double *frame_coeff, const double *dR,
+                       const double *dh, double *grad, hipStream_t s);
 }  // namespace ta
 
 namespace {
@@ -1760,12 +1763,47 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
                      int64_t n_grad, double *dG_out) {
   if (!h || !grad) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
-  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
-    return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term exists for the per-atom MLP models");
   if (!dR && !dh) {
     if (!frame_coeff) return fail(h, TA_ERR_INVALID, "nothing to differentiate");
     return ta_energy_gradient(h, frame_coeff, grad, n_grad);
   }
+  if (h->eam) {
+    // nn functions of a plain EAM model (round 3): one second-order pass per network, ta_eam.hip::eam_loss_gradient
+    if (!ta::eam_loss_gradient_supported(h->eam))
+      return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term covers plain EAM models "
+                                         "(Zjw04-family or tabulated analytic parts); ADP keeps the central difference");
+    if (h->filtered)
+      return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: not available on a skin-filtered batch; "
+                                         "ta_set_skin(h, 0) and ta_set_frames first");
+    return guarded(h, [&]() {
+      const int64_t total = ta::eam_param_count(h->eam);
+      if (n_grad != total)
+        throw std::invalid_argument("ta_loss_gradient: expected room for " + std::to_string(total) + " values");
+      if (dG_out) throw std::invalid_argument("ta_loss_gradient: dG_out is for the descriptor models");
+      if (total == 0) return;
+      if (ta::eam_nn_tables_on(h->eam)) HIP_CHECK(hipStreamSynchronize(h->stream));
+      ta::eam_mark_trained(h->eam);  // exact networks from here on (see ta_energy_gradient)
+      ta::eam_ensure(h->eam, h->db);
+      compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // rho, F', per-pair columns with the current weights
+      hipStream_t s = h->stream;
+      const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+      h->train_grad.ensure((size_t)total + 8);
+      h->train_coeff.ensure(F + 8);
+      h->tan_dir.ensure(3 * N + 9 * F + 8);
+      double *d_dR = h->tan_dir.ptr, *d_dh = h->tan_dir.ptr + 3 * N;
+      if (dR) HIP_CHECK(hipMemcpyAsync(d_dR, dR, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+      if (dh) HIP_CHECK(hipMemcpyAsync(d_dh, dh, 9 * F * sizeof(double), hipMemcpyHostToDevice, s));
+      if (frame_coeff && F)
+        HIP_CHECK(hipMemcpyAsync(h->train_coeff.ptr, frame_coeff, F * sizeof(double), hipMemcpyHostToDevice, s));
+      ta::eam_loss_gradient(h->eam, h->db, frame_coeff ? h->train_coeff.ptr : nullptr, dR ? d_dR : nullptr,
+                            dh ? d_dh : nullptr, h->train_grad.ptr, s);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(grad, h->train_grad.ptr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    });
+  }
+  if (h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term exists for the per-atom MLP models");
   // Per-pair buffers of this entry (tangents, Jacobian) are sized and walked by the resident
   // list's pair count. Under a Verlet skin the kernels run on the exact list extracted from it
   // (apply_filter: only the first pair_start[N] entries of the ex_* arrays are defined), so the two

@@ -63,6 +63,11 @@ void launch_mlp_grad_rows(const MlpDev &mlp, int activation, const int32_t *atom
                           const double *x, const double *row_coeff, const int32_t *frame_of_atom,
                           const double *frame_coeff, double *scratch, double *partial, double *grad,
                           hipStream_t s);
+size_t mlp_grad2_scratch_doubles(const MlpDev &mlp, int n_atoms);
+void launch_mlp_grad2_rows(const MlpDev &mlp, int activation, const int32_t *atoms, int n_rows, const double *x,
+                           const double *xdot, const double *row_coeff, const int32_t *frame_of_atom,
+                           const double *frame_coeff, double *scratch, double *partial, double *grad,
+                           hipStream_t s);
 
 namespace {
 
@@ -1998,6 +2003,221 @@ void eam_energy_gradient(EamModel *m, const DeviceBatch &b, const double *frame_
                          0, s, m->p, b, cls, k, frame_coeff, m->dF, m->mom, m->gcoeff);
     launch_mlp_grad_rows(net, m->activation, nullptr, n_pairs, rbuf, m->gcoeff, nullptr, nullptr, m->gscratch,
                          m->gpartial, g, s);
+  }
+}
+
+namespace {
+// ---- force / stress terms of the loss for the nn functions of a plain EAM model ------------------
+// (reference nn/losses.py:285-437 through tf.gradients; round 2 took a central difference of dE/dtheta
+// on two displaced copies of every frame.) With the loss written as  L = sum_f c_f E_f + D E,  D E the
+// directional derivative of the energy along (dR, dh) (train.py), and
+//   E = sum_i F(rho_i) + 1/2 sum_p phi(r_p),   rho_i = sum_p rho(r_p),
+//   D E = sum_i F'(rho_i) rhodot_i + 1/2 sum_p phi'(r_p) rdot_p,   rhodot_i = sum_p rho'(r_p) rdot_p,
+// every network enters through its value f and its input derivative f' at known points with known
+// weights, so dL/dtheta is  sum_rows [a f(x) + b f'(x)]  differentiated with respect to theta:
+//   embedding net of element e: rows = its atoms, x = rho_i,  a = c_f,                          b = rhodot_i
+//   density net of species s:   rows = pairs to s, x = r_p,    a = c_f F'(rho_i) + F''(rho_i) rhodot_i,  b = F'(rho_i) rdot_p
+//   pair net of type t:         rows = pairs of t, x = r_p,    a = c_f / 2,                      b = rdot_p / 2
+// (launch_mlp_grad2_rows: one second-order pass per network). F'' of an embedding NETWORK comes from a
+// value / first / second derivative sweep (scalar_net_d2_kernel), of an analytic or tabulated
+// embedding function from dual arithmetic as in the Hessian-vector kernels.
+constexpr int kNetMaxWidth = 128;
+
+__global__ __launch_bounds__(kBlock) void scalar_net_d2_kernel(MlpDev net, int act, const int32_t *atoms,
+                                                               int n_rows, const double *__restrict__ x,
+                                                               const double *__restrict__ scale, double *out) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_rows) return;
+  const int id = atoms ? atoms[t] : t;
+  double v[2][kNetMaxWidth], d1[2][kNetMaxWidth], d2[2][kNetMaxWidth];
+  int cur = 0;
+  v[0][0] = x[id];
+  d1[0][0] = 1.0;
+  d2[0][0] = 0.0;
+  for (int l = 0; l < net.n_layers; ++l) {
+    const MlpLayerDev ly = net.layer[l];
+    const int nxt = cur ^ 1;
+    for (int n = 0; n < ly.n; ++n) {
+      double z = ly.b ? ly.b[n] : 0.0, z1 = 0.0, z2 = 0.0;
+      for (int k = 0; k < ly.k; ++k) {
+        const double w = ly.w[(size_t)k * ly.np + n];
+        z = fma(w, v[cur][k], z);
+        z1 = fma(w, d1[cur][k], z1);
+        z2 = fma(w, d2[cur][k], z2);
+      }
+      double h = z, dh = 1.0, d2h = 0.0;
+      if (ly.act) activation_fn2(act, z, h, dh, d2h);
+      double o = h, o1 = dh * z1, o2 = d2h * z1 * z1 + dh * z2;
+      if (ly.res) {
+        o += v[cur][n];
+        o1 += d1[cur][n];
+        o2 += d2[cur][n];
+      }
+      v[nxt][n] = o;
+      d1[nxt][n] = o1;
+      d2[nxt][n] = o2;
+    }
+    cur = nxt;
+  }
+  out[id] = d2[cur][0] * scale[id];
+}
+
+// one wavefront per atom: rdot of its pairs, rhodot_i, and F''(rho_i) rhodot_i when the embedding
+// function is analytic or tabulated (networks: scalar_net_d2_kernel afterwards)
+__global__ __launch_bounds__(kBlock) void eam_lg_atom_kernel(EamParams P, DeviceBatch b, HvpArgs a,
+                                                             const TabDev *__restrict__ tabs,
+                                                             const double *__restrict__ pf, size_t ps,
+                                                             double *rdot, double *rhodot, double *d2F) {
+  __shared__ Dual el[kMaxEamElements][20];
+  const int nel = P.nel;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= b.n_atoms) return;
+  const int fr = b.frame_of_atom[i];
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  const double *h = b.cells + 9 * (size_t)fr;
+  const double *ri = b.pos + 3 * (size_t)i;
+  double acc = 0.0, rho_sum = 0.0;
+  for (int sb = 0; sb < nel; ++sb) {
+    const bool rho_nn = (P.nn_rho >> sb) & 1u, rho_tab = (P.tab_rho >> sb) & 1u;
+    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+      const int j = b.pair_j[q];
+      const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
+      const double *rj = b.pos + 3 * (size_t)j;
+      double D[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) D[c] = (rj[c] - ri[c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+      const double r2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2] + a.eps;
+      if (P.list_rc2 > 0.0 && !(r2 < P.list_rc2)) {
+        rdot[q] = 0.0;
+        continue;
+      }
+      const double r = sqrt(r2);
+      double T[3];
+      hvp_pair_tangent(a, b, 0, i, j, fr, S, T);
+      const double rd = (D[0] * T[0] + D[1] * T[1] + D[2] * T[2]) / r;
+      rdot[q] = rd;
+      double f, df;
+      if (rho_nn) {
+        f = pf[PF_RHO * ps + q];
+        df = pf[PF_DRHO * ps + q];
+      } else if (rho_tab) {
+        spline_eval(tabs[slot_rho(sb)], r, f, df);
+      } else {
+        zjw_rho<double>(P.el[sb], r, f, df);
+      }
+      rho_sum += f;
+      acc = fma(df, rd, acc);
+    }
+  }
+  acc = wave_sum(acc);
+  rho_sum = wave_sum(rho_sum);
+  if (lane == 0) {
+    rhodot[i] = acc;
+    if (!((P.nn_embed >> sA) & 1u)) {
+      Dual F, dF;
+      const double rho = rho_sum;  // (rho_buf holds the densities of the atoms with an embedding NETWORK only)
+      if ((P.tab_embed >> sA) & 1u) spline_eval_dual(tabs[slot_embed(nel, sA)], make_dual(rho, 1.0), F, dF);
+      else zjw_embed<Dual>(el[sA], P.embed_kind[sA], make_dual(rho, 1.0), F, dF);
+      d2F[i] = dF.d * acc;
+    }
+  }
+}
+
+// rows of one per-pair network (cls 0: density of species k, cls 1: pair function of type k): the
+// weights a (value) and b (input derivative) of every pair, zero for the pairs it does not serve
+__global__ __launch_bounds__(kBlock) void eam_lg_coeff_kernel(EamParams P, DeviceBatch b, int cls, int k,
+                                                              const double *__restrict__ frame_coeff,
+                                                              const double *__restrict__ dF,
+                                                              const double *__restrict__ d2F,
+                                                              const double *__restrict__ rdot, double *ca,
+                                                              double *cb) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= b.n_pairs) return;
+  const int nel = P.nel;
+  const int i = b.pair_i[p];
+  const int sA = b.species[i], sb = b.species[b.pair_j[p]];
+  const int key = cls == 0 ? sb : pair_type(sA, sb, nel);
+  double va = 0.0, vb = 0.0;
+  const bool listed = !(P.list_rc2 > 0.0) || pair_geom(b, (size_t)p)[1].y < P.list_rc2;
+  if (key == k && listed) {
+    const double c = frame_coeff ? frame_coeff[b.frame_of_atom[i]] : 0.0;
+    if (cls == 0) {
+      va = c * dF[i] + d2F[i];
+      vb = dF[i] * rdot[p];
+    } else {
+      va = 0.5 * c;
+      vb = 0.5 * rdot[p];
+    }
+  }
+  ca[p] = va;
+  cb[p] = vb;
+}
+}  // namespace
+
+bool eam_loss_gradient_supported(const EamModel *m) {
+  if (m->p.adp) return false;  // dipole / quadrupole networks: the central difference stays
+  for (int e = 0; e < m->p.nel; ++e)
+    if (m->p.el_kind[e] != 0) return false;
+  for (int sl = 0; sl < m->n_slots; ++sl)
+    if (m->nets[sl].n_layers && (m->nets[sl].max_np > kNetMaxWidth || m->nets[sl].max_kp > kNetMaxWidth || m->nets[sl].xlo))
+      return false;
+  return true;
+}
+
+// grad (device) = d/dtheta [ sum_f frame_coeff[f] E_f + D_(dR, dh) E ]; needs the forward pass of eam_compute on
+// this batch with the current weights (dF, rho, per-pair columns). frame_coeff may be null (no energy term).
+void eam_loss_gradient(EamModel *m, const DeviceBatch &b, const double *frame_coeff, const double *dR,
+                       const double *dh, double *grad, hipStream_t s) {
+  const int nel = m->p.nel, npair = nel * (nel + 1) / 2;
+  const int n_pairs = (int)b.n_pairs, n_atoms = (int)b.n_atoms;
+  size_t scratch = 1, partial = 1;
+  for (int sl = 0; sl < m->n_slots; ++sl) {
+    const MlpDev &net = m->nets[sl];
+    if (!net.n_layers) continue;
+    const bool embed = sl >= nel && sl < 2 * nel;
+    const int rows = embed ? n_atoms : n_pairs;
+    scratch = std::max(scratch, mlp_grad2_scratch_doubles(net, rows));
+    partial = std::max(partial, mlp_grad_partial_doubles(net, rows));
+  }
+  grow(m->gscratch, m->cap_gscratch, scratch + 8);
+  grow(m->gpartial, m->cap_gpartial, partial + 8);
+  grow(m->gcoeff, m->cap_gcoeff, 3 * (size_t)n_pairs + 2 * (size_t)n_atoms + 8);
+  double *ca = m->gcoeff, *cb = ca + n_pairs, *rdot = cb + n_pairs, *rhodot = rdot + n_pairs, *d2F = rhodot + n_atoms;
+  const double *rbuf = m->pf ? m->pf + (size_t)(m->p.adp ? 8 : 4) * m->cap_pairs : nullptr;
+  const HvpArgs a{1, 0, 0, dR, dh, m->eps};
+  if (n_atoms > 0)
+    hipLaunchKernelGGL(eam_lg_atom_kernel, dim3((unsigned)((n_atoms + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock),
+                       0, s, m->p, b, a, m->tabs_dev, m->pf, m->cap_pairs, rdot, rhodot, d2F);
+  for (int e = 0; e < nel; ++e) {
+    const MlpDev &net = m->nets[slot_embed(nel, e)];
+    const int n_el = b.elem_start[e + 1] - b.elem_start[e];
+    if (!net.n_layers || n_el == 0) continue;
+    hipLaunchKernelGGL(scalar_net_d2_kernel, dim3((unsigned)((n_el + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, net,
+                       m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, rhodot, d2F);
+  }
+  size_t off = 0;
+  for (int sl = 0; sl < m->n_slots; ++sl) {
+    const MlpDev &net = m->nets[sl];
+    if (!net.n_layers) continue;
+    double *g = grad + off;
+    off += (size_t)mlp_param_count(net);
+    if (sl >= nel && sl < 2 * nel) {
+      const int e = sl - nel;
+      launch_mlp_grad2_rows(net, m->activation, b.elem_atoms + b.elem_start[e], b.elem_start[e + 1] - b.elem_start[e],
+                            m->rho_buf, rhodot, nullptr, b.frame_of_atom, frame_coeff, m->gscratch, m->gpartial, g, s);
+      continue;
+    }
+    const int cls = sl < nel ? 0 : 1 + (sl - 2 * nel) / npair;
+    const int k = sl < nel ? sl : (sl - 2 * nel) % npair;
+    if (n_pairs > 0)
+      hipLaunchKernelGGL(eam_lg_coeff_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                         m->p, b, cls, k, frame_coeff, m->dF, d2F, rdot, ca, cb);
+    launch_mlp_grad2_rows(net, m->activation, nullptr, n_pairs, rbuf, cb, ca, nullptr, nullptr, m->gscratch,
+                          m->gpartial, g, s);
   }
 }
 

@@ -183,8 +183,10 @@ __global__ __launch_bounds__(kThreads) void mlp_grad2_kernel(MlpDev mlp, GradLay
                                                              const int32_t *atoms, int n_atoms,
                                                              const double *G, const double *dG,
                                                              const int32_t *frame_of_atom,
-                                                             const double *frame_coeff, double *scratch,
+                                                             const double *frame_coeff,
+                                                             const double *row_coeff, double *scratch,
                                                              double *partial, int stride) {
+  // `row_coeff` (scalar-input networks of nn-EAM over pairs): kappa seed of a row instead of c[frame]
   extern __shared__ double lds[];
   double *bufX0 = lds, *bufX1 = bufX0 + kMlpRows * stride, *bufT0 = bufX1 + kMlpRows * stride,
          *bufT1 = bufT0 + kMlpRows * stride;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void mlp_grad2_kernel(MlpDev mlp, GradLay
       double c = 0.0, one = 0.0;
       if (col == 0 && row < nrows) {
         const int id = atoms ? atoms[a0 + row] : a0 + row;
-        c = frame_coeff ? frame_coeff[frame_of_atom[id]] : 0.0;
+        c = row_coeff ? row_coeff[id] : (frame_coeff ? frame_coeff[frame_of_atom[id]] : 0.0);
         one = 1.0;
       }
       curX[row * stride + col] = c;    // kappa
@@ -446,7 +448,7 @@ void launch_mlp_grad2(const MlpDev &mlp, int activation, int ndim, const int32_t
   const size_t lds = 4 * (size_t)kMlpRows * stride * sizeof(double);
   const int blocks = std::min((n_atoms + kMlpRows - 1) / kMlpRows, kMaxBlocks);
   hipLaunchKernelGGL(mlp_grad2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation,
-                     ndim, atoms, n_atoms, b.G, dG, b.frame_of_atom, frame_coeff, scratch, partial, stride);
+                     ndim, atoms, n_atoms, b.G, dG, b.frame_of_atom, frame_coeff, nullptr, scratch, partial, stride);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
 }
@@ -485,6 +487,28 @@ void launch_mlp_grad_rows(const MlpDev &mlp, int activation, const int32_t *atom
   const int blocks = std::min((n_rows + kMlpRows - 1) / kMlpRows, kMaxBlocks);
   hipLaunchKernelGGL(mlp_grad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation, 1,
                      atoms, n_rows, x, frame_of_atom, frame_coeff, row_coeff, scratch, partial, stride);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
+}
+
+// Second-order pass for a scalar-input network: gradient of  sum_rows [a_row f(x_row) + b_row f'(x_row)]
+// with respect to the flat parameters (a = `row_coeff`, or c[frame of the atom] when null; b = `xdot`).
+// The force / stress-loss gradient of the nn functions of an EAM model is made of such sums
+// (ta_eam.hip::eam_loss_gradient).
+void launch_mlp_grad2_rows(const MlpDev &mlp, int activation, const int32_t *atoms, int n_rows, const double *x,
+                           const double *xdot, const double *row_coeff, const int32_t *frame_of_atom,
+                           const double *frame_coeff, double *scratch, double *partial, double *grad,
+                           hipStream_t s) {
+  const GradLayout lay = make_layout(mlp);
+  if (n_rows == 0) {
+    (void)hipMemsetAsync(grad, 0, (size_t)lay.n_params * sizeof(double), s);
+    return;
+  }
+  const int stride = mlp_stride(mlp);
+  const size_t lds = 4 * (size_t)kMlpRows * stride * sizeof(double);
+  const int blocks = std::min((n_rows + kMlpRows - 1) / kMlpRows, kMaxBlocks);
+  hipLaunchKernelGGL(mlp_grad2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation, 1,
+                     atoms, n_rows, x, xdot, frame_of_atom, frame_coeff, row_coeff, scratch, partial, stride);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
 }

@@ -351,9 +351,11 @@ class Trainer:
     (`ta_loss_gradient`: descriptor Jacobian once per resident batch, then a pair sweep + the MLP
     pass per step, energy term included). An EAM model whose functions are all analytic trains their
     CONSTANTS instead (potentials/potentials.py:129-163): `ta_constant_gradient` differentiates the
-    same functional in dual arithmetic, one seeded constant per grid row. The nn functions of EAM / ADP
-    models, whose pair networks see r itself, keep the central difference of g = dE/dtheta on two displaced copies of every
-    frame (`analytic=False` forces it everywhere; step `fd_step` Angstrom, error O(step^2)).
+    same functional in dual arithmetic, one seeded constant per grid row. The nn functions of a plain EAM
+    model (round 3) enter D_delta E through their values and input derivatives at known points: one
+    second-order pass per network (`ta_loss_gradient` again). ADP models keep the central difference of
+    g = dE/dtheta on two displaced copies of every frame (`analytic=False` forces it everywhere; step
+    `fd_step` Angstrom, error O(step^2)).
     """
 
     def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
@@ -374,8 +376,11 @@ class Trainer:
         self.constants_mode = hasattr(nn, "nn_functions") and not any(s is not None for s in nn.nn_functions())
         # the analytic second-order pass exists for the per-atom MLP models (and, in dual arithmetic,
         # for the constants)
-        self.analytic = (not hasattr(nn, "nn_functions") or self.constants_mode) if analytic is None \
-            else bool(analytic)
+        # ... and, since round 3, for the nn functions of a plain EAM model (`ta_loss_gradient`, one
+        # second-order pass per network); ADP's dipole / quadrupole networks keep the central difference
+        eam_nets = hasattr(nn, "nn_functions") and not self.constants_mode
+        plain_eam = eam_nets and type(nn).__name__ == "EamAlloyNN"
+        self.analytic = (not eam_nets or plain_eam) if analytic is None else bool(analytic)
         if self.constants_mode and not self.analytic:
             raise ValueError("the constants have no finite-difference path")
         self._resident = False

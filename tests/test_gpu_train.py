@@ -491,3 +491,101 @@ def test_pressure_rrmse_and_l2_terms_in_the_trainer(lib):
         nn.weights = unflatten_weights(nn, theta)
         fd = (lp - lm) / (2 * d)
         assert abs(fd - grad[k]) < 2e-6 * max(1.0, abs(fd)), (k, fd, grad[k])
+
+
+@pytest.mark.parametrize("kind", ["eam_ni", "eam_binary_mixed", "eam_setfl_embed"])
+def test_nn_eam_analytic_force_stress_loss_gradient(lib, kind):
+    """Round 3: d/dtheta [sum_f c_f E_f + D_(dR, dh) E] for the nn functions of a plain EAM model in one
+    second-order pass per network (`ta_loss_gradient`, ta_eam.hip::eam_loss_gradient), against (a) the
+    central difference of `ta_energy_gradient` on displaced frames that round 2 used and (b) central
+    differences of the ORACLE's energies, in the direction and in single weights."""
+    from tensoralloy_amd import Atoms, Engine
+    from tensoralloy_amd.train import flatten_weights, trainable_mask, unflatten_weights
+    from tests.helpers import make_eam, oracle_eam_eval
+    if kind == "eam_ni":
+        nn = make_eam(["Ni"], 6.0, potential=None, hidden_sizes=[16, 8])
+        frames = [fcc(rep=(2, 2, 2), jitter=0.08), fcc(rep=(2, 2, 3), a=3.4, seed=3, jitter=0.05)]
+    elif kind == "eam_binary_mixed":
+        pots = {"Ni": {"rho": "nn", "embed": "zjw04"}, "Mo": {"rho": "zjw04", "embed": "nn"},
+                "NiNi": {"phi": "zjw04"}, "MoNi": {"phi": "nn"}, "MoMo": {"phi": "nn"}}
+        nn = make_eam(["Mo", "Ni"], 6.0, potential=pots, hidden_sizes=[12])
+        frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))]
+    else:
+        pots = {"Ni": {"rho": "nn", "embed": "zjw04"}, "NiNi": {"phi": "nn"}}
+        nn = make_eam(["Ni"], 5.5, potential=pots, hidden_sizes=[8, 8])
+        frames = [fcc(rep=(2, 2, 2), jitter=0.1, seed=7)]
+    rng = np.random.RandomState(11)
+    coeff = rng.randn(len(frames))
+    dR = [rng.randn(len(a), 3) * 0.3 for a in frames]
+    dh = [rng.randn(3, 3) * 0.2 for _ in frames]
+    theta = flatten_weights(nn)
+    mask = trainable_mask(nn)
+
+    def displaced(eps):
+        return [Atoms(numbers=np.asarray(a.numbers).copy(), positions=a.positions + eps * dR[k],
+                      cell=np.asarray(a.get_cell(complete=True)) + eps * dh[k], pbc=np.asarray(a.pbc).copy())
+                for k, a in enumerate(frames)]
+
+    with Engine(nn) as eng:
+        eng.set_frames(frames)
+        g = eng.loss_gradient(coeff, np.concatenate(dR), np.array(dh)) * mask
+        g_dir_only = eng.loss_gradient(None, np.concatenate(dR), np.array(dh)) * mask
+        g_e = eng.energy_gradient(coeff) * mask
+        e = 1e-4
+        eng.set_frames(displaced(e))
+        gp = eng.energy_gradient(np.ones(len(frames)))
+        eng.set_frames(displaced(-e))
+        gm = eng.energy_gradient(np.ones(len(frames)))
+    fd = (gp - gm) / (2 * e) * mask
+    scale = max(1.0, np.abs(g).max())
+    assert np.abs(g_dir_only - fd).max() < 2e-6 * scale
+    assert np.abs(g - (g_e + fd)).max() < 2e-6 * scale
+    assert np.abs(g_dir_only).max() > 1e-3          # the direction really couples to the weights
+
+    saved = nn.weights
+
+    def oracle_J(vec):
+        nn.weights = unflatten_weights(nn, vec)
+        try:
+            out = 0.0
+            for k, a in enumerate(frames):
+                out += coeff[k] * oracle_eam_eval(nn, a)["energy"]
+            d = 1e-4
+            ep = sum(oracle_eam_eval(nn, a)["energy"] for a in displaced(d))
+            em = sum(oracle_eam_eval(nn, a)["energy"] for a in displaced(-d))
+            return out + (ep - em) / (2 * d)
+        finally:
+            nn.weights = saved
+
+    live = np.flatnonzero(mask)
+    picks = list(np.random.RandomState(5).choice(live, size=6, replace=False)) + [live[0], live[-1]]
+    for k in picks:
+        d = 1e-4
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += d
+        tm[k] -= d
+        num = (oracle_J(tp) - oracle_J(tm)) / (2 * d)
+        assert abs(g[k] - num) < 2e-5 * scale, (k, g[k], num)
+
+
+def test_trainer_uses_the_analytic_pass_for_nn_eam(lib):
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import Trainer
+    from tests.helpers import make_eam
+    teacher = make_eam(["Ni"], 5.0, potential=None, hidden_sizes=[8], seed=1)
+    frames = [fcc(rep=(2, 2, 2), a=a, seed=k, jitter=0.05) for k, a in enumerate((3.45, 3.55, 3.65))]
+    with Engine(teacher) as eng:
+        res = eng.evaluate(frames)
+    student = make_eam(["Ni"], 5.0, potential=None, hidden_sizes=[8], seed=2)
+    kw = dict(energies=[r["energy"] for r in res], forces=[r["forces"] for r in res],
+              stresses=[r["stress"] for r in res], device=0, learning_rate=0.002)
+    tr = Trainer(student, frames, **kw)
+    assert tr.analytic
+    la, _, ga = tr.loss_and_gradient()
+    tr.close()
+    student2 = make_eam(["Ni"], 5.0, potential=None, hidden_sizes=[8], seed=2)
+    tf = Trainer(student2, frames, analytic=False, fd_step=1e-4, **kw)
+    lf, _, gf = tf.loss_and_gradient()
+    tf.close()
+    assert abs(la - lf) < 1e-12 * max(1.0, abs(lf))
+    assert np.abs(np.asarray(ga) - np.asarray(gf)).max() < 2e-6 * max(1.0, np.abs(gf).max())
