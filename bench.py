@@ -504,11 +504,13 @@ def main():
             pos = np.ascontiguousarray(frames[0].positions)
             n_inc = max(10, min(args.steps, 50))
 
-            def loop(n):
+            def loop(n, view=True):
                 eng.synchronize()
                 t = time.perf_counter()
                 for _ in range(n):
-                    eng.step(pos, want)   # ta_step = ta_update_positions + ta_compute + ta_get_results
+                    # ta_step_view = ta_update_positions + ta_compute + results in the library's page-locked
+                    # host buffer, wrapped as arrays (view=False: ta_step, copied on into caller arrays)
+                    eng.step(pos, want, view=view)
                 return (time.perf_counter() - t) / n
             loop(3)
             t_rebuild = loop(n_inc)
@@ -516,6 +518,7 @@ def main():
             info_s = eng.set_frames(frames)
             loop(3)
             t_reuse = loop(n_inc)
+            t_reuse_copy = loop(n_inc, view=False)
             builds, reuses = eng.list_stats()
             eng.set_skin(0.0)
             eng.set_frames(frames)
@@ -524,8 +527,11 @@ def main():
                          "h2d_bytes_per_step": 24 * n_atoms, "d2h_bytes_per_step": 8 * (4 * n_atoms + 10),
                          "lists_reused": reuses,
                          "new_list_every_step": {"value": n_atoms / t_rebuild, "ms_per_step": t_rebuild * 1e3},
+                         "copied_into_caller_arrays": {"value": n_atoms / t_reuse_copy,
+                                                       "ms_per_step": t_reuse_copy * 1e3},
                          "note": "H2D positions + ta_compute + D2H energy/forces/virial/atomic, host-timed, "
-                                 "one synchronisation per step"}
+                                 "one synchronisation per step; results left in the library's page-locked host "
+                                 "buffer (ta_step_view); `copied_into_caller_arrays` = ta_step"}
 
         # ---- parity gate + CPU baseline (oracle = checker, timed on host cores) ----
         cpu = None

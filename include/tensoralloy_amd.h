@@ -187,7 +187,7 @@ int ta_device_count(void);
  * sizeof(ta_model_desc) as the library was compiled: a binding checks both before the first real
  * call, so that a stale or foreign build of the library is refused instead of misreading a struct.
  * (The reference has no counterpart: its "ABI" is the frozen graph's `Metadata/api`, basic.py:43.) */
-#define TA_ABI_VERSION 3
+#define TA_ABI_VERSION 4
 int ta_abi_version(void);
 int ta_model_desc_size(void);
 
@@ -252,6 +252,17 @@ int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want
  * those three; forces / virial / atomic / rebuilt may be NULL. */
 int ta_step(ta_handle h, const double *positions, const double *cells, uint32_t want, double *energy,
             double *forces, double *virial, double *atomic, int32_t *rebuilt);
+
+/* The same results WITHOUT the copy into caller arrays: pointers into the handle's page-locked staging
+ * buffer, where the device wrote them (layout as ta_get_results; NULL for what `want` did not ask for).
+ * They stay valid until the next call on this handle. For bindings that wrap the memory as arrays
+ * (numpy.ctypeslib): one MD step hands back 128 KB for a 4000-atom frame, and copying them out of
+ * freshly DMA-written memory costs the host more than the transfer itself.
+ *   ta_view_results  after ta_compute;  ta_step_view = ta_update_positions + ta_compute + ta_view_results */
+int ta_view_results(ta_handle h, uint32_t want, const double **energy, const double **forces,
+                    const double **virial, const double **atomic);
+int ta_step_view(ta_handle h, const double *positions, const double *cells, uint32_t want, const double **energy,
+                 const double **forces, const double **virial, const double **atomic, int32_t *rebuilt);
 
 /* Enqueue all further work of this handle on `stream` (a hipStream_t of the
  * handle's device owned by the caller, e.g. the stream a RCCL collective is

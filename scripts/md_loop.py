@@ -23,5 +23,5 @@ with Engine(ni_model()) as eng:
             eng.compute(want)
             eng.fetch(want)
         else:
-            eng.step(pos, want)
+            eng.step(pos, want, view=not os.environ.get("TA_MD_COPY"))
     print("ms per step", (time.perf_counter() - t0) / steps * 1e3)

@@ -32,7 +32,7 @@ TA_CUTOFF = {"cosine": 0, "polynomial": 1}
 TA_ACT = {"relu": 0, "softplus": 1, "tanh": 2, "squareplus": 3, "leaky_relu": 4,
           "sigmoid": 5, "softsign": 6, "elu": 7}
 TA_N_KERNEL_SLOTS = 10
-TA_ABI_VERSION = 3  # include/tensoralloy_amd.h: TA_ABI_VERSION
+TA_ABI_VERSION = 4  # include/tensoralloy_amd.h: TA_ABI_VERSION
 KERNEL_SLOTS = ["pair_geometry", "g4_forward", "descriptor_reduce", "mlp", "backward",
                 "force_gather", "frame_reduce", "eam", "neighbor_update", "grap_forward"]
 
@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "ta_eam_tabulate", "ta_set_batch_energy_target", "ta_param_count", "ta_update_weights",
     "ta_energy_gradient", "ta_measure_hbm_copy", "ta_set_skin", "ta_update_positions", "ta_list_stats",
     "ta_count_contributing_triples", "ta_loss_gradient", "ta_constant_count", "ta_get_constants", "ta_update_constants",
-    "ta_constant_gradient", "ta_list_sizes", "ta_abi_version", "ta_model_desc_size", "ta_set_nn_tables", "ta_step", "ta_hessian_vectors",
+    "ta_constant_gradient", "ta_list_sizes", "ta_abi_version", "ta_model_desc_size", "ta_set_nn_tables", "ta_step", "ta_hessian_vectors", "ta_view_results", "ta_step_view",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -219,6 +219,9 @@ def load():
     lib.ta_set_nn_tables.argtypes = [H, C.c_int]
     lib.ta_hessian_vectors.argtypes = [H, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]
     lib.ta_step.argtypes = [H, _dp, _dp, C.c_uint32, _dp, _dp, _dp, _dp, _ip]
+    _dpp = C.POINTER(_dp)
+    lib.ta_view_results.argtypes = [H, C.c_uint32, _dpp, _dpp, _dpp, _dpp]
+    lib.ta_step_view.argtypes = [H, _dp, _dp, C.c_uint32, _dpp, _dpp, _dpp, _dpp, _ip]
     lib.ta_free.argtypes = [C.c_void_p]
     lib.ta_eam_tabulate.argtypes = [H, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.ta_free.restype = None

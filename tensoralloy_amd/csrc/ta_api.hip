@@ -1373,44 +1373,69 @@ int ta_synchronize(ta_handle h) {
   return guarded(h, [&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); });
 }
 
+namespace {
+// one download of the span of [energy F | virial 9F | atomic N | forces 3N] that is asked for into the
+// page-locked staging buffer; returns the pointer that indexes it like h->results (null: nothing asked)
+const double *results_to_stage(ta_context *h, bool energy, bool forces, bool virial, bool atomic, double *descriptors) {
+  const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+  hipStream_t s = h->stream;
+  const bool have_forces = (h->last_want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
+  if ((forces || virial) && !have_forces)
+    throw std::invalid_argument("forces / virial requested but the last ta_compute did not produce them");
+  if (descriptors && h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
+    throw std::invalid_argument("descriptors are only defined for symmetry-function and GRAP models");
+  size_t lo = (size_t)-1, hi = 0;
+  auto need = [&](bool on, size_t off, size_t n) {
+    if (!on || n == 0) return;
+    lo = std::min(lo, off);
+    hi = std::max(hi, off + n);
+  };
+  need(energy, 0, F);
+  need(virial, F, 9 * F);
+  need(atomic, 10 * F, N);
+  need(forces, 10 * F + N, 3 * N);
+  const double *stage = nullptr;
+  if (hi > lo) {
+    h->stage_out.ensure((hi - lo) * sizeof(double));
+    stage = reinterpret_cast<const double *>(h->stage_out.ptr) - lo;
+    staged_copy(reinterpret_cast<double *>(h->stage_out.ptr), h->results.ptr + lo, hi - lo, true, s);
+  }
+  if (descriptors && N)
+    HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double), hipMemcpyDeviceToHost, s));
+  wait_stream(s);
+  h->upload_pending = false;
+  return stage;
+}
+}  // namespace
+
 int ta_get_results(ta_handle h, double *energy, double *forces, double *virial, double *atomic,
                    double *descriptors) {
   if (!h) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
   return guarded(h, [&]() {
     const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
-    hipStream_t s = h->stream;
-    const bool have_forces = (h->last_want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
-    if ((forces || virial) && !have_forces)
-      throw std::invalid_argument("forces / virial requested but the last ta_compute did not produce them");
-    if (descriptors && h->kind != TA_MODEL_SF_MLP && h->kind != TA_MODEL_GRAP_MLP)
-      throw std::invalid_argument("descriptors are only defined for symmetry-function and GRAP models");
-    // one download of the span of [energy F | virial 9F | atomic N | forces 3N] that was asked for
-    size_t lo = (size_t)-1, hi = 0;
-    auto need = [&](bool on, size_t off, size_t n) {
-      if (!on || n == 0) return;
-      lo = std::min(lo, off);
-      hi = std::max(hi, off + n);
-    };
-    need(energy != nullptr, 0, F);
-    need(virial != nullptr, F, 9 * F);
-    need(atomic != nullptr, 10 * F, N);
-    need(forces != nullptr, 10 * F + N, 3 * N);
-    const double *stage = nullptr;
-    if (hi > lo) {
-      h->stage_out.ensure((hi - lo) * sizeof(double));
-      stage = reinterpret_cast<const double *>(h->stage_out.ptr) - lo;
-      staged_copy(reinterpret_cast<double *>(h->stage_out.ptr), h->results.ptr + lo, hi - lo, true, s);
-    }
-    if (descriptors && N)
-      HIP_CHECK(hipMemcpyAsync(descriptors, h->db.G, N * h->sf.ndim * sizeof(double),
-                               hipMemcpyDeviceToHost, s));
-    wait_stream(s);
-    h->upload_pending = false;
+    const double *stage = results_to_stage(h, energy != nullptr, forces != nullptr, virial != nullptr,
+                                           atomic != nullptr, descriptors);
     if (energy && F) std::memcpy(energy, stage, F * sizeof(double));
     if (virial && F) std::memcpy(virial, stage + F, 9 * F * sizeof(double));
     if (atomic && N) std::memcpy(atomic, stage + 10 * F, N * sizeof(double));
     if (forces && N) std::memcpy(forces, stage + 10 * F + N, 3 * N * sizeof(double));
+  });
+}
+
+int ta_view_results(ta_handle h, uint32_t want, const double **energy, const double **forces,
+                    const double **virial, const double **atomic) {
+  if (!h) return TA_ERR_INVALID;
+  if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
+  return guarded(h, [&]() {
+    const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
+    const bool fv = (want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
+    const double *stage = results_to_stage(h, energy != nullptr, forces && fv, virial && fv,
+                                           atomic && (want & TA_WANT_ATOMIC), nullptr);
+    if (energy) *energy = (stage && F) ? stage : nullptr;
+    if (virial) *virial = (stage && fv && F) ? stage + F : nullptr;
+    if (atomic) *atomic = (stage && (want & TA_WANT_ATOMIC) && N) ? stage + 10 * F : nullptr;
+    if (forces) *forces = (stage && fv && N) ? stage + 10 * F + N : nullptr;
   });
 }
 
@@ -1421,6 +1446,15 @@ int ta_step(ta_handle h, const double *positions, const double *cells, uint32_t 
   rc = ta_compute(h, want);
   if (rc != TA_OK) return rc;
   return ta_get_results(h, energy, forces, virial, atomic, nullptr);
+}
+
+int ta_step_view(ta_handle h, const double *positions, const double *cells, uint32_t want, const double **energy,
+                 const double **forces, const double **virial, const double **atomic, int32_t *rebuilt) {
+  int rc = ta_update_positions(h, positions, cells, rebuilt);
+  if (rc != TA_OK) return rc;
+  rc = ta_compute(h, want);
+  if (rc != TA_OK) return rc;
+  return ta_view_results(h, want, energy, forces, virial, atomic);
 }
 
 int ta_eval(ta_handle h, int32_t n_frames, const ta_frame *frames, uint32_t want, double *energy,

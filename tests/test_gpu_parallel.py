@@ -167,6 +167,40 @@ def test_update_positions_reuses_and_rebuilds_the_list(lib):
             assert int(eng.info.n_atoms) == len(atoms)
 
 
+def test_step_and_step_view_match_the_three_calls(lib):
+    """`ta_step` (results copied into caller arrays) and `ta_step_view` (results left in the library's
+    page-locked buffer, wrapped as arrays) against update_positions + compute + fetch, over list reuses
+    and rebuilds; the view of an energy-only step hands back no force arrays."""
+    from tensoralloy_amd import Engine, _lib
+    from tests.helpers import fcc, make_nn
+    want = _lib.TA_WANT_ENERGY | _lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL | _lib.TA_WANT_ATOMIC
+    nn = make_nn(["Ni"], 6.0, True, [16])
+    atoms = fcc(rep=(4, 4, 4))
+    rng = np.random.RandomState(4)
+    with Engine(nn) as a, Engine(nn) as b, Engine(nn) as c:
+        for eng in (a, b, c):
+            eng.set_skin(0.5)
+            eng.set_frames([atoms])
+        pos = atoms.positions.copy()
+        for step in range(6):
+            pos = pos + rng.normal(0, 0.05, pos.shape)
+            a.update_positions(pos)
+            a.compute(want)
+            ref = a.fetch(want)
+            got = b.step(pos, want)
+            view = c.step(pos, want, view=True)
+            for res in (got, view):
+                # (the angular kernels' LDS adds arrive in any order: last-bit noise between engines)
+                assert abs(res["energy"][0] - ref["energy"][0]) < 1e-9
+                assert np.abs(res["forces"] - ref["forces"]).max() < 1e-12
+                assert np.abs(res["virial"] - ref["virial"]).max() < 1e-10
+                assert np.abs(res["atomic"] - ref["atomic"]).max() < 1e-12
+        assert a.list_stats() == b.list_stats() == c.list_stats()
+        assert a.list_stats()[0] > 1 and a.list_stats()[1] > 0   # both reuses and rebuilds happened
+        only_e = c.step(pos, _lib.TA_WANT_ENERGY, view=True)
+        assert "forces" not in only_e and abs(only_e["energy"][0] - ref["energy"][0]) < 1e-9
+
+
 TRAIN_WORKER = r"""
 import json, os, sys
 sys.path.insert(0, {root!r})
