@@ -324,10 +324,10 @@ int ta_energy_gradient(ta_handle h, const double *frame_coeff, double *grad, int
  * pair sweep and ONE second-order pass through the MLP. frame_coeff, dR, dh may each be NULL (= 0).
  * dG_out (may be NULL): the directional derivative of the raw descriptors [n_atoms_total][D] that
  * entered the pass (parity tests).
- * Plain EAM models with nn functions (the reference's default potentials, alloy.py:110-112) since round 3:
- * every network enters D_delta E through its value and its input derivative at known points, so the
- * gradient is one second-order pass per network over its rows (pairs / atoms); dG_out must be NULL.
- * ADP models and the sutton90 / Be/1 / grimes families: TA_ERR_UNSUPPORTED (callers difference
+ * EAM / ADP models with nn functions (the reference's default potentials, alloy.py:110-112, adp.py:120-124)
+ * since round 3: every network enters D_delta E through its value and its input derivative at known
+ * points, so the gradient is one second-order pass per network over its rows (pairs / atoms); dG_out
+ * must be NULL. The sutton90 / Be/1 / grimes families: TA_ERR_UNSUPPORTED (callers difference
  * ta_energy_gradient on displaced frames instead). */
 int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh,
                      double *grad, int64_t n_grad, double *dG_out);

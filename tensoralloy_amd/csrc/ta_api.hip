@@ -1802,10 +1802,10 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
     return ta_energy_gradient(h, frame_coeff, grad, n_grad);
   }
   if (h->eam) {
-    // nn functions of a plain EAM model (round 3): one second-order pass per network, ta_eam.hip::eam_loss_gradient
+    // nn functions of an EAM / ADP model (round 3): one second-order pass per network, ta_eam.hip::eam_loss_gradient
     if (!ta::eam_loss_gradient_supported(h->eam))
-      return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term covers plain EAM models "
-                                         "(Zjw04-family or tabulated analytic parts); ADP keeps the central difference");
+      return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: the analytic force / stress term covers EAM / ADP models "
+                                         "whose analytic parts are of the Zjw04 family or tabulated");
     if (h->filtered)
       return fail(h, TA_ERR_UNSUPPORTED, "ta_loss_gradient: not available on a skin-filtered batch; "
                                          "ta_set_skin(h, 0) and ta_set_frames first");

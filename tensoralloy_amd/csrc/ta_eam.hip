@@ -2018,6 +2018,11 @@ namespace {
 //   embedding net of element e: rows = its atoms, x = rho_i,  a = c_f,                          b = rhodot_i
 //   density net of species s:   rows = pairs to s, x = r_p,    a = c_f F'(rho_i) + F''(rho_i) rhodot_i,  b = F'(rho_i) rdot_p
 //   pair net of type t:         rows = pairs of t, x = r_p,    a = c_f / 2,                      b = rdot_p / 2
+// ADP adds 1/2 |mu|^2 + 1/2 sum lambda_ab^2 - (tr lambda)^2 / 6 per (atom, neighbour species), mu = sum u(r) D,
+// lambda = sum w(r) D (x) D; with T = the tangent of D, mudot = sum (u' rdot D + u T), lambdadot likewise, and
+// Lambda = lambda - tr lambda / 3 (what `mom` stores), D E_adp = mu . mudot + Lambda : lambdadot, so
+//   dipole net of type t:       a = c_f mu.D + mudot.D + mu.T,                         b = rdot_p mu.D
+//   quadrupole net of type t:   a = c_f D.Lambda.D + D.Lambdadot.D + 2 T.Lambda.D,     b = rdot_p D.Lambda.D
 // (launch_mlp_grad2_rows: one second-order pass per network). F'' of an embedding NETWORK comes from a
 // value / first / second derivative sweep (scalar_net_d2_kernel), of an analytic or tabulated
 // embedding function from dual arithmetic as in the Hessian-vector kernels.
@@ -2067,7 +2072,8 @@ __global__ __launch_bounds__(kBlock) void scalar_net_d2_kernel(MlpDev net, int a
 __global__ __launch_bounds__(kBlock) void eam_lg_atom_kernel(EamParams P, DeviceBatch b, HvpArgs a,
                                                              const TabDev *__restrict__ tabs,
                                                              const double *__restrict__ pf, size_t ps,
-                                                             double *rdot, double *rhodot, double *d2F) {
+                                                             double *rdot, double *rhodot, double *d2F,
+                                                             double *momdot) {
   __shared__ Dual el[kMaxEamElements][20];
   const int nel = P.nel;
   for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
@@ -2083,6 +2089,11 @@ __global__ __launch_bounds__(kBlock) void eam_lg_atom_kernel(EamParams P, Device
   double acc = 0.0, rho_sum = 0.0;
   for (int sb = 0; sb < nel; ++sb) {
     const bool rho_nn = (P.nn_rho >> sb) & 1u, rho_tab = (P.tab_rho >> sb) & 1u;
+    const int pt = pair_type(sA, sb, nel);
+    const double *pp = P.pair[pt];
+    const bool u_nn = (P.nn_u >> pt) & 1u, u_tab = (P.tab_u >> pt) & 1u;
+    const bool w_nn = (P.nn_w >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
+    double md[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ADP: mu-dot, lambda-dot (xx yy zz yz xz xy) of (i, sb)
     for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
       const int j = b.pair_j[q];
       const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
@@ -2111,6 +2122,43 @@ __global__ __launch_bounds__(kBlock) void eam_lg_atom_kernel(EamParams P, Device
       }
       rho_sum += f;
       acc = fma(df, rd, acc);
+      if (P.adp) {  // mu-dot = sum (u' rdot D + u T), lambda-dot = sum (w' rdot D (x) D + w (T (x) D + D (x) T))
+        double u, du, w, dw;
+        if (u_nn) {
+          u = pf[PF_U * ps + q];
+          du = pf[PF_DU * ps + q];
+        } else if (u_tab) {
+          spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
+        } else {
+          mishin_polar<double>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        }
+        if (w_nn) {
+          w = pf[PF_W * ps + q];
+          dw = pf[PF_DW * ps + q];
+        } else if (w_tab) {
+          spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
+        } else {
+          mishin_polar<double>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        }
+        const double ur = du * rd, wr = dw * rd;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) md[c] += ur * D[c] + u * T[c];
+        md[3] += wr * D[0] * D[0] + 2.0 * w * T[0] * D[0];
+        md[4] += wr * D[1] * D[1] + 2.0 * w * T[1] * D[1];
+        md[5] += wr * D[2] * D[2] + 2.0 * w * T[2] * D[2];
+        md[6] += wr * D[1] * D[2] + w * (T[1] * D[2] + D[1] * T[2]);
+        md[7] += wr * D[0] * D[2] + w * (T[0] * D[2] + D[0] * T[2]);
+        md[8] += wr * D[0] * D[1] + w * (T[0] * D[1] + D[0] * T[1]);
+      }
+    }
+    if (P.adp) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) md[k] = wave_sum(md[k]);
+      if (lane == 0) {
+        const double nu = md[3] + md[4] + md[5];  // stored like the moments themselves: trace removed
+        double *dst = momdot + ((size_t)i * nel + sb) * 9;
+        for (int k = 0; k < 9; ++k) dst[k] = (k >= 3 && k < 6) ? md[k] - nu / 3.0 : md[k];
+      }
     }
   }
   acc = wave_sum(acc);
@@ -2133,24 +2181,54 @@ __global__ __launch_bounds__(kBlock) void eam_lg_coeff_kernel(EamParams P, Devic
                                                               const double *__restrict__ frame_coeff,
                                                               const double *__restrict__ dF,
                                                               const double *__restrict__ d2F,
-                                                              const double *__restrict__ rdot, double *ca,
-                                                              double *cb) {
+                                                              const double *__restrict__ rdot,
+                                                              const double *__restrict__ mom,
+                                                              const double *__restrict__ momdot, HvpArgs a,
+                                                              double *ca, double *cb) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= b.n_pairs) return;
   const int nel = P.nel;
-  const int i = b.pair_i[p];
-  const int sA = b.species[i], sb = b.species[b.pair_j[p]];
+  const int i = b.pair_i[p], j = b.pair_j[p];
+  const int sA = b.species[i], sb = b.species[j];
   const int key = cls == 0 ? sb : pair_type(sA, sb, nel);
   double va = 0.0, vb = 0.0;
-  const bool listed = !(P.list_rc2 > 0.0) || pair_geom(b, (size_t)p)[1].y < P.list_rc2;
+  // the pair vector again from the coordinates (the records need not exist in every mode of the forward pass)
+  const int fr = b.frame_of_atom[i];
+  const double *h = b.cells + 9 * (size_t)fr;
+  const int S[3] = {b.pair_shift[3 * (size_t)p], b.pair_shift[3 * (size_t)p + 1], b.pair_shift[3 * (size_t)p + 2]};
+  double D[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    D[c] = (b.pos[3 * (size_t)j + c] - b.pos[3 * (size_t)i + c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+  const double r2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2] + a.eps;
+  const bool listed = !(P.list_rc2 > 0.0) || r2 < P.list_rc2;
   if (key == k && listed) {
-    const double c = frame_coeff ? frame_coeff[b.frame_of_atom[i]] : 0.0;
+    const double c = frame_coeff ? frame_coeff[fr] : 0.0;
     if (cls == 0) {
       va = c * dF[i] + d2F[i];
       vb = dF[i] * rdot[p];
-    } else {
+    } else if (cls == 1) {
       va = 0.5 * c;
       vb = 0.5 * rdot[p];
+    } else {
+      double T[3];
+      hvp_pair_tangent(a, b, 0, i, j, fr, S, T);
+      const double *m = mom + ((size_t)i * nel + sb) * 9, *md = momdot + ((size_t)i * nel + sb) * 9;
+      if (cls == 2) {  // dipole function u: E through mu = sum u D
+        const double muD = m[0] * D[0] + m[1] * D[1] + m[2] * D[2];
+        va = c * muD + (md[0] * D[0] + md[1] * D[1] + md[2] * D[2]) + (m[0] * T[0] + m[1] * T[1] + m[2] * T[2]);
+        vb = rdot[p] * muD;
+      } else {         // quadrupole function w: E through lambda = sum w D (x) D; m[3..8] = Lambda (trace removed)
+        auto quad = [](const double *q, const double *x, const double *y) {
+          const double lx = q[3] * y[0] + q[8] * y[1] + q[7] * y[2];
+          const double ly = q[8] * y[0] + q[4] * y[1] + q[6] * y[2];
+          const double lz = q[7] * y[0] + q[6] * y[1] + q[5] * y[2];
+          return x[0] * lx + x[1] * ly + x[2] * lz;
+        };
+        const double DLD = quad(m, D, D);
+        va = c * DLD + quad(md, D, D) + 2.0 * quad(m, T, D);
+        vb = rdot[p] * DLD;
+      }
     }
   }
   ca[p] = va;
@@ -2159,7 +2237,6 @@ __global__ __launch_bounds__(kBlock) void eam_lg_coeff_kernel(EamParams P, Devic
 }  // namespace
 
 bool eam_loss_gradient_supported(const EamModel *m) {
-  if (m->p.adp) return false;  // dipole / quadrupole networks: the central difference stays
   for (int e = 0; e < m->p.nel; ++e)
     if (m->p.el_kind[e] != 0) return false;
   for (int sl = 0; sl < m->n_slots; ++sl)
@@ -2185,13 +2262,14 @@ void eam_loss_gradient(EamModel *m, const DeviceBatch &b, const double *frame_co
   }
   grow(m->gscratch, m->cap_gscratch, scratch + 8);
   grow(m->gpartial, m->cap_gpartial, partial + 8);
-  grow(m->gcoeff, m->cap_gcoeff, 3 * (size_t)n_pairs + 2 * (size_t)n_atoms + 8);
+  grow(m->gcoeff, m->cap_gcoeff, 3 * (size_t)n_pairs + (2 + (m->p.adp ? 9 * (size_t)nel : 0)) * (size_t)n_atoms + 8);
   double *ca = m->gcoeff, *cb = ca + n_pairs, *rdot = cb + n_pairs, *rhodot = rdot + n_pairs, *d2F = rhodot + n_atoms;
+  double *momdot = d2F + n_atoms;  // ADP: tangents of the moments [n_atoms][nel][9]
   const double *rbuf = m->pf ? m->pf + (size_t)(m->p.adp ? 8 : 4) * m->cap_pairs : nullptr;
   const HvpArgs a{1, 0, 0, dR, dh, m->eps};
   if (n_atoms > 0)
     hipLaunchKernelGGL(eam_lg_atom_kernel, dim3((unsigned)((n_atoms + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock),
-                       0, s, m->p, b, a, m->tabs_dev, m->pf, m->cap_pairs, rdot, rhodot, d2F);
+                       0, s, m->p, b, a, m->tabs_dev, m->pf, m->cap_pairs, rdot, rhodot, d2F, momdot);
   for (int e = 0; e < nel; ++e) {
     const MlpDev &net = m->nets[slot_embed(nel, e)];
     const int n_el = b.elem_start[e + 1] - b.elem_start[e];
@@ -2215,7 +2293,7 @@ void eam_loss_gradient(EamModel *m, const DeviceBatch &b, const double *frame_co
     const int k = sl < nel ? sl : (sl - 2 * nel) % npair;
     if (n_pairs > 0)
       hipLaunchKernelGGL(eam_lg_coeff_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                         m->p, b, cls, k, frame_coeff, m->dF, d2F, rdot, ca, cb);
+                         m->p, b, cls, k, frame_coeff, m->dF, d2F, rdot, m->mom, momdot, a, ca, cb);
     launch_mlp_grad2_rows(net, m->activation, nullptr, n_pairs, rbuf, cb, ca, nullptr, nullptr, m->gscratch,
                           m->gpartial, g, s);
   }

@@ -352,10 +352,10 @@ class Trainer:
     pass per step, energy term included). An EAM model whose functions are all analytic trains their
     CONSTANTS instead (potentials/potentials.py:129-163): `ta_constant_gradient` differentiates the
     same functional in dual arithmetic, one seeded constant per grid row. The nn functions of a plain EAM
-    model (round 3) enter D_delta E through their values and input derivatives at known points: one
-    second-order pass per network (`ta_loss_gradient` again). ADP models keep the central difference of
-    g = dE/dtheta on two displaced copies of every frame (`analytic=False` forces it everywhere; step
-    `fd_step` Angstrom, error O(step^2)).
+    / ADP model (round 3) enter D_delta E through their values and input derivatives at known points: one
+    second-order pass per network (`ta_loss_gradient` again), ADP's dipole and quadrupole networks
+    included. `analytic=False` forces the central difference of g = dE/dtheta on two displaced copies of
+    every frame everywhere (step `fd_step` Angstrom, error O(step^2)).
     """
 
     def __init__(self, nn, frames, energies, forces=None, stresses=None, device=None,
@@ -376,11 +376,11 @@ class Trainer:
         self.constants_mode = hasattr(nn, "nn_functions") and not any(s is not None for s in nn.nn_functions())
         # the analytic second-order pass exists for the per-atom MLP models (and, in dual arithmetic,
         # for the constants)
-        # ... and, since round 3, for the nn functions of a plain EAM model (`ta_loss_gradient`, one
-        # second-order pass per network); ADP's dipole / quadrupole networks keep the central difference
-        eam_nets = hasattr(nn, "nn_functions") and not self.constants_mode
-        plain_eam = eam_nets and type(nn).__name__ == "EamAlloyNN"
-        self.analytic = (not eam_nets or plain_eam) if analytic is None else bool(analytic)
+        # ... and, since round 3, for the nn functions of EAM / ADP models (`ta_loss_gradient`, one
+        # second-order pass per network); the library refuses the sutton90 / Be/1 / grimes families, for
+        # which loss_and_gradient falls back to the central difference
+        self._eam_nets = hasattr(nn, "nn_functions") and not self.constants_mode
+        self.analytic = True if analytic is None else bool(analytic)
         if self.constants_mode and not self.analytic:
             raise ValueError("the constants have no finite-difference path")
         self._resident = False
@@ -464,7 +464,13 @@ class Trainer:
             dh = np.array([np.asarray(a.get_cell(complete=True), dtype=np.float64) @ Y[k]
                            for k, a in enumerate(self.frames)])
             gradient = eng.constant_gradient if self.constants_mode else eng.loss_gradient
-            grad = gradient(c, dR if second else None, dh if second else None)
+            try:
+                grad = gradient(c, dR if second else None, dh if second else None)
+            except RuntimeError as err:
+                if not (self._eam_nets and "ta_loss_gradient" in str(err)):
+                    raise
+                self.analytic = self._resident = False   # a family without the analytic pass
+                return self.loss_and_gradient()
         elif second:
             disp, coeff = [], []
             for k, a in enumerate(self.frames):

@@ -493,7 +493,7 @@ def test_pressure_rrmse_and_l2_terms_in_the_trainer(lib):
         assert abs(fd - grad[k]) < 2e-6 * max(1.0, abs(fd)), (k, fd, grad[k])
 
 
-@pytest.mark.parametrize("kind", ["eam_ni", "eam_binary_mixed", "eam_setfl_embed"])
+@pytest.mark.parametrize("kind", ["eam_ni", "eam_binary_mixed", "eam_setfl_embed", "adp", "adp_mixed"])
 def test_nn_eam_analytic_force_stress_loss_gradient(lib, kind):
     """Round 3: d/dtheta [sum_f c_f E_f + D_(dR, dh) E] for the nn functions of a plain EAM model in one
     second-order pass per network (`ta_loss_gradient`, ta_eam.hip::eam_loss_gradient), against (a) the
@@ -510,10 +510,17 @@ def test_nn_eam_analytic_force_stress_loss_gradient(lib, kind):
                 "NiNi": {"phi": "zjw04"}, "MoNi": {"phi": "nn"}, "MoMo": {"phi": "nn"}}
         nn = make_eam(["Mo", "Ni"], 6.0, potential=pots, hidden_sizes=[12])
         frames = [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))]
-    else:
+    elif kind == "eam_setfl_embed":
         pots = {"Ni": {"rho": "nn", "embed": "zjw04"}, "NiNi": {"phi": "nn"}}
         nn = make_eam(["Ni"], 5.5, potential=pots, hidden_sizes=[8, 8])
         frames = [fcc(rep=(2, 2, 2), jitter=0.1, seed=7)]
+    elif kind == "adp":   # every function a network, dipole and quadrupole included
+        nn = make_eam(["Mo", "Ni"], 5.5, adp=True, potential=None, hidden_sizes=[8, 8])
+        frames = [_alloy(["Ni", "Mo"], rep=(2, 2, 2))]
+    else:                 # analytic MishinH dipole, quadrupole network
+        pots = {"Ni": {"rho": "nn", "embed": "nn"}, "NiNi": {"phi": "zjw04", "dipole": "mishinh", "quadrupole": "nn"}}
+        nn = make_eam(["Ni"], 5.5, adp=True, potential=pots, hidden_sizes=[8])
+        frames = [fcc(rep=(2, 2, 2), jitter=0.1, seed=9)]
     rng = np.random.RandomState(11)
     coeff = rng.randn(len(frames))
     dR = [rng.randn(len(a), 3) * 0.3 for a in frames]
