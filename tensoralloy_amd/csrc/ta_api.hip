@@ -241,6 +241,9 @@ struct ta_context {
   DevBuf<unsigned long long> nl_stats, nl_zero;
   unsigned long long *nl_stats_ptr = nullptr;  // statistics block of the builder that made the list
   bool nl_sorted = false;  // list in key order (one-pass builder): reverse pairs by binary search
+  bool nl_zero_clean = false;  // nl_zero is all zero where the next list needs it (see nl_build)
+  int64_t nl_zero_atoms = -1;
+  int nl_zero_bins = -1;
   DevBuf<double> hvp_buf;  // ta_hessian_vectors: tangents in, force / virial tangents out
 #ifdef TA_PHASE_STAMPS
   DevBuf<unsigned long long> stamp_buf;
@@ -624,21 +627,29 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
   h->nl_sorted = false;
   const bool kernel_writes_host = !(std::getenv("TA_NL_COPY_STARTS") && std::getenv("TA_NL_COPY_STARTS")[0] == '1');
   if (!two_pass_only) {
-    h->nl_zero.ensure(nl_build_zero_words((int)N, n_bins));
+    {  // the zero block stays clean from list to list while its layout (atoms, bins) does not change
+      const unsigned long long *before = h->nl_zero.ptr;
+      h->nl_zero.ensure(nl_build_zero_words((int)N, n_bins));
+      if (h->nl_zero.ptr != before || h->nl_zero_atoms != (int64_t)N || h->nl_zero_bins != n_bins) h->nl_zero_clean = false;
+      h->nl_zero_atoms = (int64_t)N;
+      h->nl_zero_bins = n_bins;
+    }
     for (int attempt = 0; attempt < 2 && !h->nl_sorted; ++attempt) {
       const size_t capacity = std::min(std::min(h->pair_i.cap, h->pair_j.cap), h->pair_shift.cap / 3);
       NlWork w = nl_work(h);
       // the kernel writes the per-atom offsets to the page-locked buffer itself; the statistics follow
       // in one small copy kernel once every group is through
       nl_build((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
-               h->nl_zero.ptr, (long long)std::min<size_t>(capacity, (size_t)INT32_MAX), h->pair_start.ptr,
+               h->nl_zero.ptr, h->nl_zero_clean, (long long)std::min<size_t>(capacity, (size_t)INT32_MAX), h->pair_start.ptr,
                kernel_writes_host ? starts : nullptr, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr, s);
       HIP_CHECK(hipGetLastError());
+      h->nl_zero_clean = false;  // until this list is through (an exception below leaves it marked dirty)
       if (!kernel_writes_host)
         staged_copy(reinterpret_cast<double *>(starts), reinterpret_cast<const double *>(h->pair_start.ptr),
                     (N + 2) / 2, true, s);
       staged_copy(reinterpret_cast<double *>(stats), reinterpret_cast<const double *>(h->nl_zero.ptr), 8, true, s);
       wait_stream(s);
+      h->nl_zero_clean = N > 0;  // the kernels ran to the end: histogram cleared, the rest is cleared on entry
       if (si[3] != 0) break;  // beyond the one-pass builder's limits
       if (stats[4] > (unsigned long long)INT32_MAX) throw std::runtime_error("batch too large for 32-bit pair indices");
       if (stats[4] <= capacity) {
@@ -1224,14 +1235,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   } else {
     ta::eam_ensure(h->eam, h->db);
   }
-  wait_stream(h->stream);  // staging buffers are reused by the next call
-  h->upload_pending = false;
-  if (h->pairs_on_device) {
-    nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
-    if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
-      throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
-  }
   // what ta_update_positions needs: the geometry this list was built for and the frames' shapes
+  // (host-side copies, made while the device still works on the reverse index)
   h->o_pos = o_pos;
   h->o_cells = o_cells;
   h->o_species = o_species;
@@ -1243,6 +1248,13 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   for (size_t f = 0; f < F; ++f) {
     h->keep_natoms[f] = frames[f].n_atoms;
     for (int a3 = 0; a3 < 3; ++a3) h->keep_pbc[3 * f + a3] = frames[f].pbc[a3] ? 1 : 0;
+  }
+  wait_stream(h->stream);  // staging buffers are reused by the next call
+  h->upload_pending = false;
+  if (h->pairs_on_device) {
+    nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
+    if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
+      throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
   }
   if (filter_applies(h)) apply_filter(h);
   if (h->eam) ta::eam_set_list_cutoff(h->eam, (h->skin > 0.0 && !h->filtered) ? h->rmax : 0.0);

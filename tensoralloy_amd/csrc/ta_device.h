@@ -190,7 +190,8 @@ struct NlGrid {  // linked-cell grid of one frame, in fractional coordinates
   // neighbouring bins looked at along each axis: offsets -m .. m (1 unless the cell is thinner than the
   // cutoff along a periodic axis: then nb = 1 there and m = floor(rmax / height) + 1 images of the one bin)
   int32_t m[3];
-  int32_t pad2_;
+  int32_t ortho;    // cell vectors mutually orthogonal: the per-axis gaps to a bin add in quadrature
+  double bw[3];     // perpendicular (Cartesian) width of one bin along each axis; 0 = unknown, no pruning
 };
 struct NlRec {  // one atom, stored in bin order
   double x, y, z;
@@ -221,8 +222,8 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
 size_t nl_build_zero_words(int n_atoms, int n_bins);
 void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
-              long long capacity, int32_t *pair_start, int32_t *host_pair_start, int32_t *pair_i,
-              int32_t *pair_j, int32_t *pair_shift, hipStream_t s);
+              bool zero_is_clean, long long capacity, int32_t *pair_start, int32_t *host_pair_start,
+              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, hipStream_t s);
 void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
                        const int32_t *pair_i, const int32_t *pair_j, const int32_t *pair_shift,
                        int32_t *pair_rev, unsigned long long *stats, hipStream_t s);

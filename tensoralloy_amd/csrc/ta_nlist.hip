@@ -36,8 +36,12 @@ __global__ __launch_bounds__(kBlock) void bin_atoms_kernel(int n_atoms, const do
                                                            const int32_t *frame_of_atom,
                                                            const NlGrid *grids, int32_t *wrap,
                                                            int32_t *binid, int32_t *bin_count,
-                                                           int32_t *slot_in_bin) {
+                                                           int32_t *slot_in_bin, unsigned long long *clear,
+                                                           int n_clear) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  // one-pass builder: its statistics and look-back words of the PREVIOUS call are cleared here, before the
+  // kernel that uses them (no memset launch in front of every list)
+  for (int k = i; k < n_clear; k += gridDim.x * kBlock) clear[k] = 0ull;
   if (i >= n_atoms) return;
   const NlGrid &g = grids[frame_of_atom[i]];
   const double *r = pos + 3 * (size_t)i;
@@ -348,10 +352,43 @@ __device__ __forceinline__ unsigned long long nl_key(int sp, int j, int sx, int 
          ((unsigned long long)(unsigned)(sy + kShiftBias) << 10) | (unsigned long long)(unsigned)(sz + kShiftBias);
 }
 
-__global__ __launch_bounds__(kBlock) void place_recs_kernel(int n_atoms, const double *pos,
+// SCAN: every workgroup forms the bins' offsets itself in LDS (a few hundred bins for one frame) instead of
+// a one-workgroup scan launch in front; workgroup 0 also leaves them in `bin_start` for the pair kernel
+constexpr int kPlaceScanBins = 2048;
+
+template <bool SCAN>
+__global__ __launch_bounds__(kBlock) void place_recs_kernel(int n_atoms, int n_bins, const double *pos,
                                                             const int32_t *species, const int32_t *wrap,
-                                                            const int32_t *binid, const int32_t *bin_start,
-                                                            const int32_t *slot_in_bin, NlRec *recs) {
+                                                            const int32_t *binid, const int32_t *bin_count,
+                                                            int32_t *bin_start, const int32_t *slot_in_bin,
+                                                            NlRec *recs) {
+  __shared__ int start[SCAN ? kPlaceScanBins + 1 : 1];
+  __shared__ int wtot[kBlock / 64];
+  if constexpr (SCAN) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk = (n_bins + kBlock - 1) / kBlock;
+    const int lo = min(n_bins, t * chunk), hi = min(n_bins, lo + chunk);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += bin_count[k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int k = lo; k < hi; ++k) {
+      start[k] = run;
+      run += bin_count[k];
+    }
+    if (t == kBlock - 1) start[n_bins] = run;
+    __syncthreads();
+    if (blockIdx.x == 0)
+      for (int k = t; k <= n_bins; k += kBlock) bin_start[k] = start[k];
+  }
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_atoms) return;
   NlRec r;
@@ -364,15 +401,16 @@ __global__ __launch_bounds__(kBlock) void place_recs_kernel(int n_atoms, const d
   r.j = i;
   r.sp = species[i];
   r.pad_ = 0;
-  recs[bin_start[binid[i]] + slot_in_bin[i]] = r;
+  const int first = SCAN ? start[binid[i]] : bin_start[binid[i]];
+  recs[first + slot_in_bin[i]] = r;
 }
 
 // stats (8 x u64, zero before the launch): [0] triples; as int32: [2] nnl_max, [3] `bad` (a centre beyond
 // the limits, or the look-back gave up: use the two-pass builder), [6] reverse pairs missing; [4] pairs.
 __global__ __launch_bounds__(64 * kBuildGroup) void build_pairs_kernel(
     int n_atoms, int nel, double rmax, const double *pos, const int32_t *frame_of_atom, const NlGrid *grids,
-    const int32_t *wrap, const int32_t *binid, const int32_t *bin_start, const NlRec *recs,
-    unsigned long long *gstate, long long capacity, int32_t *seg_start, int32_t *pair_start,
+    const int32_t *wrap, const int32_t *binid, const int32_t *bin_start, const NlRec *recs, int32_t *bin_count,
+    int n_bins, unsigned long long *gstate, long long capacity, int32_t *seg_start, int32_t *pair_start,
     int32_t *host_pair_start, int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift,
     unsigned long long *stats) {
   __shared__ unsigned long long stash[kBuildGroup][kBuildStash];
@@ -383,6 +421,9 @@ __global__ __launch_bounds__(64 * kBuildGroup) void build_pairs_kernel(
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * kBuildGroup + w);
   const bool act = i < n_atoms;
+  // the bin histogram has been consumed (place_recs_kernel): cleared here for the next list
+  for (int k = blockIdx.x * 64 * kBuildGroup + threadIdx.x; k <= n_bins; k += gridDim.x * 64 * kBuildGroup)
+    bin_count[k] = 0;
   unsigned long long *mine = stash[w];
   int n = 0;
   bool bad = false;
@@ -396,13 +437,37 @@ __global__ __launch_bounds__(64 * kBuildGroup) void build_pairs_kernel(
     const int e0 = 2 * g.m[0] + 1, e1 = 2 * g.m[1] + 1, e2 = 2 * g.m[2] + 1;
     const int n_combo = e0 * e1 * e2;
     constexpr int kSelf = 0x888;
+    // where the centre sits inside its own bin (0 .. 1 per axis): a neighbouring bin whose nearest face is
+    // farther than rmax holds no neighbour and is skipped (27 bins of width >= rmax hold 6.4 times the
+    // sphere's volume; for an orthogonal cell about a third of them drop out)
+    const int own[3] = {bx, by, bz};
+    double inbin[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double fa = rix * g.hinv[0 * 3 + a] + riy * g.hinv[1 * 3 + a] + riz * g.hinv[2 * 3 + a];
+      if (g.pbc[a]) fa -= floor(fa);
+      const double t = (fa - g.lo[a]) * g.inv_w[a] - own[a];
+      inbin[a] = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    }
     for (int c0 = 0; c0 < n_combo; c0 += 27) {
       int lo = 0, len = 0, code = kSelf;
       if (lane < 27 && c0 + lane < n_combo) {
         const int id = c0 + lane;
-        int c[3] = {bx + id / (e1 * e2) - g.m[0], by + (id / e2) % e1 - g.m[1], bz + id % e2 - g.m[2]};
+        const int d[3] = {id / (e1 * e2) - g.m[0], (id / e2) % e1 - g.m[1], id % e2 - g.m[2]};
+        int c[3] = {bx + d[0], by + d[1], bz + d[2]};
         int sh[3] = {0, 0, 0};
         bool ok = true;
+        {
+          double far2 = 0.0, far1 = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double gap = d[a] == 0 ? 0.0 : ((d[a] < 0 ? -d[a] - 1 + inbin[a] : d[a] - inbin[a]) * g.bw[a]);
+            far2 = fma(gap, gap, far2);
+            far1 = gap > far1 ? gap : far1;
+          }
+          const double lim = rmax * (1.0 + 1e-9);
+          if (g.ortho ? far2 > lim * lim : far1 > lim) ok = false;
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           if (c[a] < 0 || c[a] >= g.nb[a]) {
@@ -821,6 +886,15 @@ bool nl_make_grid(const ta_frame &fr, double rmax, int bin_offset, NlGrid &g) {
       g.inv_w[a] = ext > 0 ? nb / ext : 0.0;
     }
   }
+  for (int a = 0; a < 3; ++a) {
+    const double height = vol / norm(cr[a]);
+    g.bw[a] = g.inv_w[a] > 0.0 ? height / g.inv_w[a] : 0.0;
+  }
+  auto dot = [&](int a, int b) { return g.h[3 * a] * g.h[3 * b] + g.h[3 * a + 1] * g.h[3 * b + 1] + g.h[3 * a + 2] * g.h[3 * b + 2]; };
+  g.ortho = 1;
+  for (int a = 0; a < 3; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (std::fabs(dot(a, b)) > 1e-12 * std::sqrt(dot(a, a) * dot(b, b))) g.ortho = 0;
   g.bin_offset = bin_offset;
   return true;
 }
@@ -838,7 +912,7 @@ void nl_count(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
   (void)hipMemsetAsync(w.stats, 0, 8 * sizeof(unsigned long long), s);
   if (n_atoms == 0) return;
   hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
-                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, (int32_t *)nullptr);
+                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, (int32_t *)nullptr, (unsigned long long *)nullptr, 0);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
                      (int32_t *)nullptr);
   hipLaunchKernelGGL(fill_bins_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms,
@@ -880,23 +954,32 @@ size_t nl_build_zero_words(int n_atoms, int n_bins) {
 
 void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
-              long long capacity, int32_t *pair_start, int32_t *host_pair_start, int32_t *pair_i,
-              int32_t *pair_j, int32_t *pair_shift, hipStream_t s) {
+              bool zero_is_clean, long long capacity, int32_t *pair_start, int32_t *host_pair_start,
+              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, hipStream_t s) {
   const size_t n_groups = nblk(n_atoms, kBuildGroup);
-  (void)hipMemsetAsync(zero, 0, nl_build_zero_words(n_atoms, n_bins) * sizeof(unsigned long long), s);
+  // `zero_is_clean`: the previous list had the same layout and left the histogram zero (build_pairs_kernel);
+  // the statistics and look-back words are cleared by bin_atoms_kernel
+  if (!zero_is_clean)
+    (void)hipMemsetAsync(zero, 0, nl_build_zero_words(n_atoms, n_bins) * sizeof(unsigned long long), s);
   w.stats = zero;
   unsigned long long *gstate = zero + 8;
   w.bin_count = reinterpret_cast<int32_t *>(zero + 8 + n_groups + 1);
   if (n_atoms == 0) return;
   hipLaunchKernelGGL(bin_atoms_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
-                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, w.bin_atoms);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
-                     (int32_t *)nullptr);
-  hipLaunchKernelGGL(place_recs_kernel, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, pos,
-                     species, w.wrap, w.binid, w.bin_start, w.bin_atoms, w.recs);
+                     frame_of_atom, grids, w.wrap, w.binid, w.bin_count, w.bin_atoms, zero,
+                     (int)(8 + n_groups + 1));
+  if (n_bins <= kPlaceScanBins) {
+    hipLaunchKernelGGL(place_recs_kernel<true>, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, n_bins,
+                       pos, species, w.wrap, w.binid, w.bin_count, w.bin_start, w.bin_atoms, w.recs);
+  } else {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, n_bins, w.bin_count, w.bin_start,
+                       (int32_t *)nullptr);
+    hipLaunchKernelGGL(place_recs_kernel<false>, dim3(nblk(n_atoms, kBlock)), dim3(kBlock), 0, s, n_atoms, n_bins,
+                       pos, species, w.wrap, w.binid, w.bin_count, w.bin_start, w.bin_atoms, w.recs);
+  }
   hipLaunchKernelGGL(build_pairs_kernel, dim3(n_groups), dim3(64 * kBuildGroup), 0, s, n_atoms, nel, rmax,
-                     pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start, w.recs, gstate, capacity,
-                     w.seg_start, pair_start, host_pair_start, pair_i, pair_j, pair_shift, zero);
+                     pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start, w.recs, w.bin_count, n_bins, gstate,
+                     capacity, w.seg_start, pair_start, host_pair_start, pair_i, pair_j, pair_shift, zero);
 }
 
 void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
