@@ -241,6 +241,7 @@ struct ta_context {
   DevBuf<unsigned long long> nl_stats, nl_zero;
   unsigned long long *nl_stats_ptr = nullptr;  // statistics block of the builder that made the list
   bool nl_sorted = false;  // list in key order (one-pass builder): reverse pairs by binary search
+  bool nl_rev_done = false;  // ... and the reverse index is already there (launched behind the pairs)
   bool nl_zero_clean = false;  // nl_zero is all zero where the next list needs it (see nl_build)
   int64_t nl_zero_atoms = -1;
   int nl_zero_bins = -1;
@@ -634,14 +635,22 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
       h->nl_zero_atoms = (int64_t)N;
       h->nl_zero_bins = n_bins;
     }
+    h->nl_rev_done = false;
     for (int attempt = 0; attempt < 2 && !h->nl_sorted; ++attempt) {
       const size_t capacity = std::min(std::min(h->pair_i.cap, h->pair_j.cap), h->pair_shift.cap / 3);
+      // the reverse index is launched right behind the pairs, before the count is known here: over as many
+      // pairs as the previous list of these atoms had (+ a quarter), at most what the arrays hold
+      h->pair_rev.ensure(capacity);
+      const size_t guess = (hp.n_atoms == (int64_t)N && hp.n_pairs > 0) ? (size_t)hp.n_pairs + (size_t)hp.n_pairs / 4 + 4096
+                                                                         : capacity;
+      const size_t rev_cover = std::min(std::min(capacity, guess), (size_t)INT32_MAX);
       NlWork w = nl_work(h);
       // the kernel writes the per-atom offsets to the page-locked buffer itself; the statistics follow
       // in one small copy kernel once every group is through
       nl_build((int)N, n_bins, nel, h->r_list, h->db.pos, h->db.species, h->db.frame_of_atom, h->d_grids, w,
                h->nl_zero.ptr, h->nl_zero_clean, (long long)std::min<size_t>(capacity, (size_t)INT32_MAX), h->pair_start.ptr,
-               kernel_writes_host ? starts : nullptr, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr, s);
+               kernel_writes_host ? starts : nullptr, h->pair_i.ptr, h->pair_j.ptr, h->pair_shift.ptr,
+               h->pair_rev.ptr, (long long)rev_cover, s);
       HIP_CHECK(hipGetLastError());
       h->nl_zero_clean = false;  // until this list is through (an exception below leaves it marked dirty)
       if (!kernel_writes_host)
@@ -654,6 +663,9 @@ void build_pairs_on_device(ta_context *h, size_t N, int n_bins) {
       if (stats[4] > (unsigned long long)INT32_MAX) throw std::runtime_error("batch too large for 32-bit pair indices");
       if (stats[4] <= capacity) {
         h->nl_sorted = true;
+        h->nl_rev_done = stats[4] <= rev_cover;  // (else fill_pairs_on_device launches it over the whole list)
+        if (h->nl_rev_done && si[6] != 0)
+          throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");
       } else {
         h->pair_i.ensure((size_t)stats[4]);
         h->pair_j.ensure((size_t)stats[4]);
@@ -1159,8 +1171,9 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   }
   if (!device_nl) std::memset(static_cast<void *>(grids), 0, F * sizeof(ta::NlGrid));
   // one upload for everything but blk_center (which needs the pair counts)
-  if (o_blk)
-    HIP_CHECK(hipMemcpyAsync(h->inbuf.ptr, hb, o_blk, hipMemcpyHostToDevice, h->stream));
+  if (o_blk)  // (small batches: by a kernel reading the page-locked buffer, see staged_copy; sections are 16-byte aligned)
+    staged_copy(reinterpret_cast<double *>(h->inbuf.ptr), reinterpret_cast<const double *>(hb), o_blk / sizeof(double),
+                false, h->stream);
   char *db_ = h->inbuf.ptr;
   h->db.n_frames = n_frames;
   h->db.pos = reinterpret_cast<double *>(db_ + o_pos);
@@ -1182,7 +1195,8 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   double nl_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nl).count();
   upload_batch(h);
   const auto t_fill = std::chrono::steady_clock::now();
-  if (h->pairs_on_device) {
+  const bool list_done = h->pairs_on_device && h->nl_sorted && h->nl_rev_done;  // nothing left but the run packing
+  if (h->pairs_on_device && !list_done) {
     fill_pairs_on_device(h);
     // "reverse pair missing" counter, read after the synchronisation below
     staged_copy(reinterpret_cast<double *>(h->stage_out.ptr), reinterpret_cast<const double *>(h->nl_stats_ptr),
@@ -1220,9 +1234,13 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
     }
     h->db.n_blk = nb ? nb - 1 : 0;
     ensure_job_lists(h, (size_t)h->db.n_blk);
-    if (nb)
-      HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
-                               h->stream));
+    if (nb) {
+      if (list_done)  // a kernel on the compute stream reads the page-locked buffer: no DMA hand-over
+        staged_copy(reinterpret_cast<double *>(db_ + o_blk), reinterpret_cast<const double *>(blk), ((size_t)nb + 1) / 2,
+                    false, h->stream);
+      else
+        HIP_CHECK(hipMemcpyAsync(db_ + o_blk, blk, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
   }
   if (h->kind == TA_MODEL_SF_MLP) {
     if (!h->use_v2 && ta::g4_lds_bytes(h->hp.nnl_max) > 160 * 1024 && h->sf.angular)
@@ -1249,9 +1267,15 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
     h->keep_natoms[f] = frames[f].n_atoms;
     for (int a3 = 0; a3 < 3; ++a3) h->keep_pbc[3 * f + a3] = frames[f].pbc[a3] ? 1 : 0;
   }
-  wait_stream(h->stream);  // staging buffers are reused by the next call
-  h->upload_pending = false;
-  if (h->pairs_on_device) {
+  if (list_done) {
+    // one-pass builder: the list was complete (and checked) at the builder's own wait; the run packing is
+    // in flight out of stage_in, whose next writer waits for the stream (upload_pending)
+    h->upload_pending = true;
+  } else {
+    wait_stream(h->stream);  // staging buffers are reused by the next call
+    h->upload_pending = false;
+  }
+  if (h->pairs_on_device && !list_done) {
     nl_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
     if (reinterpret_cast<const int32_t *>(h->stage_out.ptr)[6] != 0)
       throw std::runtime_error("neighbour list is not symmetric (reverse pair missing)");

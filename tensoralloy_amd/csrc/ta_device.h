@@ -223,7 +223,8 @@ size_t nl_build_zero_words(int n_atoms, int n_bins);
 void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
               bool zero_is_clean, long long capacity, int32_t *pair_start, int32_t *host_pair_start,
-              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, hipStream_t s);
+              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, long long rev_cover,
+              hipStream_t s);
 void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
                        const int32_t *pair_i, const int32_t *pair_j, const int32_t *pair_shift,
                        int32_t *pair_rev, unsigned long long *stats, hipStream_t s);

@@ -652,13 +652,22 @@ __global__ __launch_bounds__(64 * kBuildGroup) void build_pairs_kernel(
 
 // reverse pair in a list in key order: lower bound of i among the js of j's segment of species(i), then
 // the (few) images of i
+// `n_dev` (one-pass builder, launched right behind build_pairs_kernel, before the host knows the count):
+// the number of pairs is read from the device, the grid covers an estimate; a list that did not fit
+// `capacity` was not written and is left alone.
 __global__ __launch_bounds__(kBlock) void reverse_sorted_kernel(int64_t n_pairs, int nel,
+                                                                const unsigned long long *n_dev, int64_t capacity,
                                                                 const int32_t *species,
                                                                 const int32_t *seg_start,
                                                                 const int32_t *pair_i, const int32_t *pair_j,
                                                                 const int32_t *pair_shift, int32_t *pair_rev,
                                                                 int32_t *n_missing) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (n_dev) {
+    const unsigned long long n = *n_dev;
+    if (n > (unsigned long long)capacity) return;
+    n_pairs = (int64_t)n < n_pairs ? (int64_t)n : n_pairs;
+  }
   if (p >= n_pairs) return;
   const int i = pair_i[p], j = pair_j[p];
   const int sx = pair_shift[3 * p], sy = pair_shift[3 * p + 1], sz = pair_shift[3 * p + 2];
@@ -955,7 +964,8 @@ size_t nl_build_zero_words(int n_atoms, int n_bins) {
 void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, const int32_t *species,
               const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w, unsigned long long *zero,
               bool zero_is_clean, long long capacity, int32_t *pair_start, int32_t *host_pair_start,
-              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, hipStream_t s) {
+              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, long long rev_cover,
+              hipStream_t s) {
   const size_t n_groups = nblk(n_atoms, kBuildGroup);
   // `zero_is_clean`: the previous list had the same layout and left the histogram zero (build_pairs_kernel);
   // the statistics and look-back words are cleared by bin_atoms_kernel
@@ -980,6 +990,12 @@ void nl_build(int n_atoms, int n_bins, int nel, double rmax, const double *pos, 
   hipLaunchKernelGGL(build_pairs_kernel, dim3(n_groups), dim3(64 * kBuildGroup), 0, s, n_atoms, nel, rmax,
                      pos, frame_of_atom, grids, w.wrap, w.binid, w.bin_start, w.recs, w.bin_count, n_bins, gstate,
                      capacity, w.seg_start, pair_start, host_pair_start, pair_i, pair_j, pair_shift, zero);
+  // the reverse index right behind it, over the first `rev_cover` pairs (the caller's estimate of the count:
+  // it launches the kernel again should the list turn out longer)
+  if (pair_rev && rev_cover > 0)
+    hipLaunchKernelGGL(reverse_sorted_kernel, dim3(nblk(rev_cover, kBlock)), dim3(kBlock), 0, s, (int64_t)rev_cover, nel,
+                       zero + 4, (int64_t)capacity, species, w.seg_start, pair_i, pair_j, pair_shift, pair_rev,
+                       reinterpret_cast<int32_t *>(zero) + 6);
 }
 
 void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const int32_t *seg_start,
@@ -987,7 +1003,8 @@ void nl_reverse_sorted(int64_t n_pairs, int nel, const int32_t *species, const i
                        int32_t *pair_rev, unsigned long long *stats, hipStream_t s) {
   if (n_pairs > 0)
     hipLaunchKernelGGL(reverse_sorted_kernel, dim3(nblk(n_pairs, kBlock)), dim3(kBlock), 0, s, n_pairs, nel,
-                       species, seg_start, pair_i, pair_j, pair_shift, pair_rev,
+                       (const unsigned long long *)nullptr, (int64_t)0, species, seg_start, pair_i, pair_j, pair_shift,
+                       pair_rev,
                        reinterpret_cast<int32_t *>(stats) + 6);
 }
 
