@@ -11,7 +11,7 @@ OUT=$CS/build/stamps
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -I$ROOT/include -I$CS -DTA_PHASE_STAMPS -DTA_V2_FEW"
 pids=""
-for f in ta_api.hip ta_kernels.hip ta_kernels_v2.hip ta_mlp.hip ta_eam.hip ta_nlist.hip ta_grap.hip ta_train.hip ta_neighbor.cpp; do
+for f in ta_api.hip ta_kernels.hip ta_kernels_v2.hip ta_mlp.hip ta_eam.hip ta_nlist.hip ta_grap.hip ta_train.hip ta_hvp.hip ta_neighbor.cpp; do
   /opt/rocm/bin/hipcc $FLAGS -c $CS/$f -o $OUT/${f%.*}.o &
   pids="$pids $!"
 done

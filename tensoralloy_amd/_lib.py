@@ -20,7 +20,7 @@ INCLUDE_DIR = REPO_DIR / "include"
 LIB_PATH = PKG_DIR / "libtensoralloy_amd.so"
 
 SOURCES = ["ta_api.hip", "ta_kernels.hip", "ta_kernels_v2.hip", "ta_mlp.hip", "ta_eam.hip",
-           "ta_nlist.hip", "ta_grap.hip", "ta_train.hip", "ta_neighbor.cpp"]
+           "ta_nlist.hip", "ta_grap.hip", "ta_train.hip", "ta_hvp.hip", "ta_neighbor.cpp"]
 OBJ_DIR = CSRC_DIR / "build"
 
 TA_OK = 0

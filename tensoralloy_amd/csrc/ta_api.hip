@@ -33,7 +33,14 @@ void launch_mlp_grad(const MlpDev &mlp, int activation, int ndim, const int32_t 
 size_t mlp_grad2_scratch_doubles(const MlpDev &mlp, int n_atoms);
 void launch_mlp_grad2(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                       const DeviceBatch &b, const double *dG, const double *frame_coeff, double *scratch,
-                      double *partial, double *grad, hipStream_t s);
+                      double *partial, double *grad, hipStream_t s, double *kappa_out = nullptr);
+// analytic Hessian-vector products of the descriptor models (ta_hvp.hip)
+void launch_pair_vec(const DeviceBatch &b, double *Dv, hipStream_t s);
+void launch_backward_hvp(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz, bool first, bool angular,
+                         const DeviceBatch &b, const double *Dv, const double *Dd, const double *wdot, double *gv,
+                         double *gd, hipStream_t s);
+void launch_hvp_gather(const DeviceBatch &b, const double *Dv, const double *Dd, const double *gv, const double *gd,
+                       double *fdot, double *wdot_at, hipStream_t s);
 void launch_pair_tangent(const DeviceBatch &b, const double *dR, const double *dh, double *dD, hipStream_t s);
 void launch_descriptor_jvp(const DeviceBatch &b, int ndim, const double *J, const double *dD, double *dG,
                            hipStream_t s);
@@ -1827,6 +1834,26 @@ void backward_only(ta_context *h) {
     launch_grap_backward(h->grap, db, s);
   }
 }
+// J[c][p] = dG_{i(p), c} / dD_p of the resident batch: the backward kernels with a one-hot dE/dG, once per
+// channel and once per batch (ta_loss_gradient, ta_hessian_vectors of the descriptor models)
+void ensure_pair_jacobians(ta_context *h) {
+  hipStream_t s = h->stream;
+  const size_t N = (size_t)h->db.n_atoms, P = (size_t)h->db.n_pairs;
+  const int D = h->sf.ndim;
+  if (!h->descriptors_valid || !h->jvp_valid)
+    compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // pair records, masks, moments, descriptors
+  if (h->jvp_valid) return;
+  h->jvp_J.ensure((size_t)D * 4 * P + 8);
+  for (int c = 0; c < D; ++c) {
+    ta::launch_one_hot(h->db.dEdG, (int64_t)N, D, c, s);
+    backward_only(h);
+    if (P)
+      HIP_CHECK(hipMemcpyAsync(h->jvp_J.ptr + (size_t)c * 4 * P, h->db.g, 4 * P * sizeof(double),
+                               hipMemcpyDeviceToDevice, s));
+  }
+  HIP_CHECK(hipGetLastError());
+  h->jvp_valid = true;
+}
 }  // namespace
 
 int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, const double *dh, double *grad,
@@ -1889,21 +1916,7 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
     hipStream_t s = h->stream;
     const size_t N = (size_t)h->db.n_atoms, P = (size_t)h->db.n_pairs, F = (size_t)h->db.n_frames;
     const int D = h->sf.ndim;
-    if (!h->descriptors_valid || !h->jvp_valid)
-      compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // pair records, masks, moments, descriptors
-    if (!h->jvp_valid) {
-      // J[c][p] = dG_{i(p), c} / dD_p: the backward kernels with a one-hot dE/dG, once per channel
-      h->jvp_J.ensure((size_t)D * 4 * P + 8);
-      for (int c = 0; c < D; ++c) {
-        ta::launch_one_hot(h->db.dEdG, (int64_t)N, D, c, s);
-        backward_only(h);
-        if (P)
-          HIP_CHECK(hipMemcpyAsync(h->jvp_J.ptr + (size_t)c * 4 * P, h->db.g, 4 * P * sizeof(double),
-                                   hipMemcpyDeviceToDevice, s));
-      }
-      HIP_CHECK(hipGetLastError());
-      h->jvp_valid = true;
-    }
+    ensure_pair_jacobians(h);
     // direction -> pairs -> descriptors
     h->tan_dir.ensure(3 * N + 9 * F + 8);
     h->tan_dD.ensure(4 * P + 8);
@@ -2048,15 +2061,103 @@ int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *
                        double *dW) {
   if (!h || !dF || n_dir < 0) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
-  if (!h->eam || !ta::eam_hvp_supported(h->eam))
-    return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives exist for EAM models whose "
-                                       "functions are of the Zjw04 family or tabulated");
+  const bool sf_model = h->kind == TA_MODEL_SF_MLP;
+  if (sf_model) {
+    if (h->filtered)
+      return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: not available on a skin-filtered batch; "
+                                         "ta_set_skin(h, 0) and ta_set_frames first");
+    for (const ChunkPlan &cp : h->chunks)
+      for (int iz = 0; iz < cp.nz; ++iz)
+        if (cp.ch.zeta_int[iz] <= 0)
+          return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: integer zetas only");
+  } else if (!h->eam || !ta::eam_hvp_supported(h->eam)) {
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives exist for the symmetry-function "
+                                       "models and for EAM models whose functions are of the Zjw04 family or tabulated");
+  }
   const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
   const bool unit = !dR && !dh;
   if (unit && (first < 0 || (size_t)first + (size_t)n_dir > 3 * N))
     return fail(h, TA_ERR_INVALID, "ta_hessian_vectors: without dR / dh the directions are unit displacements "
                                    "first .. first + n_dir - 1 of the 3 N");
   if ((size_t)n_dir > 65535) return fail(h, TA_ERR_INVALID, "ta_hessian_vectors: at most 65535 directions per call");
+  if (sf_model)
+    return guarded(h, [&]() {
+      // Per direction: D-dot per pair, G-dot through the pair Jacobians, w-dot = H_mlp G-dot from the
+      // second-order MLP pass, then g and g-dot from the dual-arithmetic backward expression (ta_hvp.hip).
+      if (n_dir == 0 || N == 0) return;
+      hipStream_t s = h->stream;
+      const size_t P = (size_t)h->db.n_pairs, nd = (size_t)n_dir;
+      const int D = h->sf.ndim;
+      ensure_pair_jacobians(h);
+      compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // dE/dG of the resident positions (the one-hots overwrote it)
+      size_t scratch = 0, partial = 0, total = 0;
+      for (int e = 0; e < h->n_elements; ++e) {
+        const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+        scratch = std::max(scratch, ta::mlp_grad2_scratch_doubles(h->mlp[e], n_el));
+        partial = std::max(partial, ta::mlp_grad_partial_doubles(h->mlp[e], n_el));
+        total += (size_t)ta::mlp_param_count(h->mlp[e]);
+      }
+      h->train_scratch.ensure(scratch + 8);
+      h->train_partial.ensure(partial + 8);
+      h->train_grad.ensure(total + 8);
+      h->tan_dir.ensure(3 * N + 9 * F + 8);
+      h->tan_dD.ensure(4 * P + 8);
+      h->tan_dG.ensure(N * (size_t)D + 8);
+      // Dv, gv, gd [P][4]; w-dot [N][D]; F-dot [N][3], W-dot rows [N][9] of one direction
+      h->hvp_buf.ensure(12 * P + N * (size_t)D + 12 * N + 64);
+      double *Dv = h->hvp_buf.ptr, *gv = Dv + 4 * P, *gd = gv + 4 * P, *wdot = gd + 4 * P, *fdot = wdot + N * (size_t)D,
+             *wrow = fdot + 3 * N;
+      ta::launch_pair_vec(h->db, Dv, s);
+      std::vector<double> dir_R(3 * N), dir_h(9 * F), rows(9 * N);
+      double *d_dR = h->tan_dir.ptr, *d_dh = h->tan_dir.ptr + 3 * N;
+      for (size_t d = 0; d < nd; ++d) {
+        if (unit) {
+          std::fill(dir_R.begin(), dir_R.end(), 0.0);
+          dir_R[(size_t)first + d] = 1.0;
+        } else if (dR) {
+          std::copy(dR + d * 3 * N, dR + (d + 1) * 3 * N, dir_R.begin());
+        } else {
+          std::fill(dir_R.begin(), dir_R.end(), 0.0);
+        }
+        if (dh) std::copy(dh + d * 9 * F, dh + (d + 1) * 9 * F, dir_h.begin());
+        else std::fill(dir_h.begin(), dir_h.end(), 0.0);
+        HIP_CHECK(hipMemcpyAsync(d_dR, dir_R.data(), 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_dh, dir_h.data(), 9 * F * sizeof(double), hipMemcpyHostToDevice, s));
+        ta::launch_pair_tangent(h->db, d_dR, d_dh, h->tan_dD.ptr, s);
+        ta::launch_descriptor_jvp(h->db, D, h->jvp_J.ptr, h->tan_dD.ptr, h->tan_dG.ptr, s);
+        size_t off = 0;
+        for (int e = 0; e < h->n_elements; ++e) {
+          const int n_el = h->db.elem_start[e + 1] - h->db.elem_start[e];
+          ta::launch_mlp_grad2(h->mlp[e], h->activation, D, h->db.elem_atoms + h->db.elem_start[e], n_el, h->db,
+                               h->tan_dG.ptr, nullptr, h->train_scratch.ptr, h->train_partial.ptr,
+                               h->train_grad.ptr + off, s, wdot);
+          off += (size_t)ta::mlp_param_count(h->mlp[e]);
+        }
+        if (h->sf.angular) {
+          bool first_launch = true;
+          for (const ChunkPlan &cp : h->chunks) {
+            ta::launch_backward_hvp(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first_launch, true, h->db, Dv, h->tan_dD.ptr, wdot,
+                                    gv, gd, s);
+            first_launch = false;
+          }
+        } else {
+          ta::AngChunk dummy;
+          std::memset(&dummy, 0, sizeof(dummy));
+          ta::launch_backward_hvp(h->sf, dummy, 1, 1, 1, true, false, h->db, Dv, h->tan_dD.ptr, wdot, gv, gd, s);
+        }
+        ta::launch_hvp_gather(h->db, Dv, h->tan_dD.ptr, gv, gd, fdot, dW ? wrow : nullptr, s);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(dF + d * 3 * N, fdot, 3 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (dW) HIP_CHECK(hipMemcpyAsync(rows.data(), wrow, 9 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // (the direction buffers are reused)
+        if (dW) {
+          std::fill(dW + d * F * 9, dW + (d + 1) * F * 9, 0.0);
+          const std::vector<int32_t> &foa = h->hp.frame_of_atom;
+          for (size_t i = 0; i < N; ++i)
+            for (int k = 0; k < 9; ++k) dW[(d * F + (size_t)foa[i]) * 9 + k] += rows[9 * i + k];
+        }
+      }
+    });
   return guarded(h, [&]() {
     if (n_dir == 0 || N == 0) return;
     hipStream_t s = h->stream;

@@ -84,6 +84,28 @@ __device__ __forceinline__ void cutoff_u(int kind, double u, double &f, double &
   }
 }
 
+// fc(u), d fc / d u and d^2 fc / d u^2 (analytic Hessian-vector products, ta_hvp.hip)
+__device__ __forceinline__ void cutoff_u2(int kind, double u, double &f, double &dfdu, double &d2fdu2) {
+  if (kind == TA_CUTOFF_COSINE) {
+    double y = 0.0, d = 0.0, dd = 0.0;
+#pragma unroll
+    for (int k = 11; k >= 0; --k) {  // Horner with first and second derivative
+      dd = fma(dd, u, 2.0 * d);
+      d = fma(d, u, y);
+      y = fma(y, u, cos_coef(k));
+    }
+    f = y * y;
+    dfdu = 2.0 * y * d;
+    d2fdu2 = 2.0 * (d * d + y * dd);
+  } else {
+    const double x = sqrt(u);
+    const double x3 = u * x, x5 = x3 * u;
+    f = 1.0 + 5.0 * x5 * x - 6.0 * x5;
+    dfdu = 15.0 * x3 * (x - 1.0);
+    d2fdu2 = 30.0 * u - 22.5 * x;
+  }
+}
+
 // value only
 __device__ __forceinline__ double cutoff_u_value(int kind, double u) {
   if (kind == TA_CUTOFF_COSINE) {

@@ -185,8 +185,10 @@ __global__ __launch_bounds__(kThreads) void mlp_grad2_kernel(MlpDev mlp, GradLay
                                                              const int32_t *frame_of_atom,
                                                              const double *frame_coeff,
                                                              const double *row_coeff, double *scratch,
-                                                             double *partial, int stride) {
+                                                             double *partial, int stride, double *kappa_out) {
   // `row_coeff` (scalar-input networks of nn-EAM over pairs): kappa seed of a row instead of c[frame]
+  // `kappa_out` [rows][ndim] (may be null): the adjoint of the raw inputs, c dy/dG + (d^2 y / dG^2) dG: with
+  // c = 0 the Hessian-vector product of the network (ta_hvp.hip)
   extern __shared__ double lds[];
   double *bufX0 = lds, *bufX1 = bufX0 + kMlpRows * stride, *bufT0 = bufX1 + kMlpRows * stride,
          *bufT1 = bufT0 + kMlpRows * stride;
@@ -327,6 +329,18 @@ __global__ __launch_bounds__(kThreads) void mlp_grad2_kernel(MlpDev mlp, GradLay
       double *t = curX; curX = nxtX; nxtX = t;
       t = curT; curT = nxtT; nxtT = t;
     }
+    if (kappa_out) {
+      for (int idx = tid; idx < nrows * ndim; idx += kThreads) {
+        const int row = idx / ndim, k = idx - row * ndim;
+        const size_t id = (size_t)(atoms ? atoms[a0 + row] : a0 + row);
+        double v = curX[row * stride + k];
+        if (mlp.xlo) {
+          const double den = mlp.xhi[k] - mlp.xlo[k];
+          v = (den != 0.0) ? -v / den : 0.0;
+        }
+        kappa_out[id * ndim + k] = v;
+      }
+    }
   }
 }
 
@@ -438,7 +452,7 @@ size_t mlp_grad2_scratch_doubles(const MlpDev &mlp, int n_atoms) {
 // directional derivative of the descriptors [N][ndim] (device)
 void launch_mlp_grad2(const MlpDev &mlp, int activation, int ndim, const int32_t *atoms, int n_atoms,
                       const DeviceBatch &b, const double *dG, const double *frame_coeff, double *scratch,
-                      double *partial, double *grad, hipStream_t s) {
+                      double *partial, double *grad, hipStream_t s, double *kappa_out) {
   const GradLayout lay = make_layout(mlp);
   if (n_atoms == 0) {
     (void)hipMemsetAsync(grad, 0, (size_t)lay.n_params * sizeof(double), s);
@@ -448,7 +462,7 @@ void launch_mlp_grad2(const MlpDev &mlp, int activation, int ndim, const int32_t
   const size_t lds = 4 * (size_t)kMlpRows * stride * sizeof(double);
   const int blocks = std::min((n_atoms + kMlpRows - 1) / kMlpRows, kMaxBlocks);
   hipLaunchKernelGGL(mlp_grad2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation,
-                     ndim, atoms, n_atoms, b.G, dG, b.frame_of_atom, frame_coeff, nullptr, scratch, partial, stride);
+                     ndim, atoms, n_atoms, b.G, dG, b.frame_of_atom, frame_coeff, nullptr, scratch, partial, stride, kappa_out);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
 }
@@ -508,7 +522,7 @@ void launch_mlp_grad2_rows(const MlpDev &mlp, int activation, const int32_t *ato
   const size_t lds = 4 * (size_t)kMlpRows * stride * sizeof(double);
   const int blocks = std::min((n_rows + kMlpRows - 1) / kMlpRows, kMaxBlocks);
   hipLaunchKernelGGL(mlp_grad2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, s, mlp, lay, activation, 1,
-                     atoms, n_rows, x, xdot, frame_of_atom, frame_coeff, row_coeff, scratch, partial, stride);
+                     atoms, n_rows, x, xdot, frame_of_atom, frame_coeff, row_coeff, scratch, partial, stride, (double *)nullptr);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((lay.n_params + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, partial, blocks, lay.n_params, grad);
 }

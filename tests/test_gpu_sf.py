@@ -314,3 +314,53 @@ def test_angular_kernels_without_job_lists(lib, monkeypatch):
     monkeypatch.setenv("TA_NO_JOBS", "1")
     _compare(make_nn(["Ni"], 6.5, True, [16, 16]), [fcc(rep=(3, 3, 3), jitter=0.05), fcc(rep=(2, 2, 2), a=3.4, seed=4)])
     _compare(make_nn(["Mo", "Ni"], 6.0, True, [16]), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ni_default", "binary_minmax_resnet_poly", "radial_only", "multi_chunk"])
+def test_analytic_hessian_vectors_of_the_descriptor_models(lib, kind):
+    """Round 3: `ta_hessian_vectors` for the symmetry-function + MLP models (ta_hvp.hip: the first-generation
+    backward expression in dual arithmetic with w = (dE/dG, H_mlp G-dot); replaces tf.hessians,
+    nn/basic.py:411-421, and the cell derivative of the virial, nn/constraint/elastic.py:24-44) against
+    central differences of the GPU's own analytic forces and virials along random directions of positions
+    and cell, plus symmetry and the acoustic sum rule of the Hessian from the unit directions."""
+    from tensoralloy_amd import Atoms, Engine
+    from tests.helpers import fcc, make_nn
+    if kind == "ni_default":
+        nn, atoms = make_nn(["Ni"], 6.0, True, [32, 32]), fcc(rep=(2, 2, 2), seed=3, jitter=0.1)
+    elif kind == "binary_minmax_resnet_poly":
+        nn = make_nn(["Mo", "Ni"], 5.5, True, [16, 16], minmax=True, resnet=True, cutoff="polynomial", activation="tanh")
+        base = fcc(rep=(2, 2, 2), seed=5, jitter=0.1)
+        cell = np.asarray(base.get_cell(complete=True)).copy()
+        cell[1, 0] = 0.2 * cell[0, 0]
+        atoms = Atoms(symbols=["Mo" if k % 3 == 0 else "Ni" for k in range(len(base))], positions=base.positions,
+                      cell=cell, pbc=True)
+    elif kind == "radial_only":
+        nn, atoms = make_nn(["Ni"], 6.0, False, [16]), fcc(rep=(2, 2, 2), seed=4, jitter=0.1)
+    else:   # several betas: more than one angular launch
+        nn = make_nn(["Ni"], 5.0, True, [16], sf_kwargs=dict(beta=[0.005, 0.02, 0.1], gamma=[1.0, -1.0], zeta=[1.0, 2.0]))
+        atoms = fcc(rep=(2, 2, 2), seed=6, jitter=0.1)
+    n = len(atoms)
+    h = np.asarray(atoms.get_cell(complete=True), dtype=float)
+    rng = np.random.RandomState(2)
+    dR = rng.normal(size=(2, n, 3))
+    dh = rng.normal(size=(2, 1, 3, 3)) * 0.3
+    dR[1] = 0.0        # second direction: the cell alone (the elastic-constant case)
+    want, eps = 1 | 2 | 4, 1e-4
+    with Engine(nn) as eng:
+        eng.set_frames([atoms])
+        dF, dW = eng.hessian_vectors(dR=dR, dh=dh, want_virial=True)
+        H = -eng.hessian_vectors()                  # [3 n, n, 3]
+        for d in range(2):
+            fd_F, fd_W = 0.0, 0.0
+            for sgn in (1.0, -1.0):
+                a = Atoms(symbols=atoms.get_chemical_symbols(), positions=atoms.positions + sgn * eps * dR[d],
+                          cell=h + sgn * eps * dh[d, 0], pbc=True)
+                r = eng.evaluate([a], want=want)[0]
+                fd_F = fd_F + sgn * r["forces"] / (2 * eps)
+                fd_W = fd_W + sgn * r["virial"] / (2 * eps)
+            assert np.abs(dF[d] - fd_F).max() < 2e-6 * max(1.0, np.abs(fd_F).max()), (d, np.abs(dF[d] - fd_F).max())
+            assert np.abs(dW[d, 0] - fd_W).max() < 2e-6 * max(1.0, np.abs(fd_W).max()), (d, np.abs(dW[d, 0] - fd_W).max())
+    Hm = H.reshape(3 * n, 3 * n)
+    assert np.abs(Hm - Hm.T).max() < 1e-9 * max(1.0, np.abs(Hm).max())
+    assert np.abs(Hm.sum(axis=1)).max() < 1e-8          # acoustic sum rule: a rigid shift costs nothing
