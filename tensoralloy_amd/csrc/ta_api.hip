@@ -275,12 +275,16 @@ struct ta_context {
   size_t o_pos = 0, o_cells = 0, o_species = 0;  // byte offsets in the packed input
   // exact list of the current step, extracted on the device from the resident skin list (nl_filter)
   DevBuf<int32_t> ex_pair_i, ex_pair_j, ex_pair_shift, ex_pair_rev, ex_pair_start, ex_pair_stop, ex_seg_start, ex_counts,
-      ex_map, ex_blk;
+      ex_map, ex_blk, ex_slot_q;
   bool filtered = false;                       // db points at the ex_* arrays
   // a copy out of stage_in may still be in flight (set by ta_update_positions, cleared by every wait
   // for the stream on the step path): whoever rewrites stage_in waits for the stream first. (An event
   // recorded behind the copy cost a 5 us bubble between the copy and the next kernel of every MD step.)
   bool upload_pending = false;
+  // ta_step: the next compute mirrors its results into stage_out (frame_reduce_kernel); `mirror_want` = the
+  // want bits whose results the page-locked image holds right now (0: none), cleared by whoever reuses stage_out
+  bool mirror_next = false;
+  uint32_t mirror_want = 0;
   int64_t n_list_builds = 0, n_list_reuses = 0;
 
   hipEvent_t ev[2 * TA_N_KERNEL_SLOTS + 2] = {nullptr};
@@ -876,7 +880,20 @@ void compute_impl(ta_context *h, uint32_t want, bool timed, double *slot_ms) {
     used[TA_K_EAM] = true;
   }
   begin(TA_K_FRAME_REDUCE);
-  launch_frame_reduce(db, need_forces, s);
+  {
+    // MD step (ta_step / ta_step_view): the last kernel also writes the results' page-locked image
+    double *mirror = nullptr;
+    int64_t n_tail = 0;
+    h->mirror_want = 0;
+    if (h->mirror_next && !timed) {
+      const size_t N = (size_t)db.n_atoms, F = (size_t)db.n_frames;
+      h->stage_out.ensure((10 * F + 4 * N + 2) * sizeof(double));
+      mirror = reinterpret_cast<double *>(h->stage_out.ptr);
+      n_tail = (int64_t)(need_forces ? 4 * N : N);
+      h->mirror_want = want | TA_WANT_ENERGY | TA_WANT_ATOMIC;
+    }
+    launch_frame_reduce(db, need_forces, mirror, n_tail, s);
+  }
   end(TA_K_FRAME_REDUCE);
   used[TA_K_FRAME_REDUCE] = true;
   HIP_CHECK(hipGetLastError());
@@ -1004,7 +1021,7 @@ int ta_destroy(ta_handle h) {
   h->pair_start.release(); h->seg_start.release(); h->pair_i.release(); h->pair_j.release();
   h->pair_shift.release(); h->pair_rev.release();
   for (auto *b : {&h->ex_pair_i, &h->ex_pair_j, &h->ex_pair_shift, &h->ex_pair_rev, &h->ex_pair_start, &h->ex_pair_stop,
-                  &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk})
+                  &h->ex_seg_start, &h->ex_counts, &h->ex_map, &h->ex_blk, &h->ex_slot_q})
     b->release();
   h->masks.release(); h->job_word.release(); h->job_count.release();
   for (auto *b : {&h->nl_wrap, &h->nl_binid, &h->nl_bin_count, &h->nl_bin_start, &h->nl_bin_cursor,
@@ -1066,10 +1083,18 @@ void apply_filter(ta_context *h) {
   const int n_run_slots = nl_filter_blocks((int)N);
   h->ex_blk.ensure((size_t)n_run_slots + 4);
   const bool blocks = h->kind == TA_MODEL_SF_MLP;
+  // symmetry-function models: no reverse-index launch; force_gather looks the reverse pair up through the map
+  // (TA_FILTER_REV_KERNEL=1: the launch, for A/B)
+  const bool indirect = blocks && !std::getenv("TA_FILTER_REV_KERNEL");
+  if (indirect) h->ex_slot_q.ensure(P + 1);
   nl_filter((int)N, (int64_t)P, nel, h->rmax, h->db.pos, h->db.cells, h->db.frame_of_atom,
             h->pair_start.ptr, h->seg_start.ptr, h->pair_j.ptr, h->pair_shift.ptr, h->pair_rev.ptr, h->ex_map.ptr,
             h->ex_seg_start.ptr, h->ex_pair_start.ptr, h->ex_pair_stop.ptr, h->ex_pair_i.ptr, h->ex_pair_j.ptr,
-            h->ex_pair_shift.ptr, h->ex_pair_rev.ptr, h->db.cap, blocks ? h->ex_blk.ptr : nullptr, h->stream);
+            h->ex_pair_shift.ptr, h->ex_pair_rev.ptr, indirect ? h->ex_slot_q.ptr : nullptr, h->db.cap,
+            blocks ? h->ex_blk.ptr : nullptr, h->stream);
+  h->db.slot_q = indirect ? h->ex_slot_q.ptr : nullptr;
+  h->db.rev_super = indirect ? h->pair_rev.ptr : nullptr;
+  h->db.rev_map = indirect ? h->ex_map.ptr : nullptr;
   HIP_CHECK(hipGetLastError());
   h->db.pair_start = h->ex_pair_start.ptr;
   h->db.pair_stop = h->ex_pair_stop.ptr;
@@ -1106,7 +1131,9 @@ void set_frames_impl(ta_context *h, int32_t n_frames, const ta_frame *frames, ta
   h->have_batch = false;
   h->descriptors_valid = false;
   h->jvp_valid = false;
+  h->mirror_want = 0;  // (stage_out carries the builder's counts from here on)
   h->filtered = false;
+  h->db.slot_q = h->db.rev_super = h->db.rev_map = nullptr;
   h->db.pair_stop = nullptr;
   h->db.blk_groups = 0;
   h->db.n_blk_dev = nullptr;
@@ -1340,25 +1367,9 @@ int ta_update_positions(ta_handle h, const double *positions, const double *cell
     bool keep = h->have_batch && h->skin > 0.0;
     if (keep && cells) keep = std::memcmp(cells, h->ref_cells.data(), 9 * F * sizeof(double)) == 0;
     if (keep) {
-      const double lim2 = 0.25 * h->skin * h->skin;
-      const double *ref = h->ref_pos.data();
-      double worst = 0.0;
-      for (size_t i = 0; i < N; ++i) {
-        const double dx = positions[3 * i] - ref[3 * i], dy = positions[3 * i + 1] - ref[3 * i + 1],
-                     dz = positions[3 * i + 2] - ref[3 * i + 2];
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        worst = d2 > worst ? d2 : worst;  // NaN never wins the comparison; caught below
-        if (!(d2 <= lim2)) {
-          keep = false;
-          break;
-        }
-      }
-      (void)worst;
-    }
-    if (rebuilt) *rebuilt = keep ? 0 : 1;
-    if (keep) {
-      // same list: only the coordinates travel (one H2D copy out of page-locked memory); the
-      // forward kernels recompute the pair geometry from positions + shifts
+      // Optimistic order: the coordinates go up and the exact list of the step is extracted (device work)
+      // BEFORE the host has checked the displacements, which it then does while the device is busy. A list
+      // that turns out stale is rebuilt below; what was launched for it is overwritten by the rebuild.
       if (h->upload_pending) {  // the staging buffer must be free again
         HIP_CHECK(hipStreamSynchronize(h->stream));
         h->upload_pending = false;
@@ -1370,6 +1381,20 @@ int ta_update_positions(ta_handle h, const double *positions, const double *cell
       if (h->filtered) apply_filter(h);  // the exact list of the new positions, on the device
       h->descriptors_valid = false;
       h->jvp_valid = false;
+      const double lim2 = 0.25 * h->skin * h->skin;
+      const double *ref = h->ref_pos.data();
+      for (size_t i = 0; i < N; ++i) {
+        const double dx = positions[3 * i] - ref[3 * i], dy = positions[3 * i + 1] - ref[3 * i + 1],
+                     dz = positions[3 * i + 2] - ref[3 * i + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (!(d2 <= lim2)) {  // (a NaN fails the comparison too and is reported by the rebuild)
+          keep = false;
+          break;
+        }
+      }
+    }
+    if (rebuilt) *rebuilt = keep ? 0 : 1;
+    if (keep) {
       ++h->n_list_reuses;
       return;
     }
@@ -1438,7 +1463,11 @@ const double *results_to_stage(ta_context *h, bool energy, bool forces, bool vir
   need(atomic, 10 * F, N);
   need(forces, 10 * F + N, 3 * N);
   const double *stage = nullptr;
-  if (hi > lo) {
+  const bool fv = (h->mirror_want & (TA_WANT_FORCES | TA_WANT_VIRIAL)) != 0;
+  if (hi > lo && h->mirror_want && (!(forces || virial) || fv)) {
+    stage = reinterpret_cast<const double *>(h->stage_out.ptr);  // already there (frame_reduce_kernel's mirror)
+  } else if (hi > lo) {
+    h->mirror_want = 0;
     h->stage_out.ensure((hi - lo) * sizeof(double));
     stage = reinterpret_cast<const double *>(h->stage_out.ptr) - lo;
     staged_copy(reinterpret_cast<double *>(h->stage_out.ptr), h->results.ptr + lo, hi - lo, true, s);
@@ -1486,7 +1515,9 @@ int ta_step(ta_handle h, const double *positions, const double *cells, uint32_t 
             double *forces, double *virial, double *atomic, int32_t *rebuilt) {
   int rc = ta_update_positions(h, positions, cells, rebuilt);
   if (rc != TA_OK) return rc;
+  h->mirror_next = true;
   rc = ta_compute(h, want);
+  h->mirror_next = false;
   if (rc != TA_OK) return rc;
   return ta_get_results(h, energy, forces, virial, atomic, nullptr);
 }
@@ -1495,7 +1526,9 @@ int ta_step_view(ta_handle h, const double *positions, const double *cells, uint
                  const double **forces, const double **virial, const double **atomic, int32_t *rebuilt) {
   int rc = ta_update_positions(h, positions, cells, rebuilt);
   if (rc != TA_OK) return rc;
+  h->mirror_next = true;
   rc = ta_compute(h, want);
+  h->mirror_next = false;
   if (rc != TA_OK) return rc;
   return ta_view_results(h, want, energy, forces, virial, atomic);
 }

@@ -73,6 +73,10 @@ struct DeviceBatch {
   int32_t *pair_stop = nullptr;
   int32_t *seg_start = nullptr;  // [N][nel+1]
   int32_t *pair_i = nullptr, *pair_j = nullptr, *pair_shift = nullptr, *pair_rev = nullptr;
+  // MD path of the symmetry-function models: the exact list has no reverse index of its own; the reverse of
+  // slot p is rev_map[rev_super[slot_q[p]]] (slot -> skin-list pair -> its reverse there -> that pair's slot),
+  // looked up by the one kernel that needs it (force_gather) instead of a launch that writes it out
+  const int32_t *slot_q = nullptr, *rev_super = nullptr, *rev_map = nullptr;
   int32_t *blk_center = nullptr; // [n_blk+1] first centre of every v2 workgroup
   int n_blk = 0;
   // MD step (ta_nlist.hip::filter_group_kernel): > 0 = number of groups of 16 centres, each owning 16
@@ -133,6 +137,9 @@ __device__ __forceinline__ int pair_stop_of(const DeviceBatch &b, int64_t i) {
 
 // {Dx, Dy}, {Dz, r^2} of pair q, from the compact or the full record
 #ifdef __HIPCC__
+__device__ __forceinline__ int pair_rev_of(const DeviceBatch &b, int q) {
+  return b.slot_q ? b.rev_map[b.rev_super[b.slot_q[q]]] : b.pair_rev[q];
+}
 __device__ __forceinline__ const double2 *pair_geom(const DeviceBatch &b, size_t q) {
   return reinterpret_cast<const double2 *>(b.rec4 ? b.rec4 + 4 * q : b.rec + kRecDoubles * q);
 }
@@ -164,7 +171,7 @@ void launch_mlp(const SFParams &sf, const MlpDev &mlp, int activation, int eleme
 void launch_backward(const SFParams &sf, const AngChunk &ch, int nb, int ng, int nz,
                      bool first, bool radial_only, const DeviceBatch &b, hipStream_t s);
 void launch_force_gather(const SFParams &sf, const DeviceBatch &b, hipStream_t s);
-void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s);
+void launch_frame_reduce(const DeviceBatch &b, bool want_virial, double *mirror, int64_t n_tail, hipStream_t s);
 
 size_t g4_lds_bytes(int nnl_max);
 
@@ -233,7 +240,7 @@ void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double 
                const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super,
                const int32_t *pj_super, const int32_t *ps_super, const int32_t *rev_super, int32_t *map,
                int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out, int32_t *pj_out,
-               int32_t *ps_out, int32_t *rev_out, int cap, int32_t *blk_center, hipStream_t s);
+               int32_t *ps_out, int32_t *rev_out, int32_t *slot_q, int cap, int32_t *blk_center, hipStream_t s);
 void nl_fill(int n_atoms, int64_t n_pairs, int nel, double rmax, const double *pos,
              const int32_t *species, const int32_t *frame_of_atom, const NlGrid *grids, NlWork &w,
              int32_t *pair_i, int32_t *pair_j, int32_t *pair_shift, int32_t *pair_rev, hipStream_t s);

@@ -24,6 +24,8 @@
 // (no atomics, no cross-lane traffic); the descriptor sum takes half of it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <stdexcept>
 
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(16 * W) void force_gather_kernel(DeviceBatch b) {
       for (int k = 0; k < 4; ++k) {
         const int q = qb + W * k;
         ok[k] = q < q1;
-        r[k] = ok[k] ? b.pair_rev[q] : 0;
+        r[k] = ok[k] ? pair_rev_of(b, q) : 0;
       }
       double gr[4][3];
 #pragma unroll
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(16 * W) void force_gather_kernel(DeviceBatch b) {
     for (int k = 0; k < 4; ++k) {
       const int q = qb + W * k;
       ok[k] = q < q1;
-      r[k] = ok[k] ? b.pair_rev[q] : 0;
+      r[k] = ok[k] ? pair_rev_of(b, q) : 0;
     }
     double gq[4][3], gr[4][3], d[4][3];
 #pragma unroll
@@ -451,7 +453,20 @@ __global__ __launch_bounds__(16 * W) void force_gather_kernel(DeviceBatch b) {
 constexpr int kRedBlock = 1024;
 
 // `use_partials`: force_gather / the EAM force kernel ran and left the 16-atom group records
-__global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial, int use_partials) {
+// `mirror` (MD step, ta_step): a page-locked host image of the packed results [energy F | virial 9F | atomic N |
+// forces 3N]. The frame sums are written to both places, and workgroups beyond the frames copy the
+// first `n_tail` per-atom values (finished by the kernels before this one) across, so the step needs no
+// download launch behind this one.
+__global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, int want_virial, int use_partials,
+                                                                 double *mirror, long long n_tail) {
+  if ((int)blockIdx.x >= b.n_frames) {
+    const double *src = b.energy + 10 * (size_t)b.n_frames;
+    double *dst = mirror + 10 * (size_t)b.n_frames;
+    const long long stride = (long long)(gridDim.x - b.n_frames) * kRedBlock;
+    for (long long k = (long long)((int)blockIdx.x - b.n_frames) * kRedBlock + threadIdx.x; k < n_tail; k += stride)
+      dst[k] = src[k];
+    return;
+  }
   __shared__ double red[10][kRedBlock / 64];
   const int f = blockIdx.x;
   const int a0 = b.atom_start[f], a1 = b.atom_start[f + 1];
@@ -495,9 +510,11 @@ __global__ __launch_bounds__(kRedBlock) void frame_reduce_kernel(DeviceBatch b, 
     for (int w = 0; w < kRedBlock / 64; ++w) v += red[threadIdx.x][w];
     if (threadIdx.x == 0) {
       b.energy[f] = v;
+      if (mirror) mirror[f] = v;
       if (b.n_frames == 1) b.batch_energy[0] = v;
     } else if (want_virial) {
       b.virial[9 * (size_t)f + (threadIdx.x - 1)] = v;
+      if (mirror) mirror[(size_t)b.n_frames + 9 * (size_t)f + (threadIdx.x - 1)] = v;
     }
   }
 }
@@ -593,11 +610,12 @@ void launch_force_gather(const SFParams &, const DeviceBatch &b, hipStream_t s) 
   else hipLaunchKernelGGL(force_gather_kernel<16>, grid, dim3(256), 0, s, b);
 }
 
-void launch_frame_reduce(const DeviceBatch &b, bool want_virial, hipStream_t s) {
+void launch_frame_reduce(const DeviceBatch &b, bool want_virial, double *mirror, int64_t n_tail, hipStream_t s) {
   if (b.n_frames == 0) return;
   // `want_virial` = the force path ran: its kernels left the 16-atom group records behind
-  hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames), dim3(kRedBlock), 0, s, b,
-                     want_virial ? 1 : 0, want_virial ? 1 : 0);
+  const unsigned extra = (mirror && n_tail > 0) ? (unsigned)std::min<int64_t>((n_tail + kRedBlock - 1) / kRedBlock, 32) : 0u;
+  hipLaunchKernelGGL(frame_reduce_kernel, dim3((unsigned)b.n_frames + extra), dim3(kRedBlock), 0, s, b,
+                     want_virial ? 1 : 0, want_virial ? 1 : 0, mirror, (long long)(mirror ? n_tail : 0));
   if (b.n_frames > 1) hipLaunchKernelGGL(batch_energy_kernel, dim3(1), dim3(kBlock), 0, s, b);
 }
 

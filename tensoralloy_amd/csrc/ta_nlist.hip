@@ -715,7 +715,7 @@ __global__ __launch_bounds__(64 * kFilterGroup) void filter_group_kernel(
     int n_atoms, int nel, double rmax, const double *pos, const double *cells,
     const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super, const int32_t *pj_super,
     const int32_t *ps_super, int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out,
-    int32_t *pj_out, int32_t *ps_out, int32_t *map, int cap, int32_t *blk_center) {
+    int32_t *pj_out, int32_t *ps_out, int32_t *map, int32_t *slot_q, int cap, int32_t *blk_center) {
   __shared__ int cnt[kFilterGroup][kFilterMaxEl + 1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i0 = blockIdx.x * kFilterGroup;
@@ -812,6 +812,7 @@ __global__ __launch_bounds__(64 * kFilterGroup) void filter_group_kernel(
           pj_out[slot] = j;
 #pragma unroll
           for (int c = 0; c < 3; ++c) ps_out[3 * (size_t)slot + c] = S[c];
+          if (slot_q) slot_q[slot] = q;  // (no reverse-index launch: DeviceBatch::slot_q)
         }
         map[q] = slot;
       }
@@ -1018,13 +1019,14 @@ void nl_filter(int n_atoms, int64_t n_super, int nel, double rmax, const double 
                const int32_t *frame_of_atom, const int32_t *start_super, const int32_t *seg_super,
                const int32_t *pj_super, const int32_t *ps_super, const int32_t *rev_super, int32_t *map,
                int32_t *seg_exact, int32_t *pair_start, int32_t *pair_stop, int32_t *pi_out, int32_t *pj_out,
-               int32_t *ps_out, int32_t *rev_out, int cap, int32_t *blk_center, hipStream_t s) {
+               int32_t *ps_out, int32_t *rev_out, int32_t *slot_q, int cap, int32_t *blk_center, hipStream_t s) {
   if (n_atoms == 0) return;
   if (nel > kFilterMaxEl) throw std::domain_error("the MD-step list filter handles at most 8 elements");
   hipLaunchKernelGGL(filter_group_kernel, dim3(nblk(n_atoms, kFilterGroup)), dim3(64 * kFilterGroup), 0, s, n_atoms,
                      nel, rmax, pos, cells, frame_of_atom, start_super, seg_super, pj_super, ps_super, seg_exact,
-                     pair_start, pair_stop, pi_out, pj_out, ps_out, map, cap, blk_center);
-  if (n_super > 0)
+                     pair_start, pair_stop, pi_out, pj_out, ps_out, map, slot_q, cap, blk_center);
+  // `slot_q` given: the one reader of the reverse index goes through the map itself (pair_rev_of)
+  if (n_super > 0 && !slot_q)
     hipLaunchKernelGGL(filter_rev_kernel, dim3(nblk(n_super, kBlock)), dim3(kBlock), 0, s, n_super, rev_super, map,
                        rev_out);
 }

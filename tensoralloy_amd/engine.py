@@ -114,48 +114,59 @@ class Engine:
             self.info.n_pairs, self.info.n_triples, self.info.nnl_max = n_pairs.value, n_triples.value, nnl.value
         return bool(rebuilt.value)
 
+    def _view_array(self, ptr, shape):
+        """numpy array over library memory at `ptr`; the staging buffer does not move between steps, so the
+        wrapper is made once per (address, shape)."""
+        addr = C.cast(ptr, C.c_void_p).value
+        if not addr:
+            return None
+        key = (addr, shape)
+        arr = self._view_cache.get(key)
+        if arr is None:
+            if len(self._view_cache) > 16:
+                self._view_cache.clear()
+            n = int(np.prod(shape))
+            arr = np.frombuffer((C.c_double * n).from_address(addr), dtype=np.float64).reshape(shape)
+            self._view_cache[key] = arr
+        return arr
+
     def step(self, positions, want: int, cells=None, view=False) -> dict:
         """One MD step of the resident batch in one library call (`ta_step`): new coordinates in,
         evaluation, results out. Same result dict as `fetch`; the output arrays are reused from call to
         call (copy what must outlive the next step). `view=True` (`ta_step_view`): the arrays ARE the
         library's page-locked staging memory the device wrote, valid until the next call on this engine
         (no copy out of it: 128 KB per step for 4000 atoms)."""
-        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        pos = positions if (type(positions) is np.ndarray and positions.dtype == np.float64 and
+                            positions.flags.c_contiguous) else np.ascontiguousarray(positions, dtype=np.float64)
         N, F = int(self.info.n_atoms), int(self.info.n_frames)
         if pos.size != 3 * N:
             raise ValueError("positions for every atom of the resident batch are needed")
-        null = C.POINTER(C.c_double)()
+        st = self.__dict__.get("_step_state")
+        if st is None:   # ctypes objects of the call, made once
+            null = C.POINTER(C.c_double)()
+            ptrs = tuple(C.POINTER(C.c_double)() for _ in range(4))
+            rebuilt = C.c_int32(0)
+            st = self._step_state = (null, ptrs, tuple(C.byref(p) for p in ptrs), rebuilt, C.byref(rebuilt))
+            self._view_cache = {}
+        null, ptrs, refs, rebuilt, rebuilt_ref = st
         cptr = null
         if cells is not None:
             cells = np.ascontiguousarray(cells, dtype=np.float64).reshape(-1, 3, 3)
             if len(cells) != F:
                 raise ValueError("one cell per resident frame")
             cptr = _lib.as_dp(cells)
+        want = int(want)
         want_f = bool(want & (_lib.TA_WANT_FORCES | _lib.TA_WANT_VIRIAL))
-        rebuilt = C.c_int32(0)
         if view:
-            pe, pf, pv, pa = (C.POINTER(C.c_double)() for _ in range(4))
-            self._check(self._lib.ta_step_view(self._handle, _lib.as_dp(pos), cptr, int(want), C.byref(pe),
-                                               C.byref(pf), C.byref(pv), C.byref(pa), C.byref(rebuilt)))
-            cache = self.__dict__.setdefault("_view_cache", {})
-
-            def as_array(ptr, shape):
-                # the staging buffer does not move between steps: wrap it once per (address, shape)
-                if not ptr:
-                    return None
-                key = (C.cast(ptr, C.c_void_p).value, shape)
-                arr = cache.get(key)
-                if arr is None:
-                    if len(cache) > 16:
-                        cache.clear()
-                    n = int(np.prod(shape))
-                    arr = np.frombuffer((C.c_double * n).from_address(key[0]), dtype=np.float64).reshape(shape)
-                    cache[key] = arr
-                return arr
-            energy = as_array(pe, (F,))
+            rc = self._lib.ta_step_view(self._handle, pos.ctypes.data_as(_lib._dp), cptr, want, refs[0], refs[1],
+                                        refs[2], refs[3], rebuilt_ref)
+            if rc:
+                self._check(rc)
+            energy = self._view_array(ptrs[0], (F,))
             if energy is None:
                 energy = np.empty(0)
-            forces, virial, atomic = as_array(pf, (N, 3)), as_array(pv, (F, 3, 3)), as_array(pa, (N,))
+            forces, virial = self._view_array(ptrs[1], (N, 3)), self._view_array(ptrs[2], (F, 3, 3))
+            atomic = self._view_array(ptrs[3], (N,))
         else:
             buf = getattr(self, "_step_buf", None)
             if buf is None or buf[0] != (N, F):
@@ -163,9 +174,9 @@ class Engine:
                 self._step_buf = buf
             _, energy, forces, virial, atomic = buf
             self._check(self._lib.ta_step(
-                self._handle, _lib.as_dp(pos), cptr, int(want), _lib.as_dp(energy),
+                self._handle, _lib.as_dp(pos), cptr, want, _lib.as_dp(energy),
                 _lib.as_dp(forces) if want_f else null, _lib.as_dp(virial) if want_f else null,
-                _lib.as_dp(atomic) if want & _lib.TA_WANT_ATOMIC else null, C.byref(rebuilt)))
+                _lib.as_dp(atomic) if want & _lib.TA_WANT_ATOMIC else null, rebuilt_ref))
         self.batch_generation += 1
         if cells is not None:
             self._volumes = np.abs(np.linalg.det(cells))
