@@ -1383,10 +1383,14 @@ __global__ __launch_bounds__(kBlock) void eam_hvp_atom_kernel(EamParams P, Devic
   rho = wave_sum(rho);
   rhodot = wave_sum(rhodot);
   if (lane == 0) {
-    Dual F, dF;
-    if ((P.tab_embed >> sA) & 1u) spline_eval_dual(tabs[slot_embed(nel, sA)], make_dual(rho, 1.0), F, dF);
-    else zjw_embed<Dual>(el[sA], P.embed_kind[sA], make_dual(rho, 1.0), F, dF);
-    *out = dF.d * rhodot;  // F''(rho_i) rho_i-dot
+    if ((P.nn_embed >> sA) & 1u) {
+      *out = rhodot;  // an embedding NETWORK: F'' is applied by scalar_net_d2_kernel (eam_hvp)
+    } else {
+      Dual F, dF;
+      if ((P.tab_embed >> sA) & 1u) spline_eval_dual(tabs[slot_embed(nel, sA)], make_dual(rho, 1.0), F, dF);
+      else zjw_embed<Dual>(el[sA], P.embed_kind[sA], make_dual(rho, 1.0), F, dF);
+      *out = dF.d * rhodot;  // F''(rho_i) rho_i-dot
+    }
   }
 }
 
@@ -2030,10 +2034,12 @@ constexpr int kNetMaxWidth = 128;
 
 __global__ __launch_bounds__(kBlock) void scalar_net_d2_kernel(MlpDev net, int act, const int32_t *atoms,
                                                                int n_rows, const double *__restrict__ x,
-                                                               const double *__restrict__ scale, double *out) {
+                                                               const double *scale, double *out, size_t dir_stride) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_rows) return;
   const int id = atoms ? atoms[t] : t;
+  scale += blockIdx.y * dir_stride;  // grid.y = direction (Hessian-vector products); scale may be out
+  out += blockIdx.y * dir_stride;
   double v[2][kNetMaxWidth], d1[2][kNetMaxWidth], d2[2][kNetMaxWidth];
   int cur = 0;
   v[0][0] = x[id];
@@ -2275,7 +2281,7 @@ void eam_loss_gradient(EamModel *m, const DeviceBatch &b, const double *frame_co
     const int n_el = b.elem_start[e + 1] - b.elem_start[e];
     if (!net.n_layers || n_el == 0) continue;
     hipLaunchKernelGGL(scalar_net_d2_kernel, dim3((unsigned)((n_el + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, net,
-                       m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, rhodot, d2F);
+                       m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, rhodot, d2F, (size_t)0);
   }
   size_t off = 0;
   for (int sl = 0; sl < m->n_slots; ++sl) {
@@ -2512,7 +2518,12 @@ void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *fram
 // Hessian-vector products on the resident batch (the forward pass of eam_compute must have run: F'(rho)
 // in m->dF). Device pointers; `dFdot` [n_dir][N] scratch. False = this model keeps the central differences.
 bool eam_hvp_supported(const EamModel *m) {
-  if (m->p.adp || m->pair_nets || m->embed_nets) return false;
+  if (m->p.adp || m->pair_nets) return false;  // (nn pair functions: through their tables only)
+  for (int e = 0; e < m->p.nel && m->embed_nets; ++e) {  // embedding networks: F'' by the second-derivative sweep
+    if (slot_embed(m->p.nel, e) >= m->n_slots) return false;
+    const MlpDev &net = m->nets[slot_embed(m->p.nel, e)];
+    if (net.n_layers && (net.max_np > kNetMaxWidth || net.max_kp > kNetMaxWidth || net.xlo)) return false;
+  }
   for (int e = 0; e < m->p.nel; ++e)
     if (m->p.el_kind[e] != 0) return false;  // sutton90 / Be/1 / grimes: first derivatives only
   return true;
@@ -2523,6 +2534,14 @@ void eam_hvp(EamModel *m, const DeviceBatch &b, int n_dir, bool unit, int first,
   const HvpArgs a{n_dir, unit ? 1 : 0, first, dR, dh, m->eps};
   const dim3 grid((unsigned)((b.n_atoms + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)n_dir);
   hipLaunchKernelGGL(eam_hvp_atom_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, dFdot);
+  for (int e = 0; e < m->p.nel && m->embed_nets; ++e) {  // atoms with an embedding network: rho-dot -> F''(rho) rho-dot
+    const MlpDev &net = m->nets[slot_embed(m->p.nel, e)];
+    const int n_el = b.elem_start[e + 1] - b.elem_start[e];
+    if (!net.n_layers || n_el == 0) continue;
+    hipLaunchKernelGGL(scalar_net_d2_kernel, dim3((unsigned)((n_el + kBlock - 1) / kBlock), (unsigned)n_dir), dim3(kBlock),
+                       0, s, net, m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, dFdot, dFdot,
+                       (size_t)b.n_atoms);
+  }
   hipLaunchKernelGGL(eam_hvp_force_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, m->dF, dFdot, fdot,
                      wdot);
 }

@@ -329,14 +329,15 @@ def test_device_functions_reproduce_the_reference_setfl_tables(lib, tmp_path):
         assert np.abs(got - np.array(ref)[1:]).max() < 1e-12 * max(1, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kind", ["zjw04", "zjw04_binary_skin", "setfl", "nn_tables"])
+@pytest.mark.parametrize("kind", ["zjw04", "zjw04_binary_skin", "setfl", "nn_tables", "nn_all"])
 def test_analytic_hessian_vectors(lib, tmp_path, kind):
     """`ta_hessian_vectors` (dual-number tangents through the analytic EAM force kernels; replaces
     tf.hessians, nn/basic.py:411-421, and the cell derivative of the virial behind the elastic
     constants, nn/constraint/elastic.py:24-44) against central differences of the GPU's own analytic
     forces and virials along random directions of positions AND cell, and the symmetry of the Hessian
     from the unit directions. Models: Zjw04 Ni; Mo-Ni with the cross pair term, a sheared cell and a
-    Verlet skin; the Al-Cu setfl tables as splines; nn pair functions through their Hermite tables."""
+    Verlet skin; the Al-Cu setfl tables as splines; nn pair functions through their Hermite tables; the
+    reference's default all-nn Mo-Ni model (embedding networks included)."""
     from tensoralloy_amd import Atoms, Engine
     from tensoralloy_amd.eam import EamAlloyNN
     if kind == "zjw04":
@@ -352,10 +353,14 @@ def test_analytic_hessian_vectors(lib, tmp_path, kind):
         nn = EamAlloyNN.from_setfl(golden_setfl("Zhou_AlCu.alloy.eam", tmp_path))
         nn.attach_transformer(UniversalTransformer(["Al", "Cu"], rcut=5.99))
         atoms = _alloy(["Al", "Cu"], rep=(2, 2, 2), a=3.9, seed=7)
-    else:
+    elif kind == "nn_tables":
         nn = make_eam(["Ni"], 6.0, potential={"Ni": {"rho": "nn", "embed": "zjw04"}, "NiNi": {"phi": "nn"}},
                       hidden_sizes=[16, 16])
         atoms = fcc(rep=(2, 2, 2), seed=9)
+    else:   # the reference's default: every function a network (pair functions through their tables,
+            # F'' of the embedding networks by a value / first / second derivative sweep)
+        nn = make_eam(["Mo", "Ni"], 5.5, potential=None, hidden_sizes=[12, 12])
+        atoms = _alloy(["Ni", "Mo"], rep=(2, 2, 2), seed=4)
     n = len(atoms)
     h = np.asarray(atoms.get_cell(complete=True), dtype=float)
     rng = np.random.RandomState(2)
@@ -388,8 +393,9 @@ def test_analytic_hessian_vectors(lib, tmp_path, kind):
 
 def test_hessian_vectors_refuse_models_without_the_analytic_path(lib):
     from tensoralloy_amd import Engine
-    for nn in (make_eam(["Ni"], 6.0, adp=True), make_eam(["Ni"], 6.0, potential=None)):   # ADP; nn embedding
+    for nn, atoms in ((make_eam(["Ni"], 6.0, adp=True), fcc(rep=(1, 1, 1))),                         # ADP
+                      (make_eam(["Ag"], 7.0, potential="sutton90"), fcc("Ag", a=4.09, rep=(1, 1, 1)))):  # sutton90
         with Engine(nn) as eng:
-            eng.set_frames([fcc(rep=(1, 1, 1))])
+            eng.set_frames([atoms])
             with pytest.raises(ValueError, match="analytic second derivatives"):
                 eng.hessian_vectors()
