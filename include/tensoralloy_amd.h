@@ -361,8 +361,8 @@ int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *d
  * the virials, dW [n_dir][n_frames][9] (may be NULL). Replaces `tf.hessians(energy, positions)`
  * (nn/basic.py:411-421: Hessian column d = -dF[d]) and the cell derivative of the virial behind the
  * elastic constants (nn/constraint/elastic.py:24-44: dh = unit matrices, dR = NULL). Forward-mode
- * (dual-number) tangents through the analytic force kernels: exact, no step size. Available for plain
- * EAM models whose functions are of the Zjw04 family, tabulated or networks (nn pair functions through
+ * (dual-number) tangents through the analytic force kernels: exact, no step size. Available for EAM and
+ * ADP models whose functions are of the Zjw04 / MishinH families, tabulated or networks (nn pair functions through
  * their tables, embedding networks by a second-derivative sweep), and (round 3) for the
  * symmetry-function + MLP models with integer zetas (per direction: the descriptors' tangent through the
  * pair Jacobians, the MLP's Hessian-vector product, then the backward expression in dual arithmetic);

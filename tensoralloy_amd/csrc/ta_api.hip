@@ -68,8 +68,9 @@ void eam_set_list_cutoff(EamModel *, double rc /* 0: the list is exact, no test 
 bool eam_is_plain(const EamModel *);
 void eam_set_nn_tables(EamModel *, bool on);
 bool eam_hvp_supported(const EamModel *);
+size_t eam_hvp_extra_doubles(const EamModel *, const DeviceBatch &b, int n_dir);
 void eam_hvp(EamModel *, const DeviceBatch &b, int n_dir, bool unit, int first, const double *dR, const double *dh,
-             double *dFdot, double *fdot, double *wdot, hipStream_t s);
+             double *dFdot, double *fdot, double *wdot, double *extra, hipStream_t s);
 bool eam_nn_tables_on(const EamModel *);
 void eam_mark_trained(EamModel *);
 int64_t eam_param_count(const EamModel *);
@@ -2196,8 +2197,11 @@ int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *
     hipStream_t s = h->stream;
     compute_impl(h, TA_WANT_ENERGY, false, nullptr);  // F'(rho_i) of the resident positions
     const size_t nd = (size_t)n_dir;
-    h->hvp_buf.ensure(nd * N * (1 + 3 + (dW ? 9 : 0)) + (dR ? nd * N * 3 : 0) + (dh ? nd * F * 9 : 0) + 8);
+    const size_t extra_n = ta::eam_hvp_extra_doubles(h->eam, h->db, n_dir);
+    h->hvp_buf.ensure(nd * N * (1 + 3 + (dW ? 9 : 0)) + (dR ? nd * N * 3 : 0) + (dh ? nd * F * 9 : 0) + extra_n + 8);
     double *p = h->hvp_buf.ptr;
+    double *extra = extra_n ? p : nullptr;
+    p += extra_n;
     double *dFdot = p; p += nd * N;
     double *fdot = p; p += nd * N * 3;
     double *wdot = nullptr;
@@ -2211,7 +2215,7 @@ int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *
       d_dh = p; p += nd * F * 9;
       HIP_CHECK(hipMemcpyAsync(d_dh, dh, nd * F * 9 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    ta::eam_hvp(h->eam, h->db, n_dir, unit, first, d_dR, d_dh, dFdot, fdot, wdot, s);
+    ta::eam_hvp(h->eam, h->db, n_dir, unit, first, d_dR, d_dh, dFdot, fdot, wdot, extra, s);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(dF, fdot, nd * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     std::vector<double> wat;

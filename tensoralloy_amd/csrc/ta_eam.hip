@@ -385,6 +385,26 @@ __device__ __forceinline__ void mishin_polar(double r, T p1, T p2, T p3, T rc, T
   df = -p1 * p2 * e * psi + left * dpsi;
 }
 
+// the same with the distance of type T as well (Hessian-vector products: r is dual, the constants plain)
+template <typename T>
+__device__ __forceinline__ void mishin_polar_r(T r, double p1, double p2, double p3, double rc, double h, T &f,
+                                               T &df) {
+  const T z = (r - rc) / h;
+  if (t_val(z) >= 0.0) {
+    f = T{};
+    df = T{};
+    return;
+  }
+  const T zz = -z, z2 = zz * zz, z4 = z2 * z2;
+  const T den = 1.0 / (1.0 + z4);
+  const T psi = z4 * den;
+  const T dpsi = -4.0 * z2 * zz * den * den / h;
+  const T e = t_exp(-(p2 * r));
+  const T left = p1 * e + p3;
+  f = left * psi;
+  df = -(p1 * p2) * e * psi + left * dpsi;
+}
+
 // moments per (atom, neighbour species): mu[3], Lambda[6] = lambda - (tr lambda / 3) I
 // in the order xx yy zz yz xz xy
 // W lanes per atom (16: one DPP row, four atoms per wavefront; 64: one wavefront per atom): an atom
@@ -1472,6 +1492,203 @@ __global__ __launch_bounds__(kBlock) void eam_hvp_force_kernel(EamParams P, Devi
   }
 }
 
+// ---- the same for ADP models ----------------------------------------------------------------------
+// adp_force_kernel's expression in dual arithmetic: besides D, r, rho', phi', F' the dipole / quadrupole
+// functions u, w (u', w' of a dual r carry u'' rdot, w'' rdot: mishin_polar_r, or the spline's second
+// derivative) and the moments of BOTH atoms of a pair are dual, mu = (mu, mu-dot), Lambda = (Lambda,
+// Lambda-dot) with mu-dot = sum (u' rdot D + u T), lambda-dot = sum (w' rdot D (x) D + w (T (x) D + D (x) T))
+// from the first pass (trace removed as in `mom`).
+__global__ __launch_bounds__(kBlock) void adp_hvp_atom_kernel(EamParams P, DeviceBatch b, HvpArgs a,
+                                                              const TabDev *__restrict__ tabs, double *dFdot,
+                                                              double *momdot) {
+  __shared__ Dual el[kMaxEamElements][20];
+  const int nel = P.nel;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, dir = blockIdx.y;
+  if (i >= b.n_atoms) return;
+  const int fr = b.frame_of_atom[i];
+  double *out = dFdot + (size_t)dir * b.n_atoms + i;
+  double *mout = momdot + (((size_t)dir * b.n_atoms + i) * nel) * 9;
+  if (a.unit && b.frame_of_atom[(a.first + dir) / 3] != fr) {  // another structure of the batch: no coupling
+    if (lane == 0) *out = 0.0;
+    for (int k = lane; k < nel * 9; k += 64) mout[k] = 0.0;
+    return;
+  }
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  const double *h = b.cells + 9 * (size_t)fr;
+  const double *ri = b.pos + 3 * (size_t)i;
+  double rho = 0.0, rhodot = 0.0;
+  for (int sb = 0; sb < nel; ++sb) {
+    const bool rho_tab = (P.tab_rho >> sb) & 1u;
+    const int pt = pair_type(sA, sb, nel);
+    const double *pp = P.pair[pt];
+    const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
+    double md[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+      const int j = b.pair_j[q];
+      const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
+      const double *rj = b.pos + 3 * (size_t)j;
+      double D[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) D[c] = (rj[c] - ri[c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+      const double r2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2] + a.eps;
+      if (P.list_rc2 > 0.0 && !(r2 < P.list_rc2)) continue;
+      const double r = sqrt(r2);
+      double T[3];
+      hvp_pair_tangent(a, b, dir, i, j, fr, S, T);
+      const double rd = (D[0] * T[0] + D[1] * T[1] + D[2] * T[2]) / r;
+      double f, df;
+      if (rho_tab) spline_eval(tabs[slot_rho(sb)], r, f, df);
+      else zjw_rho<double>(P.el[sb], r, f, df);
+      rho += f;
+      rhodot = fma(df, rd, rhodot);
+      double u, du, w, dw;
+      if (u_tab) spline_eval(tabs[slot_pair(nel, 2, pt)], r, u, du);
+      else mishin_polar<double>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+      if (w_tab) spline_eval(tabs[slot_pair(nel, 3, pt)], r, w, dw);
+      else mishin_polar<double>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+      const double ur = du * rd, wr = dw * rd;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) md[c] += ur * D[c] + u * T[c];
+      md[3] += wr * D[0] * D[0] + 2.0 * w * T[0] * D[0];
+      md[4] += wr * D[1] * D[1] + 2.0 * w * T[1] * D[1];
+      md[5] += wr * D[2] * D[2] + 2.0 * w * T[2] * D[2];
+      md[6] += wr * D[1] * D[2] + w * (T[1] * D[2] + D[1] * T[2]);
+      md[7] += wr * D[0] * D[2] + w * (T[0] * D[2] + D[0] * T[2]);
+      md[8] += wr * D[0] * D[1] + w * (T[0] * D[1] + D[0] * T[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) md[k] = wave_sum(md[k]);
+    if (lane == 0) {
+      const double nu = md[3] + md[4] + md[5];
+      for (int k = 0; k < 9; ++k) mout[sb * 9 + k] = (k >= 3 && k < 6) ? md[k] - nu / 3.0 : md[k];
+    }
+  }
+  rho = wave_sum(rho);
+  rhodot = wave_sum(rhodot);
+  if (lane == 0) {
+    if ((P.nn_embed >> sA) & 1u) {
+      *out = rhodot;
+    } else {
+      Dual F, dF;
+      if ((P.tab_embed >> sA) & 1u) spline_eval_dual(tabs[slot_embed(nel, sA)], make_dual(rho, 1.0), F, dF);
+      else zjw_embed<Dual>(el[sA], P.embed_kind[sA], make_dual(rho, 1.0), F, dF);
+      *out = dF.d * rhodot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void adp_hvp_force_kernel(EamParams P, DeviceBatch b, HvpArgs a,
+                                                               const TabDev *__restrict__ tabs,
+                                                               const double *__restrict__ dF,
+                                                               const double *__restrict__ dFdot,
+                                                               const double *__restrict__ mom,
+                                                               const double *__restrict__ momdot, double *fdot,
+                                                               double *wdot) {
+  __shared__ Dual el[kMaxEamElements][20];
+  __shared__ Dual phx[kMaxPairTypes][7];
+  const int nel = P.nel, npt = nel * (nel + 1) / 2;
+  for (int t = threadIdx.x; t < nel * 20; t += kBlock) el[t / 20][t % 20] = make_dual(P.el[t / 20][t % 20]);
+  for (int t = threadIdx.x; t < npt * 7; t += kBlock) phx[t / 7][t % 7] = make_dual(P.phi[t / 7][t % 7]);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, dir = blockIdx.y;
+  if (i >= b.n_atoms) return;
+  const int fr = b.frame_of_atom[i];
+  double *fo = fdot + ((size_t)dir * b.n_atoms + i) * 3;
+  double *wo = wdot ? wdot + ((size_t)dir * b.n_atoms + i) * 9 : nullptr;
+  double fd[3] = {0, 0, 0}, wd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!(a.unit && b.frame_of_atom[(a.first + dir) / 3] != fr)) {
+    const int sA = b.species[i];
+    const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+    const double *h = b.cells + 9 * (size_t)fr;
+    const double *ri = b.pos + 3 * (size_t)i;
+    const Dual dFi = make_dual(dF[i], dFdot[(size_t)dir * b.n_atoms + i]);
+    const bool rhoA_tab = (P.tab_rho >> sA) & 1u;
+    auto moments = [&](int64_t atom, int sp, Dual (&m)[9]) {
+      const double *v = mom + ((size_t)atom * nel + sp) * 9;
+      const double *d = momdot + (((size_t)dir * b.n_atoms + atom) * nel + sp) * 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) m[k] = make_dual(v[k], d[k]);
+    };
+    for (int sb = 0; sb < nel; ++sb) {
+      const int pt = pair_type(sA, sb, nel);
+      const double *pp = P.pair[pt];
+      const bool rhoB_tab = (P.tab_rho >> sb) & 1u, phi_tab = (P.tab_phi >> pt) & 1u;
+      const bool u_tab = (P.tab_u >> pt) & 1u, w_tab = (P.tab_w >> pt) & 1u;
+      Dual mi[9];
+      moments(i, sb, mi);
+      for (int q = seg[sb] + lane; q < seg[sb + 1]; q += 64) {
+        const int j = b.pair_j[q];
+        const int S[3] = {b.pair_shift[3 * (size_t)q], b.pair_shift[3 * (size_t)q + 1], b.pair_shift[3 * (size_t)q + 2]};
+        const double *rj = b.pos + 3 * (size_t)j;
+        double Dv[3], T[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Dv[c] = (rj[c] - ri[c]) + (S[0] * h[c] + S[1] * h[3 + c] + S[2] * h[6 + c]);
+        const double r2v = Dv[0] * Dv[0] + Dv[1] * Dv[1] + Dv[2] * Dv[2] + a.eps;
+        if (P.list_rc2 > 0.0 && !(r2v < P.list_rc2)) continue;
+        hvp_pair_tangent(a, b, dir, i, j, fr, S, T);
+        const Dual D[3] = {make_dual(Dv[0], T[0]), make_dual(Dv[1], T[1]), make_dual(Dv[2], T[2])};
+        const Dual r = t_sqrt(make_dual(r2v, 2.0 * (Dv[0] * T[0] + Dv[1] * T[1] + Dv[2] * T[2])));
+        const Dual dFj = make_dual(dF[j], dFdot[(size_t)dir * b.n_atoms + j]);
+        Dual mj[9];
+        moments(j, sA, mj);
+        Dual fn, drhoB, drhoA, dphi, u, du, w, dw;
+        if (rhoB_tab) spline_eval_dual(tabs[slot_rho(sb)], r, fn, drhoB);
+        else zjw_rho<Dual, Dual>(el[sb], r, fn, drhoB);
+        if (sb == sA) drhoA = drhoB;
+        else if (rhoA_tab) spline_eval_dual(tabs[slot_rho(sA)], r, fn, drhoA);
+        else zjw_rho<Dual, Dual>(el[sA], r, fn, drhoA);
+        if (phi_tab) spline_eval_dual(tabs[slot_pair(nel, 1, pt)], r, fn, dphi);
+        else zjw_phi<Dual, Dual>(P, el, phx, sA, sb, r, fn, dphi);
+        if (u_tab) spline_eval_dual(tabs[slot_pair(nel, 2, pt)], r, u, du);
+        else mishin_polar_r<Dual>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+        if (w_tab) spline_eval_dual(tabs[slot_pair(nel, 3, pt)], r, w, dw);
+        else mishin_polar_r<Dual>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+        const Dual inv_r = 1.0 / r;
+        auto lam = [&](const Dual (&m)[9], Dual (&l)[3]) {
+          l[0] = m[3] * D[0] + m[8] * D[1] + m[7] * D[2];
+          l[1] = m[8] * D[0] + m[4] * D[1] + m[6] * D[2];
+          l[2] = m[7] * D[0] + m[6] * D[1] + m[5] * D[2];
+        };
+        Dual li[3], lj[3];
+        lam(mi, li);
+        lam(mj, lj);
+        const Dual muD = mi[0] * D[0] + mi[1] * D[1] + mi[2] * D[2];
+        const Dual DLD = D[0] * li[0] + D[1] * li[1] + D[2] * li[2];
+        const Dual ci = (dFi * drhoB + 0.5 * dphi) * inv_r + (muD * du + DLD * dw) * inv_r;
+        const Dual muDj = mj[0] * D[0] + mj[1] * D[1] + mj[2] * D[2];
+        const Dual DLDj = D[0] * lj[0] + D[1] * lj[1] + D[2] * lj[2];
+        const Dual cj = (dFj * drhoA + 0.5 * dphi) * inv_r + (DLDj * dw - muDj * du) * inv_r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const Dual g = ci * D[c] + u * mi[c] + 2.0 * (w * li[c]);      // own side, dE/dD of (i -> j)
+          const Dual gr = u * mj[c] - cj * D[c] - 2.0 * (w * lj[c]);     // the reverse pair's, centre j, -D
+          fd[c] += (g - gr).d;
+          if (wo) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wd[3 * c + e] += (g * D[e]).d;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) fd[k] = wave_sum(fd[k]);
+  if (wo) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd[k] = wave_sum(wd[k]);
+  }
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) fo[k] = fd[k];
+    if (wo)
+      for (int k = 0; k < 9; ++k) wo[k] = wd[k];
+  }
+}
+
 constexpr int kNetThreads = 256;
 // Knots of an nn function's table over [0, rcut]: dx = rcut / 32768 (2e-4 A at rcut = 6.5). Cubic
 // Hermite error: value dx^4 / 384 |f''''|, derivative about dx^3 / 72 |f''''| (1e-17 / 1e-13 per unit of
@@ -2518,7 +2735,7 @@ void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *fram
 // Hessian-vector products on the resident batch (the forward pass of eam_compute must have run: F'(rho)
 // in m->dF). Device pointers; `dFdot` [n_dir][N] scratch. False = this model keeps the central differences.
 bool eam_hvp_supported(const EamModel *m) {
-  if (m->p.adp || m->pair_nets) return false;  // (nn pair functions: through their tables only)
+  if (m->pair_nets) return false;  // (nn pair functions: through their tables only)
   for (int e = 0; e < m->p.nel && m->embed_nets; ++e) {  // embedding networks: F'' by the second-derivative sweep
     if (slot_embed(m->p.nel, e) >= m->n_slots) return false;
     const MlpDev &net = m->nets[slot_embed(m->p.nel, e)];
@@ -2528,12 +2745,17 @@ bool eam_hvp_supported(const EamModel *m) {
     if (m->p.el_kind[e] != 0) return false;  // sutton90 / Be/1 / grimes: first derivatives only
   return true;
 }
+// doubles of work space eam_hvp needs besides dFdot / fdot / wdot (ADP: the moments' tangents)
+size_t eam_hvp_extra_doubles(const EamModel *m, const DeviceBatch &b, int n_dir) {
+  return m->p.adp ? (size_t)n_dir * (size_t)b.n_atoms * m->p.nel * 9 : 0;
+}
 void eam_hvp(EamModel *m, const DeviceBatch &b, int n_dir, bool unit, int first, const double *dR, const double *dh,
-             double *dFdot, double *fdot, double *wdot, hipStream_t s) {
+             double *dFdot, double *fdot, double *wdot, double *extra, hipStream_t s) {
   if (b.n_atoms == 0 || n_dir == 0) return;
   const HvpArgs a{n_dir, unit ? 1 : 0, first, dR, dh, m->eps};
   const dim3 grid((unsigned)((b.n_atoms + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)n_dir);
-  hipLaunchKernelGGL(eam_hvp_atom_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, dFdot);
+  if (m->p.adp) hipLaunchKernelGGL(adp_hvp_atom_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, dFdot, extra);
+  else hipLaunchKernelGGL(eam_hvp_atom_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, dFdot);
   for (int e = 0; e < m->p.nel && m->embed_nets; ++e) {  // atoms with an embedding network: rho-dot -> F''(rho) rho-dot
     const MlpDev &net = m->nets[slot_embed(m->p.nel, e)];
     const int n_el = b.elem_start[e + 1] - b.elem_start[e];
@@ -2542,8 +2764,12 @@ void eam_hvp(EamModel *m, const DeviceBatch &b, int n_dir, bool unit, int first,
                        0, s, net, m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, dFdot, dFdot,
                        (size_t)b.n_atoms);
   }
-  hipLaunchKernelGGL(eam_hvp_force_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, m->dF, dFdot, fdot,
-                     wdot);
+  if (m->p.adp)
+    hipLaunchKernelGGL(adp_hvp_force_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, m->dF, dFdot, m->mom,
+                       extra, fdot, wdot);
+  else
+    hipLaunchKernelGGL(eam_hvp_force_kernel, grid, dim3(kBlock), 0, s, m->p, b, a, m->tabs_dev, m->dF, dFdot, fdot,
+                       wdot);
 }
 
 void eam_compute(EamModel *m, const DeviceBatch &b, uint32_t want, hipStream_t s, hipEvent_t *) {

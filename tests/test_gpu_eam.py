@@ -329,7 +329,7 @@ def test_device_functions_reproduce_the_reference_setfl_tables(lib, tmp_path):
         assert np.abs(got - np.array(ref)[1:]).max() < 1e-12 * max(1, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kind", ["zjw04", "zjw04_binary_skin", "setfl", "nn_tables", "nn_all"])
+@pytest.mark.parametrize("kind", ["zjw04", "zjw04_binary_skin", "setfl", "nn_tables", "nn_all", "adp", "adp_nn"])
 def test_analytic_hessian_vectors(lib, tmp_path, kind):
     """`ta_hessian_vectors` (dual-number tangents through the analytic EAM force kernels; replaces
     tf.hessians, nn/basic.py:411-421, and the cell derivative of the virial behind the elastic
@@ -337,7 +337,8 @@ def test_analytic_hessian_vectors(lib, tmp_path, kind):
     forces and virials along random directions of positions AND cell, and the symmetry of the Hessian
     from the unit directions. Models: Zjw04 Ni; Mo-Ni with the cross pair term, a sheared cell and a
     Verlet skin; the Al-Cu setfl tables as splines; nn pair functions through their Hermite tables; the
-    reference's default all-nn Mo-Ni model (embedding networks included)."""
+    reference's default all-nn Mo-Ni model (embedding networks included); ADP with the MishinH functions and
+    with networks for everything."""
     from tensoralloy_amd import Atoms, Engine
     from tensoralloy_amd.eam import EamAlloyNN
     if kind == "zjw04":
@@ -357,10 +358,20 @@ def test_analytic_hessian_vectors(lib, tmp_path, kind):
         nn = make_eam(["Ni"], 6.0, potential={"Ni": {"rho": "nn", "embed": "zjw04"}, "NiNi": {"phi": "nn"}},
                       hidden_sizes=[16, 16])
         atoms = fcc(rep=(2, 2, 2), seed=9)
-    else:   # the reference's default: every function a network (pair functions through their tables,
-            # F'' of the embedding networks by a value / first / second derivative sweep)
+    elif kind == "nn_all":   # the reference's default: every function a network (pair functions through their
+        # tables, F'' of the embedding networks by a value / first / second derivative sweep)
         nn = make_eam(["Mo", "Ni"], 5.5, potential=None, hidden_sizes=[12, 12])
         atoms = _alloy(["Ni", "Mo"], rep=(2, 2, 2), seed=4)
+    elif kind == "adp":      # Zjw04 + MishinH dipole / quadrupole, two elements, sheared cell
+        nn = make_eam(["Mo", "Ni"], 6.0, adp=True)
+        atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2), seed=6)
+        cell = np.asarray(atoms.get_cell(complete=True)).copy()
+        cell[2, 0] = 0.15 * cell[0, 0]
+        atoms = Atoms(symbols=atoms.get_chemical_symbols(), positions=atoms.positions, cell=cell, pbc=True)
+    else:                    # nn-ADP, the reference's default ADP model. (Networks do not vanish at the cutoff:
+        # rc = 5.8 A sits between the 5.57 and 6.10 A shells, so that no pair crosses it in the differences)
+        nn = make_eam(["Ni"], 5.8, adp=True, potential=None, hidden_sizes=[8, 8])
+        atoms = fcc(rep=(2, 2, 2), seed=8)
     n = len(atoms)
     h = np.asarray(atoms.get_cell(complete=True), dtype=float)
     rng = np.random.RandomState(2)
@@ -393,8 +404,7 @@ def test_analytic_hessian_vectors(lib, tmp_path, kind):
 
 def test_hessian_vectors_refuse_models_without_the_analytic_path(lib):
     from tensoralloy_amd import Engine
-    for nn, atoms in ((make_eam(["Ni"], 6.0, adp=True), fcc(rep=(1, 1, 1))),                         # ADP
-                      (make_eam(["Ag"], 7.0, potential="sutton90"), fcc("Ag", a=4.09, rep=(1, 1, 1)))):  # sutton90
+    for nn, atoms in ((make_eam(["Ag"], 7.0, potential="sutton90"), fcc("Ag", a=4.09, rep=(1, 1, 1))),):  # sutton90
         with Engine(nn) as eng:
             eng.set_frames([atoms])
             with pytest.raises(ValueError, match="analytic second derivatives"):
