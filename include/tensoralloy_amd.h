@@ -344,9 +344,12 @@ int ta_loss_gradient(ta_handle h, const double *frame_coeff, const double *dR, c
  *   ta_get_constants      current values
  *   ta_update_constants   new values (finite); synchronises the stream first
  *   ta_constant_gradient  d/dconstants of  sum_f frame_coeff[f] E_f + D_(dR, dh) E  on the resident
- *                         batch, arguments as ta_loss_gradient. EAM / ADP models whose functions
- *                         are all analytic (TA_ERR_INVALID otherwise); forward-mode (dual
- *                         numbers), one pass over the pairs per constant in a single launch. */
+ *                         batch, arguments as ta_loss_gradient. Forward-mode (dual numbers), one
+ *                         pass over the pairs per constant in a single launch. Models that mix
+ *                         networks or tables with analytic functions (round 3): the functions
+ *                         without constants enter as plain values (exact forward pass), an
+ *                         embedding network through F', F''; callers take the weights' half of
+ *                         the gradient from ta_loss_gradient. */
 int ta_constant_count(ta_handle h, int64_t *n_constants);
 int ta_get_constants(ta_handle h, double *constants, int64_t n_constants);
 int ta_update_constants(ta_handle h, const double *constants, int64_t n_constants);

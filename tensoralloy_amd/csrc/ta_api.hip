@@ -2027,7 +2027,13 @@ int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *d
     const int64_t total = ta::eam_constant_count(h->eam);
     if (n_grad != total)
       throw std::invalid_argument("ta_constant_gradient: expected room for " + std::to_string(total) + " values");
-    // positions, cells and the list's cutoff test as the inference kernels see them
+    // positions, cells and the list's cutoff test as the inference kernels see them; models with nn functions
+    // beside the analytic ones: the networks evaluated exactly (per-pair columns, F'), as for their own gradient
+    if (ta::eam_param_count(h->eam) > 0) {
+      if (ta::eam_nn_tables_on(h->eam)) HIP_CHECK(hipStreamSynchronize(h->stream));
+      ta::eam_mark_trained(h->eam);
+      ta::eam_ensure(h->eam, h->db);
+    }
     compute_impl(h, TA_WANT_ENERGY, false, nullptr);
     hipStream_t s = h->stream;
     const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;

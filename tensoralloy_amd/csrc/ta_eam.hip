@@ -2255,7 +2255,7 @@ __global__ __launch_bounds__(kBlock) void scalar_net_d2_kernel(MlpDev net, int a
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_rows) return;
   const int id = atoms ? atoms[t] : t;
-  scale += blockIdx.y * dir_stride;  // grid.y = direction (Hessian-vector products); scale may be out
+  if (scale) scale += blockIdx.y * dir_stride;  // grid.y = direction (Hessian-vector products); scale may be out
   out += blockIdx.y * dir_stride;
   double v[2][kNetMaxWidth], d1[2][kNetMaxWidth], d2[2][kNetMaxWidth];
   int cur = 0;
@@ -2287,7 +2287,7 @@ __global__ __launch_bounds__(kBlock) void scalar_net_d2_kernel(MlpDev net, int a
     }
     cur = nxt;
   }
-  out[id] = d2[cur][0] * scale[id];
+  out[id] = d2[cur][0] * (scale ? scale[id] : 1.0);
 }
 
 // one wavefront per atom: rdot of its pairs, rhodot_i, and F''(rho_i) rhodot_i when the embedding
@@ -2546,7 +2546,13 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
                                                                 const double *__restrict__ frame_coeff,
                                                                 const double *__restrict__ dR,
                                                                 const double *__restrict__ dh, double eps,
-                                                                double *partial) {
+                                                                const TabDev *__restrict__ tabs,
+                                                                const double *__restrict__ pf, size_t ps,
+                                                                const double *__restrict__ dFv,
+                                                                const double *__restrict__ d2Fv, double *partial) {
+  // Mixed models (round 3): a function that is a network or a table has no constants; it enters as plain
+  // numbers, value and derivative from the exact forward pass (`pf` columns) or the spline, and an embedding
+  // network through F'(rho_i), F''(rho_i) per atom (dFv, d2Fv): F' of the dual density is F' + eps F'' rho.d.
   __shared__ Dual el[kMaxEamElements][20];
   __shared__ Dual phx[kMaxPairTypes][7];
   __shared__ Dual prs[kMaxPairTypes][8];
@@ -2600,16 +2606,34 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
           rdot = (dx * tx + dy * ty + dz * tz) / r;
         }
         Dual f, df;
-        el_rho<OTHER, Dual>(P, el, sb, r, f, df);  // density function of the NEIGHBOUR's element
+        const int pt = pair_type(sA, sb, nel);
+        auto plain = [&](bool nn, bool tab, int col, int slot, Dual &fv, Dual &dfv) {  // a function without constants
+          double a0, a1;
+          if (nn) {
+            a0 = pf[(size_t)col * ps + q];
+            a1 = pf[(size_t)(col + 1) * ps + q];
+          } else {
+            spline_eval(tabs[slot], r, a0, a1);
+          }
+          (void)tab;
+          fv = make_dual(a0);
+          dfv = make_dual(a1);
+        };
+        // density function of the NEIGHBOUR's element
+        if (((P.nn_rho | P.tab_rho) >> sb) & 1u) plain((P.nn_rho >> sb) & 1u, true, PF_RHO, slot_rho(sb), f, df);
+        else el_rho<OTHER, Dual>(P, el, sb, r, f, df);
         rho += f;
         rhodot += df * rdot;
-        pair_phi<OTHER, Dual>(P, el, phx, sA, sb, r, f, df);
+        if (((P.nn_phi | P.tab_phi) >> pt) & 1u) plain((P.nn_phi >> pt) & 1u, true, PF_PHI, slot_pair(nel, 1, pt), f, df);
+        else pair_phi<OTHER, Dual>(P, el, phx, sA, sb, r, f, df);
         phis += f;
         phidot += df * rdot;
         if (P.adp) {
           Dual u, du, w, dw;
-          mishin_polar<Dual>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
-          mishin_polar<Dual>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
+          if (((P.nn_u | P.tab_u) >> pt) & 1u) plain((P.nn_u >> pt) & 1u, true, PF_U, slot_pair(nel, 2, pt), u, du);
+          else mishin_polar<Dual>(r, pp[0], pp[1], pp[2], pp[7], pp[6], u, du);
+          if (((P.nn_w | P.tab_w) >> pt) & 1u) plain((P.nn_w >> pt) & 1u, true, PF_W, slot_pair(nel, 3, pt), w, dw);
+          else mishin_polar<Dual>(r, pp[3], pp[4], pp[5], pp[7], pp[6], w, dw);
           const double D[3] = {dx, dy, dz}, Td[3] = {tx, ty, tz};
           const Dual ud = du * rdot, wd = dw * rdot;
 #pragma unroll
@@ -2648,7 +2672,14 @@ __global__ __launch_bounds__(kBlock) void eam_const_grad_kernel(EamParams P, Dev
     phidot = make_dual(wave_sum(phidot.v), wave_sum(phidot.d));
     if (lane == 0) {
       Dual F, dFd;
-      el_embed<OTHER, Dual>(P, el, sA, rho, F, dFd);
+      if ((P.nn_embed >> sA) & 1u) {         // (only the dual parts matter below)
+        F = make_dual(0.0, dFv[i] * rho.d);
+        dFd = make_dual(dFv[i], d2Fv[i] * rho.d);
+      } else if ((P.tab_embed >> sA) & 1u) {
+        spline_eval_dual(tabs[slot_embed(nel, sA)], rho, F, dFd);
+      } else {
+        el_embed<OTHER, Dual>(P, el, sA, rho, F, dFd);
+      }
       const Dual L = cf * (F + 0.5 * phis) + dFd * rhodot + 0.5 * phidot + eadp;
       contrib = L.d;
     }
@@ -2709,11 +2740,13 @@ void eam_update_constants(EamModel *m, const double *flat, int64_t n) {
 void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *frame_coeff, const double *dR,
                            const double *dh, double *grad, hipStream_t s) {
   const EamParams &P = m->p;
-  if (m->pair_nets || m->embed_nets || P.nn_rho || P.nn_embed || P.nn_phi || P.nn_u || P.nn_w || P.tab_rho ||
-      P.tab_embed || P.tab_phi || P.tab_u || P.tab_w)
-    throw std::invalid_argument(
-        "ta_constant_gradient: for EAM / ADP models whose functions are all analytic (no nn or tabulated "
-        "function)");
+  // Models that mix networks / tables with analytic functions (round 3): the caller has run the exact
+  // forward pass (per-pair columns, F'); F'' of the embedding networks is made here.
+  const bool has_nets = m->pair_nets || m->embed_nets;
+  for (int sl = 0; sl < m->n_slots && m->embed_nets; ++sl)
+    if (m->nets[sl].n_layers && sl >= P.nel && sl < 2 * P.nel &&
+        (m->nets[sl].max_np > kNetMaxWidth || m->nets[sl].max_kp > kNetMaxWidth || m->nets[sl].xlo))
+      throw std::invalid_argument("ta_constant_gradient: embedding networks wider than 128 units are not covered");
   const int64_t nq = eam_constant_count(m);
   if (b.n_atoms == 0) {
     (void)hipMemsetAsync(grad, 0, (size_t)nq * sizeof(double), s);
@@ -2721,14 +2754,28 @@ void eam_constant_gradient(EamModel *m, const DeviceBatch &b, const double *fram
   }
   const unsigned blocks = (unsigned)((b.n_atoms + kBlock / 64 - 1) / (kBlock / 64));
   grow(m->gpartial, m->cap_gpartial, (size_t)nq * blocks + 8);
+  double *d2F = nullptr;
+  if (m->embed_nets) {
+    grow(m->gcoeff, m->cap_gcoeff, (size_t)b.n_atoms + 8);
+    d2F = m->gcoeff;
+    for (int e = 0; e < P.nel; ++e) {
+      const MlpDev &net = m->nets[slot_embed(P.nel, e)];
+      const int n_el = b.elem_start[e + 1] - b.elem_start[e];
+      if (!net.n_layers || n_el == 0) continue;
+      hipLaunchKernelGGL(scalar_net_d2_kernel, dim3((unsigned)((n_el + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, net,
+                         m->activation, b.elem_atoms + b.elem_start[e], n_el, m->rho_buf, (const double *)nullptr, d2F,
+                         (size_t)0);
+    }
+  }
+  (void)has_nets;
   bool other = false;
   for (int e = 0; e < P.nel; ++e) other = other || P.el_kind[e] != 0;
   if (other)
     hipLaunchKernelGGL(eam_const_grad_kernel<true>, dim3(blocks, (unsigned)nq), dim3(kBlock), 0, s, P, b,
-                       frame_coeff, dR, dh, m->eps, m->gpartial);
+                       frame_coeff, dR, dh, m->eps, m->tabs_dev, m->pf, m->cap_pairs, m->dF, d2F, m->gpartial);
   else
     hipLaunchKernelGGL(eam_const_grad_kernel<false>, dim3(blocks, (unsigned)nq), dim3(kBlock), 0, s, P, b,
-                       frame_coeff, dR, dh, m->eps, m->gpartial);
+                       frame_coeff, dR, dh, m->eps, m->tabs_dev, m->pf, m->cap_pairs, m->dF, d2F, m->gpartial);
   hipLaunchKernelGGL(eam_const_reduce_kernel, dim3((unsigned)nq), dim3(64), 0, s, m->gpartial, (int)blocks, grad);
 }
 

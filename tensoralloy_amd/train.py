@@ -363,7 +363,7 @@ class Trainer:
                  per_atom_loss=True, learning_rate=0.01, fd_step=1e-3, analytic=None, fixed=None,
                  pressures=None, pressure_weight=1.0, forces_method=None, l2_weight=0.0, l2_loss_weight=0.01,
                  l2_decayed=True, l2_decay_rate=0.99, l2_decay_steps=1000, max_train_steps=None,
-                 logscaled_dynamic_weight=True, **adam_kwargs):
+                 logscaled_dynamic_weight=True, train_constants=None, **adam_kwargs):
         from .engine import Engine
         rank, local_rank, world = world_from_env()
         lo, hi = shard_range(len(frames), rank, world)
@@ -398,12 +398,22 @@ class Trainer:
                        decay_steps=l2_decay_steps)
         self.max_train_steps, self.logscale = max_train_steps, logscaled_dynamic_weight
         self.method, self.per_atom_loss, self.fd_step = method, per_atom_loss, fd_step
+        # a model that mixes networks with analytic functions trains both, as the reference does (every
+        # variable of potentials/potentials.py:129-200 and of the nn functions): theta = [weights | constants]
+        specs = nn.nn_functions() if hasattr(nn, "nn_functions") else []
+        self.mixed = (not self.constants_mode and any(s is not None for s in specs) and
+                      any(s is None for s in specs)) if train_constants is None else bool(train_constants)
+        self._n_weights = None
         if self.constants_mode:
             self.theta = nn.constants()
             self.mask = nn.constant_mask(fixed)
         else:
             self.theta = flatten_weights(nn)
             self.mask = trainable_mask(nn)
+            if self.mixed:
+                self._n_weights = len(self.theta)
+                self.theta = np.concatenate([self.theta, nn.constants()])
+                self.mask = np.concatenate([self.mask, nn.constant_mask(fixed)])
         self.opt = Adam(len(self.theta), learning_rate=learning_rate, **adam_kwargs)
         self.history: List[dict] = []
 
@@ -466,6 +476,9 @@ class Trainer:
             gradient = eng.constant_gradient if self.constants_mode else eng.loss_gradient
             try:
                 grad = gradient(c, dR if second else None, dh if second else None)
+                if self.mixed:   # ... and the constants of the analytic functions beside the networks
+                    grad = np.concatenate([grad, eng.constant_gradient(c, dR if second else None,
+                                                                       dh if second else None)])
             except RuntimeError as err:
                 if not (self._eam_nets and "ta_loss_gradient" in str(err)):
                     raise
@@ -485,11 +498,19 @@ class Trainer:
                     coeff.append(sgn / (2.0 * e))
             eng.set_frames(disp)
             grad = grad + eng.energy_gradient(np.array(coeff))
+            self._resident = False
+        if self.mixed and len(grad) == self._n_weights:   # (central-difference path: the constants' part is analytic)
+            Rc = np.concatenate([a.positions @ Y[k] - u[k] for k, a in enumerate(self.frames)])
+            hc = np.array([np.asarray(a.get_cell(complete=True), dtype=np.float64) @ Y[k]
+                           for k, a in enumerate(self.frames)])
+            eng.set_frames(self.frames)
+            grad = np.concatenate([grad, eng.constant_gradient(c, Rc if second else None, hc if second else None)])
         if self.l2["l2_weight"] > 0.0 and self.l2["weight"] != 0.0 and not self.constants_mode:
-            l2, g2 = l2_regularization_loss(self.nn, self.theta, step=step, **self.l2)
+            nw = self._n_weights if self.mixed else len(self.theta)
+            l2, g2 = l2_regularization_loss(self.nn, self.theta[:nw], step=step, **self.l2)
             terms["l2"] = l2
             # every replica adds the same regulariser: the mean over ranks (step) leaves it as it is
-            grad = grad + g2
+            grad = grad + np.concatenate([g2, np.zeros(len(self.theta) - nw)])
         total = float(sum(terms.values()))
         return total, terms, grad * self.mask
 
@@ -505,6 +526,9 @@ class Trainer:
         self.theta = self.opt.step(self.theta, grad)
         if self.constants_mode:
             self.engine.update_constants(self.theta)
+        elif self.mixed:
+            self.engine.update_weights(self.theta[:self._n_weights])
+            self.engine.update_constants(self.theta[self._n_weights:])
         else:
             self.engine.update_weights(self.theta)
         self.history.append(dict(terms, total=total))
@@ -515,6 +539,9 @@ class Trainer:
             self.step()
         if self.constants_mode:
             self.nn.set_constants(self.theta)
+        elif self.mixed:
+            self.nn.weights = unflatten_weights(self.nn, self.theta[:self._n_weights])
+            self.nn.set_constants(self.theta[self._n_weights:])
         else:
             self.nn.weights = unflatten_weights(self.nn, self.theta)
         return self.history

@@ -267,7 +267,7 @@ def test_analytic_loss_gradient_matches_oracle(lib, kind):
     assert np.abs(g - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kind", ["zjw04", "alloy", "zjw04xc", "zjw04xcp", "sutton90", "be/1", "grimes", "adp", "adp_alloy"])
+@pytest.mark.parametrize("kind", ["zjw04", "alloy", "zjw04xc", "zjw04xcp", "sutton90", "be/1", "grimes", "adp", "adp_alloy", "mixed_embed_nn", "mixed_rho_phi_nn", "mixed_adp_nn"])
 def test_empirical_constant_gradient(lib, kind):
     """The reference trains the constants of its empirical potentials (potentials.py:129-163).
     `ta_constant_gradient` = d/dconstants of  sum_f c_f E_f + sum u.F + sum Y:W  (the model-dependent
@@ -297,8 +297,20 @@ def test_empirical_constant_gradient(lib, kind):
         # (a frame whose densities stay clear of the embedding thresholds: with Ni2Mo one Mo atom sits at
         # rho / rho_e = 1.15 + 6e-5 and any usable stencil straddles the branch)
         nn, frames = make_eam(["Mo", "Ni"], 6.0, adp=True), [_alloy(["Ni", "Ni", "Ni", "Mo"], rep=(2, 2, 2))]
-    else:
+    elif kind == "grimes":
         nn, frames = make_eam(["Pu"], 6.0, potential="grimes"), [fcc("Pu", a=4.6, rep=(2, 2, 2), jitter=0.08)]
+    # round 3: models that mix networks with analytic functions (the reference trains every variable of such a
+    # model, potentials.py:129-200); the networks enter the constants' gradient as plain functions
+    elif kind == "mixed_embed_nn":
+        pots = {"Ni": {"rho": "zjw04", "embed": "nn"}, "NiNi": {"phi": "zjw04"}}
+        nn, frames = make_eam(["Ni"], 6.0, potential=pots, hidden_sizes=[8]), [fcc(rep=(2, 2, 2), jitter=0.1)]
+    elif kind == "mixed_rho_phi_nn":
+        pots = {"Ni": {"rho": "nn", "embed": "zjw04"}, "Mo": {"rho": "zjw04", "embed": "zjw04"},
+                "NiNi": {"phi": "zjw04"}, "MoNi": {"phi": "nn"}, "MoMo": {"phi": "zjw04"}}
+        nn, frames = make_eam(["Mo", "Ni"], 6.0, potential=pots, hidden_sizes=[8]), [_alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))]
+    else:
+        pots = {"Ni": {"rho": "zjw04", "embed": "zjw04"}, "NiNi": {"phi": "zjw04", "dipole": "nn", "quadrupole": "mishinh"}}
+        nn, frames = make_eam(["Ni"], 6.0, adp=True, potential=pots, hidden_sizes=[8]), [fcc(rep=(2, 2, 2), jitter=0.1)]
     F = len(frames)
     c = rng.normal(0, 1, F)
     u = [rng.normal(0, 0.3, (len(a), 3)) for a in frames]
@@ -352,13 +364,6 @@ def test_empirical_constant_gradient(lib, kind):
             assert abs(grad_e[slot] - fd_e) < 2e-8 * max(abs(fd_e), 1e-3 * scale) + 1e-9, (name, grad_e[slot], fd_e)
         checked += 1
     assert checked >= 2
-    # models with nn (or tabulated) functions are refused, not approximated
-    if kind == "zjw04":
-        mixed = {"Ni": {"rho": "zjw04", "embed": "nn"}, "NiNi": {"phi": "zjw04"}}
-        with Engine(make_eam(["Ni"], 6.0, potential=mixed, hidden_sizes=[8])) as eng:
-            eng.set_frames(frames[:1])
-            with pytest.raises(ValueError):
-                eng.constant_gradient(np.ones(1), None, None)
 
 
 def test_fit_of_empirical_constants_recovers_a_teacher(lib):
@@ -596,3 +601,50 @@ def test_trainer_uses_the_analytic_pass_for_nn_eam(lib):
     tf.close()
     assert abs(la - lf) < 1e-12 * max(1.0, abs(lf))
     assert np.abs(np.asarray(ga) - np.asarray(gf)).max() < 2e-6 * max(1.0, np.abs(gf).max())
+
+
+def test_trainer_trains_weights_and_constants_of_a_mixed_model(lib):
+    """A model that mixes networks with analytic functions: the reference trains every variable
+    (potentials/potentials.py:129-200). theta = [weights | constants]; the two halves of the gradient
+    against central differences of the trainer's own loss, then a short fit that moves both."""
+    from tensoralloy_amd import Engine
+    from tensoralloy_amd.train import Trainer
+    from tests.helpers import make_eam
+    pots = {"Ni": {"rho": "zjw04", "embed": "nn"}, "NiNi": {"phi": "zjw04"}}
+    teacher = make_eam(["Ni"], 5.8, potential=pots, hidden_sizes=[8], seed=1)
+    frames = [fcc(rep=(2, 2, 2), a=a, seed=k, jitter=0.05) for k, a in enumerate((3.45, 3.55, 3.65))]
+    with Engine(teacher) as eng:
+        res = eng.evaluate(frames)
+    student = make_eam(["Ni"], 5.8, potential=pots, hidden_sizes=[8], seed=2)
+    c0 = student.constants()
+    student.set_constants(c0 * (1.0 + 0.02 * np.random.RandomState(3).randn(len(c0))))
+    tr = Trainer(student, frames, energies=[r["energy"] for r in res], forces=[r["forces"] for r in res],
+                 stresses=[r["stress"] for r in res], device=0, learning_rate=0.002, fixed={"Ni": ["r_eq"]})
+    assert tr.mixed and tr.analytic
+    nw = tr._n_weights
+    theta0 = tr.theta.copy()
+    l0, _, g = tr.loss_and_gradient()
+    assert len(g) == len(theta0) and np.abs(g[:nw]).max() > 0 and np.abs(g[nw:]).max() > 0
+
+    def loss_at(vec):
+        tr.engine.update_weights(vec[:nw])
+        tr.engine.update_constants(vec[nw:])
+        return tr.loss_and_gradient()[0]
+    live = np.flatnonzero(tr.mask * (np.abs(g) > 1e-3 * np.abs(g).max()))
+    rng = np.random.RandomState(5)
+    picks = list(rng.choice(live[live < nw], 3, replace=False)) + list(rng.choice(live[live >= nw], 3, replace=False))
+    for k in picks:
+        d = 1e-5 * max(abs(theta0[k]), 0.05)
+        tp, tm = theta0.copy(), theta0.copy()
+        tp[k] += d
+        tm[k] -= d
+        num = (loss_at(tp) - loss_at(tm)) / (2 * d)
+        assert abs(g[k] - num) < 2e-4 * max(abs(num), np.abs(g).max() * 1e-3), (k, g[k], num)
+    loss_at(theta0)
+    hist = tr.fit(60)
+    assert hist[-1]["total"] < 0.7 * hist[0]["total"]
+    assert np.abs(tr.theta[nw:] - theta0[nw:]).max() > 0 and np.abs(tr.theta[:nw] - theta0[:nw]).max() > 0
+    names = student.constant_names()
+    k_fixed = [i for i, n in enumerate(names) if n == ("Ni", "r_eq")]
+    assert all(tr.theta[nw + i] == theta0[nw + i] for i in k_fixed)
+    tr.close()
