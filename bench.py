@@ -639,6 +639,15 @@ def extra_config_rows(steps, cores):
          lambda: make_eam(["Ni"], 6.5), lambda: ni_frame(611), oracle_eam_eval),
         ("C4_ADP", "4000-atom Ni, AdpNN zjw04 + mishinh dipole / quadrupole, rc 6.5, E+F+virial",
          lambda: make_eam(["Ni"], 6.5, adp=True), lambda: ni_frame(611), oracle_eam_eval),
+        # the reference's DEFAULT EAM / ADP potentials: every function a 1x1 CNN (alloy.py:110-112,
+        # adp.py:120-124); inference through the device-built Hermite tables, checked against the oracle's
+        # exact networks
+        ("C4_nnEAM", "4000-atom Ni, EamAlloyNN with nn rho / phi / embedding (the reference's default "
+                     "potential), rc 6.5, E+F+virial",
+         lambda: make_eam(["Ni"], 6.5, potential=None), lambda: ni_frame(611), oracle_eam_eval),
+        ("C4_nnADP", "4000-atom Ni, AdpNN with nn rho / phi / embedding / dipole / quadrupole, rc 6.5, "
+                     "E+F+virial",
+         lambda: make_eam(["Ni"], 6.5, adp=True, potential=None), lambda: ni_frame(611), oracle_eam_eval),
     ]
     for key, what, mk_nn, mk_atoms, ref_fn in cases:
         try:
