@@ -47,6 +47,9 @@ void launch_descriptor_jvp(const DeviceBatch &b, int ndim, const double *J, cons
 void launch_one_hot(double *dEdG, int64_t n_atoms, int ndim, int c, hipStream_t s);
 // GRAP (ta_grap.hip)
 struct GrapModel;
+bool grap_hvp_supported(const GrapModel *);
+void launch_grap_hvp(GrapModel *, const DeviceBatch &b, double eps, const double *Dv, const double *Dd,
+                     const double *wdot, double *gv, double *gd, hipStream_t s);
 GrapModel *grap_create(const ta_model_desc *m, std::string &err);
 int grap_ndim(const GrapModel *g);
 bool grap_uses_filter_net(const GrapModel *g);
@@ -2101,18 +2104,22 @@ int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *
                        double *dW) {
   if (!h || !dF || n_dir < 0) return TA_ERR_INVALID;
   if (!h->have_batch) return fail(h, TA_ERR_INVALID, "no resident batch");
-  const bool sf_model = h->kind == TA_MODEL_SF_MLP;
+  const bool grap_model = h->kind == TA_MODEL_GRAP_MLP;
+  const bool sf_model = h->kind == TA_MODEL_SF_MLP || grap_model;  // the descriptor + MLP models
   if (sf_model) {
     if (h->filtered)
       return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: not available on a skin-filtered batch; "
                                          "ta_set_skin(h, 0) and ta_set_frames first");
+    if (grap_model && !ta::grap_hvp_supported(h->grap))
+      return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives of GRAP models exist for the "
+                                         "sf / morse / density / pexp filters, not for the filter network");
     for (const ChunkPlan &cp : h->chunks)
-      for (int iz = 0; iz < cp.nz; ++iz)
+      for (int iz = 0; iz < cp.nz && !grap_model; ++iz)
         if (cp.ch.zeta_int[iz] <= 0)
           return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: integer zetas only");
   } else if (!h->eam || !ta::eam_hvp_supported(h->eam)) {
-    return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives exist for the symmetry-function "
-                                       "models and for EAM models whose functions are of the Zjw04 family or tabulated");
+    return fail(h, TA_ERR_UNSUPPORTED, "ta_hessian_vectors: analytic second derivatives exist for the symmetry-function and GRAP "
+                                       "models and for EAM / ADP models whose functions are of the Zjw04 family, networks or tabulated");
   }
   const size_t N = (size_t)h->db.n_atoms, F = (size_t)h->db.n_frames;
   const bool unit = !dR && !dh;
@@ -2173,7 +2180,9 @@ int ta_hessian_vectors(ta_handle h, int32_t n_dir, int32_t first, const double *
                                h->train_grad.ptr + off, s, wdot);
           off += (size_t)ta::mlp_param_count(h->mlp[e]);
         }
-        if (h->sf.angular) {
+        if (grap_model) {
+          ta::launch_grap_hvp(h->grap, h->db, h->sf.eps, Dv, h->tan_dD.ptr, wdot, gv, gd, s);
+        } else if (h->sf.angular) {
           bool first_launch = true;
           for (const ChunkPlan &cp : h->chunks) {
             ta::launch_backward_hvp(h->sf, cp.ch, cp.nb, cp.ng, cp.nz, first_launch, true, h->db, Dv, h->tan_dD.ptr, wdot,

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "ta_device.h"
+#include "ta_dual.h"
 #include "ta_math.h"
 
 namespace ta {
@@ -633,6 +634,185 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
   }
 }
 
+// ---- analytic Hessian-vector products (round 3) ------------------------------------------------------
+// The tangent of g[p] = dE/dD_p along (D-dot, w-dot): this file's forward and backward expressions in dual
+// arithmetic, w = dE/dG dual (w-dot = H_mlp G-dot from the second-order MLP pass), D dual. One wavefront per
+// centre, a pair per lane: P[k][d] = sum_j H_k(r_j) M_d(u_j) (dual, LDS), A[k][d] = dE/dP[k][d] from it,
+// then per pair dE/dD = sum_d b_d M_d u + a_d (dM_d/du - deg_d M_d u) / r with a = sum_k H_k A, b = sum_k
+// H'_k A. Not a throughput kernel (no matrix cores, wavefront reductions per (k, d)): Hessians are for
+// cells of tens to hundreds of atoms. The four analytic filter families; the `nn` filter network has no
+// second derivative here and keeps the differences.
+template <typename T>
+__device__ __forceinline__ void filter_fn_t(int algo, double c0, double c1, double c2, T r, T &v, T &dv) {
+  switch (algo) {
+    case GRAP_SF: {
+      const T t = r - c1;
+      v = t_exp(-(c0 * (t * t)));
+      dv = v * (-2.0 * c0 * t);
+      break;
+    }
+    case GRAP_MORSE: {
+      const T e1 = t_exp(-(c1 * (r - c2)));
+      const T e2 = e1 * e1;
+      v = c0 * (e2 - 2.0 * e1);
+      dv = (c0 * c1) * (2.0 * e1 - 2.0 * e2);
+      break;
+    }
+    case GRAP_DENSITY: {
+      v = c0 * t_exp(-(c1 * r));
+      dv = -c1 * v;
+      break;
+    }
+    default: {
+      const T xp = t_exp(c0 * (t_log(r) - c1));
+      v = t_exp(-xp);
+      dv = v * (-c0 * xp / r);
+      break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWave) void grap_hvp_kernel(GrapParams g, DeviceBatch b, int ndim, double eps,
+                                                         const double *__restrict__ Dv,
+                                                         const double *__restrict__ Dd,
+                                                         const double *__restrict__ wdot, double *gv, double *gd) {
+  __shared__ Dual PA[kMaxFilters * kMaxComp];  // P[k][d], then A[k][d] in place
+  __shared__ Dual C0[kMaxFilters];             // new mode, moment 0: w0 sgn(P0) / (2 sqrt(P0^2 + 1e-16)) per filter
+  __shared__ unsigned long long cwl[kMaxComp];
+  __shared__ double Tl[kMaxComp * kMaxMom];
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int nel = g.nel, K = g.K, nd = g.nd;
+  const int sA = b.species[i];
+  const int32_t *seg = b.seg_start + (size_t)i * (nel + 1);
+  for (int d = lane; d < nd; d += kWave) cwl[d] = g.cw[d];
+  for (int t = lane; t < nd * kMaxMom; t += kWave) Tl[t] = g.T[t];
+  const double *wv = b.dEdG + (size_t)i * ndim, *wd = wdot + (size_t)i * ndim;
+  // a pair of this lane: geometry, filters with the cutoff folded in (H, H'), monomials; all dual
+  auto pair_fields = [&](int q, bool valid, Dual (&u)[3], Dual &inv_r, Dual (&H)[kMaxFilters], Dual (&Hp)[kMaxFilters],
+                         Dual (&M)[kMaxComp]) {
+    Dual D[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      D[c] = valid ? make_dual(Dv[4 * (size_t)q + c], Dd[4 * (size_t)q + c]) : make_dual(c == 0 ? 1.0 : 0.0);
+    const Dual r2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2] + eps;
+    const Dual r = t_sqrt(r2);
+    inv_r = 1.0 / r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[c] = D[c] * inv_r;
+    const Dual uu = r2 * g.inv_rc2;
+    Dual f = make_dual(0.0), df = make_dual(0.0);
+    if (valid && uu.v < 1.0) {
+      const double x = uu.v;
+      double fv, d1, d2;
+      cutoff_u2(g.cutoff, x, fv, d1, d2);
+      f = make_dual(fv, d1 * uu.d);
+      const Dual dfdu = make_dual(d1, d2 * uu.d);
+      df = dfdu * (2.0 * g.inv_rc2) * r;
+    }
+    for (int k = 0; k < K; ++k) {
+      Dual v, dv;
+      filter_fn_t<Dual>(g.algo, g.fp[4 * k], g.fp[4 * k + 1], g.fp[4 * k + 2], r, v, dv);
+      H[k] = v * f;
+      Hp[k] = dv * f + v * df;
+    }
+    M[0] = make_dual(valid ? 1.0 : 0.0);
+    for (int d = 1; d < nd; ++d) {
+      const unsigned long long w = cwl[d];
+      const int ex = (int)((w >> 24) & 7), ey = (int)((w >> 27) & 7);
+      const int parent = ex ? (int)((w >> 6) & 63) : (ey ? (int)((w >> 12) & 63) : (int)((w >> 18) & 63));
+      M[d] = M[parent] * (ex ? u[0] : (ey ? u[1] : u[2]));
+    }
+  };
+  for (int sb = 0; sb < nel; ++sb) {
+    const int lo = seg[sb], hi = seg[sb + 1];
+    if (lo == hi) continue;
+    const int tb = term_block(sA, sb);
+    __syncthreads();
+    for (int idx = lane; idx < K * nd; idx += kWave) PA[idx] = make_dual(0.0);
+    __syncthreads();
+    for (int first = lo; first < hi; first += kWave) {
+      const int q = first + lane;
+      const bool valid = q < hi;
+      Dual u[3], inv_r, H[kMaxFilters], Hp[kMaxFilters], M[kMaxComp];
+      pair_fields(q, valid, u, inv_r, H, Hp, M);
+      for (int k = 0; k < K; ++k)
+        for (int d = 0; d < nd; ++d) {
+          const Dual t = H[k] * M[d];
+          const double sv = wave_sum(valid ? t.v : 0.0), sd = wave_sum(valid ? t.d : 0.0);
+          if (lane == 0) PA[k * nd + d] += make_dual(sv, sd);
+        }
+    }
+    __syncthreads();
+    // A[k][d] = dE/dP[k][d] (grap_backward_kernel's expression), in place
+    const int col0 = g.col_of_m[0];
+    for (int k = lane; k < K; k += kWave) {
+      Dual c = make_dual(0.0);
+      if (col0 >= 0 && !g.legacy) {
+        const int col = (tb * K + k) * g.nf + col0;
+        const Dual w0 = make_dual(wv[col], wd[col]);
+        const Dual P0 = PA[k * nd];
+        const double sgn = P0.v > 0.0 ? 1.0 : (P0.v < 0.0 ? -1.0 : 0.0);
+        c = w0 * sgn / (2.0 * t_sqrt(P0 * P0 + 1e-16));
+      }
+      C0[k] = c;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < K * nd; idx += kWave) {
+      const int d = idx % nd, k = idx / nd;
+      Dual s = make_dual(0.0), lin = make_dual(0.0);
+      for (int m = 0; m < kMaxMom; ++m) {
+        if (m > g.max_moment) break;
+        const int cm = g.col_of_m[m];
+        if (cm < 0) continue;
+        const int col = (tb * K + k) * g.nf + cm;
+        Dual c = make_dual(wv[col], wd[col]);
+        if (m == 0) {
+          if (g.legacy) {
+            if (d == 0) lin = c;
+            continue;
+          }
+          c = C0[k];
+        }
+        s = s + c * Tl[d * kMaxMom + m];
+      }
+      PA[idx] = 2.0 * PA[idx] * s + lin;
+    }
+    __syncthreads();
+    for (int first = lo; first < hi; first += kWave) {
+      const int q = first + lane;
+      const bool valid = q < hi;
+      Dual u[3], inv_r, H[kMaxFilters], Hp[kMaxFilters], M[kMaxComp];
+      pair_fields(q, valid, u, inv_r, H, Hp, M);
+      Dual gq[3] = {make_dual(0.0), make_dual(0.0), make_dual(0.0)};
+      for (int d = 0; d < nd; ++d) {
+        Dual a = make_dual(0.0), bb = make_dual(0.0);
+        for (int k = 0; k < K; ++k) {
+          const Dual A = PA[k * nd + d];
+          a = a + A * H[k];
+          bb = bb + A * Hp[k];
+        }
+        const unsigned long long w = cwl[d];
+        const int e[3] = {(int)((w >> 24) & 7), (int)((w >> 27) & 7), (int)((w >> 30) & 7)};
+        const int par[3] = {(int)((w >> 6) & 63), (int)((w >> 12) & 63), (int)((w >> 18) & 63)};
+        const double deg = (double)(e[0] + e[1] + e[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const Dual dM = e[c] ? (double)e[c] * M[par[c]] : make_dual(0.0);
+          gq[c] = gq[c] + bb * M[d] * u[c] + a * (dM - deg * M[d] * u[c]) * inv_r;
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gv[4 * (size_t)q + c] = gq[c].v;
+          gd[4 * (size_t)q + c] = gq[c].d;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 struct GrapModel {
@@ -949,6 +1129,17 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStre
   else
     hipLaunchKernelGGL(grap_forward_kernel<kMaxComp>, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b,
                        g->Pbuf, g->ndim, eps);
+}
+
+bool grap_hvp_supported(const GrapModel *g) { return g->p.algo != GRAP_NN; }
+
+// g and its tangent for one direction (ta_hessian_vectors): Dv / Dd = the pair vectors and their tangents
+// [P][4], wdot = H_mlp G-dot [N][ndim]
+void launch_grap_hvp(GrapModel *g, const DeviceBatch &b, double eps, const double *Dv, const double *Dd,
+                     const double *wdot, double *gv, double *gd, hipStream_t s) {
+  if (b.n_atoms == 0) return;
+  hipLaunchKernelGGL(grap_hvp_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->ndim, eps, Dv, Dd,
+                     wdot, gv, gd);
 }
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {
