@@ -199,6 +199,26 @@ def test_step_and_step_view_match_the_three_calls(lib):
         assert a.list_stats()[0] > 1 and a.list_stats()[1] > 0   # both reuses and rebuilds happened
         only_e = c.step(pos, _lib.TA_WANT_ENERGY, view=True)
         assert "forces" not in only_e and abs(only_e["energy"][0] - ref["energy"][0]) < 1e-9
+    # a batch of uneven frames (groups of 16 atoms straddle the frame boundaries) and an EAM model
+    from tests.helpers import make_eam
+    frames = [fcc(rep=(3, 3, 3), seed=1), fcc(rep=(2, 3, 4), a=3.6, seed=2), fcc(rep=(3, 2, 2), seed=3)]
+    for model in (nn, make_eam(["Ni"], 6.0)):
+        with Engine(model) as a, Engine(model) as c:
+            for eng in (a, c):
+                eng.set_skin(0.5)
+                eng.set_frames(frames)
+            pos = np.concatenate([f.positions for f in frames])
+            for step in range(3):
+                pos = pos + rng.normal(0, 0.04, pos.shape)
+                a.update_positions(pos)
+                a.compute(want)
+                ref = a.fetch(want)
+                view = c.step(pos, want, view=True)
+                assert view["energy"].shape == (3,) and view["virial"].shape == (3, 3, 3)
+                assert np.abs(view["energy"] - ref["energy"]).max() < 1e-9
+                assert np.abs(view["forces"] - ref["forces"]).max() < 1e-12
+                assert np.abs(view["virial"] - ref["virial"]).max() < 1e-10
+                assert np.abs(view["atomic"] - ref["atomic"]).max() < 1e-12
 
 
 TRAIN_WORKER = r"""
