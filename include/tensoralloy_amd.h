@@ -367,7 +367,7 @@ int ta_constant_gradient(ta_handle h, const double *frame_coeff, const double *d
  * (dual-number) tangents through the analytic force kernels: exact, no step size. Available for EAM and
  * ADP models whose functions are of the Zjw04 / MishinH families, tabulated or networks (nn pair functions through
  * their tables, embedding networks by a second-derivative sweep), and (round 3) for the
- * symmetry-function + MLP models with integer zetas and the GRAP + MLP models with analytic filters (per direction: the descriptors' tangent through the
+ * symmetry-function + MLP models with integer zetas and the GRAP + MLP models (per direction: the descriptors' tangent through the
  * pair Jacobians, the MLP's Hessian-vector product, then the backward expression in dual arithmetic);
  * TA_ERR_UNSUPPORTED otherwise (the caller then differences the analytic forces). At most 65535
  * directions per call. */

@@ -640,8 +640,8 @@ __global__ __launch_bounds__(kBlock) void grap_nn_filter_kernel(GrapNet net, Dev
 // centre, a pair per lane: P[k][d] = sum_j H_k(r_j) M_d(u_j) (dual, LDS), A[k][d] = dE/dP[k][d] from it,
 // then per pair dE/dD = sum_d b_d M_d u + a_d (dM_d/du - deg_d M_d u) / r with a = sum_k H_k A, b = sum_k
 // H'_k A. Not a throughput kernel (no matrix cores, wavefront reductions per (k, d)): Hessians are for
-// cells of tens to hundreds of atoms. The four analytic filter families; the `nn` filter network has no
-// second derivative here and keeps the differences.
+// cells of tens to hundreds of atoms. The four analytic filter families in dual arithmetic; the `nn` filter
+// network through a value / first / second derivative sweep per pair (grap_net_d2).
 template <typename T>
 __device__ __forceinline__ void filter_fn_t(int algo, double c0, double c1, double c2, T r, T &v, T &dv) {
   switch (algo) {
@@ -672,8 +672,65 @@ __device__ __forceinline__ void filter_fn_t(int algo, double c0, double c1, doub
   }
 }
 
-__global__ __launch_bounds__(kWave) void grap_hvp_kernel(GrapParams g, DeviceBatch b, int ndim, double eps,
-                                                         const double *__restrict__ Dv,
+// The K filters of the `nn` algorithm with their first AND second r-derivative for one pair (second-order
+// forward mode through the 1x1 CNN, grap_nn_filter_kernel's network evaluated by one lane; analytic
+// Hessian-vector products only).
+__device__ __forceinline__ void grap_net_d2(const GrapNet &net, double r, double inv_rcov, int K, double *v,
+                                            double *v1, double *v2) {
+  double x = r, x1 = 1.0, x2 = 0.0;
+  if (net.modifier == 1) {
+    x = r * inv_rcov;
+    x1 = inv_rcov;
+  } else if (net.modifier == 2) {
+    x = exp(-r * inv_rcov);
+    x1 = -x * inv_rcov;
+    x2 = x * inv_rcov * inv_rcov;
+  }
+  double h[2][kNetMaxWidth], h1[2][kNetMaxWidth], h2[2][kNetMaxWidth];
+  int cur = 0;
+  for (int c = 0; c < net.np[0]; ++c) {  // layer 0: one input
+    const double wk = net.w[0][c];
+    const double z = fma(wk, x, net.b[0][c]), z1 = wk * x1, z2 = wk * x2;
+    double a = z, da = 1.0, d2a = 0.0;
+    if (net.L > 1) activation_fn2(net.act, z, a, da, d2a);
+    h[0][c] = a;
+    h1[0][c] = da * z1;
+    h2[0][c] = d2a * z1 * z1 + da * z2;
+  }
+  for (int l = 1; l < net.L; ++l) {
+    const int kp = net.np[l - 1], np = net.np[l], nxt = cur ^ 1;
+    const bool last = l == net.L - 1;
+    for (int n = 0; n < np; ++n) {
+      double z = net.b[l][n], z1 = 0.0, z2 = 0.0;
+      for (int k = 0; k < kp; ++k) {
+        const double w = net.w[l][(size_t)k * np + n];
+        z = fma(w, h[cur][k], z);
+        z1 = fma(w, h1[cur][k], z1);
+        z2 = fma(w, h2[cur][k], z2);
+      }
+      double a = z, da = 1.0, d2a = 0.0;
+      if (!last) activation_fn2(net.act, z, a, da, d2a);
+      double o = a, o1 = da * z1, o2 = d2a * z1 * z1 + da * z2;
+      if (!last && net.res[l]) {  // x = act(w x + b) + x
+        o += h[cur][n];
+        o1 += h1[cur][n];
+        o2 += h2[cur][n];
+      }
+      h[nxt][n] = o;
+      h1[nxt][n] = o1;
+      h2[nxt][n] = o2;
+    }
+    cur = nxt;
+  }
+  for (int k = 0; k < K; ++k) {
+    v[k] = h[cur][k];
+    v1[k] = h1[cur][k];
+    v2[k] = h2[cur][k];
+  }
+}
+
+__global__ __launch_bounds__(kWave) void grap_hvp_kernel(GrapParams g, GrapNet net, DeviceBatch b, int ndim,
+                                                         double eps, const double *__restrict__ Dv,
                                                          const double *__restrict__ Dd,
                                                          const double *__restrict__ wdot, double *gv, double *gd) {
   __shared__ Dual PA[kMaxFilters * kMaxComp];  // P[k][d], then A[k][d] in place
@@ -710,11 +767,21 @@ __global__ __launch_bounds__(kWave) void grap_hvp_kernel(GrapParams g, DeviceBat
       const Dual dfdu = make_dual(d1, d2 * uu.d);
       df = dfdu * (2.0 * g.inv_rc2) * r;
     }
-    for (int k = 0; k < K; ++k) {
-      Dual v, dv;
-      filter_fn_t<Dual>(g.algo, g.fp[4 * k], g.fp[4 * k + 1], g.fp[4 * k + 2], r, v, dv);
-      H[k] = v * f;
-      Hp[k] = dv * f + v * df;
+    if (g.algo == GRAP_NN) {
+      double nv[kMaxFilters], n1[kMaxFilters], n2[kMaxFilters];
+      grap_net_d2(net, r.v, net.inv_rcov[sA], K, nv, n1, n2);
+      for (int k = 0; k < K; ++k) {
+        const Dual v = make_dual(nv[k], n1[k] * r.d), dv = make_dual(n1[k], n2[k] * r.d);
+        H[k] = v * f;
+        Hp[k] = dv * f + v * df;
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        Dual v, dv;
+        filter_fn_t<Dual>(g.algo, g.fp[4 * k], g.fp[4 * k + 1], g.fp[4 * k + 2], r, v, dv);
+        H[k] = v * f;
+        Hp[k] = dv * f + v * df;
+      }
     }
     M[0] = make_dual(valid ? 1.0 : 0.0);
     for (int d = 1; d < nd; ++d) {
@@ -1131,15 +1198,15 @@ void launch_grap_forward(GrapModel *g, const DeviceBatch &b, double eps, hipStre
                        g->Pbuf, g->ndim, eps);
 }
 
-bool grap_hvp_supported(const GrapModel *g) { return g->p.algo != GRAP_NN; }
+bool grap_hvp_supported(const GrapModel *g) { return g->p.algo != GRAP_NN || g->p.K <= kMaxFilters; }
 
 // g and its tangent for one direction (ta_hessian_vectors): Dv / Dd = the pair vectors and their tangents
 // [P][4], wdot = H_mlp G-dot [N][ndim]
 void launch_grap_hvp(GrapModel *g, const DeviceBatch &b, double eps, const double *Dv, const double *Dd,
                      const double *wdot, double *gv, double *gd, hipStream_t s) {
   if (b.n_atoms == 0) return;
-  hipLaunchKernelGGL(grap_hvp_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, b, g->ndim, eps, Dv, Dd,
-                     wdot, gv, gd);
+  hipLaunchKernelGGL(grap_hvp_kernel, dim3((unsigned)b.n_atoms), dim3(kWave), 0, s, g->p, g->net, b, g->ndim, eps, Dv,
+                     Dd, wdot, gv, gd);
 }
 
 void launch_grap_backward(GrapModel *g, const DeviceBatch &b, hipStream_t s) {

@@ -163,13 +163,14 @@ def test_moment_tensors_of_rank_4_and_5(lib, tmp_path, mm):
     assert np.abs(calc.get_forces(atoms) - o["forces"]).max() < F_TOL
 
 
-@pytest.mark.parametrize("kind", ["pexp_default", "sf_binary_minmax", "morse_legacy", "density_rank5", "nn_refused"])
+@pytest.mark.parametrize("kind", ["pexp_default", "sf_binary_minmax", "morse_legacy", "density_rank5", "nn_filter",
+                                  "nn_filter_modifier"])
 def test_analytic_hessian_vectors_of_grap_models(lib, kind):
     """Round 3: `ta_hessian_vectors` for GRAP + MLP models (ta_grap.hip::grap_hvp_kernel: the forward /
     backward expressions in dual arithmetic; replaces tf.hessians, nn/basic.py:411-421, and the cell
     derivative of the virial, nn/constraint/elastic.py:24-44) against central differences of the GPU's
     own analytic forces and virials along random directions of positions and cell, plus symmetry and
-    the acoustic sum rule of the Hessian. The filter network (`nn`) has no second derivative: refused."""
+    the acoustic sum rule of the Hessian; the four analytic filter families and the filter network (`nn`)."""
     from tensoralloy_amd import Atoms, Engine
     if kind == "pexp_default":
         nn, atoms = make_grap_nn(["Ni"], 6.0, [32, 32], moment_tensors=[0, 1, 2, 3]), fcc(rep=(2, 2, 2), seed=3, jitter=0.1)
@@ -186,13 +187,12 @@ def test_analytic_hessian_vectors_of_grap_models(lib, kind):
         nn = make_grap_nn(["Ni"], 5.0, [16], "density", {"A": [1.0], "beta": [1.0, 2.0, 3.0, 4.0], "re": [4.0]},
                           moment_tensors=[0, 1, 2, 3, 4, 5], param_space_method="cross")
         atoms = fcc(rep=(2, 2, 2), seed=5, jitter=0.1)
-    else:
-        nn, atoms = make_grap_nn(["Ni"], 6.0, [16], "nn", moment_tensors=[0, 1, 2]), fcc(rep=(2, 2, 2), seed=3)
-        with Engine(nn) as eng:
-            eng.set_frames([atoms])
-            with pytest.raises(ValueError, match="filter network"):
-                eng.hessian_vectors()
-        return
+    elif kind == "nn_filter":     # the filter network: second r-derivative by a per-pair sweep (grap_net_d2)
+        nn, atoms = make_grap_nn(["Ni"], 6.0, [16], "nn", moment_tensors=[0, 1, 2]), fcc(rep=(2, 2, 2), seed=3, jitter=0.1)
+    else:                         # ... with its input modifier exp(-r / rcov) and two elements
+        nn = make_grap_nn(["Mo", "Ni"], 6.0, [16], "nn", {"hidden_sizes": [32, 32], "num_filters": 8, "h_abck_modifier": 2},
+                          moment_tensors=[0, 1, 2, 3])
+        atoms = _alloy(["Ni", "Ni", "Mo"], rep=(2, 2, 2))
     n = len(atoms)
     h = np.asarray(atoms.get_cell(complete=True), dtype=float)
     rng = np.random.RandomState(2)
